@@ -1,0 +1,318 @@
+/*
+ * hymeta_hip.h -- C ABI of libhymeta_hip.so: the Hymeta hybrid-attention hot
+ * path as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (FAndromedA/vllm-hymeta) has no FFI of its own: its boundary
+ * for this path is a set of Python callables that wrap Triton / flash-attn /
+ * vLLM device code.  Each entry point below replaces one of those callables
+ * and cites it (path:line under the reference tree).  The Python package
+ * vllm_hymeta binds these symbols with ctypes and keeps the reference's
+ * function names and argument meaning above them.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer owned by the caller; nothing is
+ *    allocated, freed or retained by the library.
+ *  - Strides are in ELEMENTS of the tensor's dtype; the innermost (head_dim)
+ *    dimension must be contiguous.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *    work is enqueued on it and nothing synchronises with the host, so every
+ *    call may be captured into a HIP graph.
+ *  - Return value: HYMETA_OK (0) or a negative error code; no exception ever
+ *    crosses the boundary.  hymeta_strerror() names a code.
+ *  - Activations, KV cache and (by default) the recurrent state are bf16;
+ *    accumulation is fp32.
+ */
+#ifndef HYMETA_HIP_H
+#define HYMETA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HYMETA_ABI_VERSION 1
+
+typedef void* hymeta_stream_t;
+
+enum hymeta_status {
+  HYMETA_OK = 0,
+  HYMETA_ERR_INVALID_ARG = -1,  /* null pointer, negative size, bad stride */
+  HYMETA_ERR_UNSUPPORTED = -2,  /* shape / dtype / mode the kernels do not cover */
+  HYMETA_ERR_WORKSPACE = -3,    /* workspace missing or too small */
+  HYMETA_ERR_LAUNCH = -4        /* hipGetLastError() != hipSuccess after launch */
+};
+
+enum hymeta_dtype { HYMETA_BF16 = 0, HYMETA_F32 = 1 };
+
+/* Fused gate prologue applied to the raw projections before the recurrence. */
+enum hymeta_gate_mode {
+  /* q, k, g are used as given (the reference kernel-level contract). */
+  HYMETA_GATE_NONE = 0,
+  /* Hymeta-7B: q = relu(q), k = relu(k), g = logsigmoid(g) / gate_normalizer
+   * (vllm_hymeta/model_for_7B/gla_attention.py:251-262). */
+  HYMETA_GATE_7B = 1,
+  /* Hymeta-70B "first" layers: q = relu(q), k~ = sigmoid(float(k)),
+   * k = min(k~, gate_clamp), g = log(1 - k), k -> bf16; the g input is ignored
+   * (vllm_hymeta/models/modeling_hymeta.py:611-619). */
+  HYMETA_GATE_70B_CLAMP = 2,
+  /* Hymeta-70B other layers: k~ = sigmoid(float(k)), gl = 1 - (1 - lb) * k~,
+   * k = 1 - gl, g = log(gl), k -> bf16, with lb = lower_bound[head, :]
+   * (vllm_hymeta/models/modeling_hymeta.py:620-629). */
+  HYMETA_GATE_70B_LOWER_BOUND = 3
+};
+
+const char* hymeta_strerror(int code);
+int hymeta_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * GLA single-token decode step with slot-indexed in-place state.
+ * Replaces my_fused_recurrent_fwd_kernel + MyFusedRecurrentFunction.forward
+ * (vllm_hymeta/models/my_fused_recurrent.py:8-119; 7B variant
+ * vllm_hymeta/model_for_7B/my_fused_recurrent.py:9-119), reached through
+ * my_fused_recurrent_gla (vllm_hymeta/models/my_fused_recurrent_gla.py:8-23).
+ *
+ * Per (sequence b, q-head h), kv-head j = h / (num_heads / num_kv_heads):
+ *   S  = state[slot_idx[b], h]                       (Dk x Dv, row-major)
+ *   S' = bf16(k_j * v_j^T) + exp(g_j)[:,None] * S    (fp32)
+ *   out[b,h,:] = sum_dk (scale * q[b,h,dk]) * S'[dk,:]
+ *   state[slot_idx[b], h] = S'  (rounded to state_dtype)
+ * slot_idx[b] == -1 skips sequence b (state and out untouched).
+ * Optional fused prologue (gate_mode) and epilogue (per-head RMS norm over Dv
+ * with weight out_norm_weight[Dv] and out_norm_eps, the g_norm of
+ * vllm_hymeta/model_for_7B/gla_attention.py:233).
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_gla_decode_args {
+  const void* q;            /* bf16 [batch, num_heads,    head_dim] */
+  const void* k;            /* bf16 [batch, num_kv_heads, head_dim] */
+  const void* v;            /* bf16 [batch, num_kv_heads, head_dim] */
+  const void* g;            /* g_dtype [batch, num_kv_heads, head_dim]; may be NULL for HYMETA_GATE_70B_* */
+  void* out;                /* bf16 [batch, num_heads, head_dim] */
+  void* state;              /* state_dtype [slots, num_heads, head_dim, head_dim] */
+  const int32_t* slot_idx;  /* [batch] */
+  const float* lower_bound;     /* fp32 [num_heads, head_dim], HYMETA_GATE_70B_LOWER_BOUND only */
+  const void* out_norm_weight;  /* bf16 [head_dim] or NULL (no epilogue norm) */
+  int32_t batch;
+  int32_t num_heads;
+  int32_t num_kv_heads;
+  int32_t head_dim;         /* 128 */
+  int64_t q_stride_b, q_stride_h;
+  int64_t k_stride_b, k_stride_h;
+  int64_t v_stride_b, v_stride_h;
+  int64_t g_stride_b, g_stride_h;
+  int64_t out_stride_b, out_stride_h;
+  int64_t state_stride_slot, state_stride_h;  /* the (Dk, Dv) block itself is contiguous */
+  int32_t g_dtype;          /* enum hymeta_dtype */
+  int32_t state_dtype;      /* enum hymeta_dtype */
+  int32_t gate_mode;        /* enum hymeta_gate_mode */
+  float scale;              /* <= 0 selects head_dim^-0.5 */
+  float gate_normalizer;    /* HYMETA_GATE_7B, 16 in the reference */
+  float gate_clamp;         /* HYMETA_GATE_70B_CLAMP, 0.95 in the reference */
+  float out_norm_eps;
+} hymeta_gla_decode_args;
+
+int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * GLA chunked prefill over ALL prefill sequences of a step in one launch.
+ * Replaces the per-sequence Python loop around fla.ops.gla.fused_chunk_gla
+ * (vllm_hymeta/models/modeling_hymeta.py:470-529 for 70B;
+ * vllm_hymeta/model_for_7B/gla_attention.py:179-221 for 7B), including the
+ * state read (:488), the first-chunk choice of initial state (:501-504), the
+ * write-back of the final state (:528) and, through context_lens, the slot
+ * zeroing of vllm_hymeta/models/modeling_hymeta.py:1202-1227.
+ *
+ * Sequence i owns tokens cu_seqlens[i] .. cu_seqlens[i+1]-1 and state slot
+ * slot_idx[i] (-1 skips it).  Its initial state is
+ *   context_lens == NULL or context_lens[i] != 0 : state[slot]
+ *   context_lens[i] == 0, meta_state != NULL     : meta_state[h]   (70B)
+ *   context_lens[i] == 0, meta_state == NULL     : zeros           (7B)
+ * Tokens: S_t = diag(exp g_t) S_{t-1} + k_t^T v_t ; o_t = (scale q_t) S_t.
+ * The final state is stored to state[slot] rounded to state_dtype.
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_gla_prefill_args {
+  const void* q;            /* bf16 [total_tokens, num_heads,    head_dim] */
+  const void* k;            /* bf16 [total_tokens, num_kv_heads, head_dim] */
+  const void* v;            /* bf16 [total_tokens, num_kv_heads, head_dim] */
+  const void* g;            /* g_dtype [total_tokens, num_kv_heads, head_dim] */
+  void* out;                /* bf16 [total_tokens, num_heads, head_dim] */
+  void* state;              /* state_dtype [slots, num_heads, head_dim, head_dim] */
+  const int32_t* slot_idx;      /* [num_seqs] */
+  const int32_t* cu_seqlens;    /* [num_seqs + 1] */
+  const int32_t* context_lens;  /* [num_seqs] or NULL */
+  const void* meta_state;       /* state_dtype [num_heads, head_dim, head_dim] or NULL */
+  const float* lower_bound;     /* as in hymeta_gla_decode_args */
+  const void* out_norm_weight;  /* as in hymeta_gla_decode_args */
+  int32_t num_seqs;
+  int32_t total_tokens;
+  int32_t max_seqlen;       /* upper bound on any sequence length in this call */
+  int32_t num_heads;
+  int32_t num_kv_heads;
+  int32_t head_dim;         /* 128 */
+  int64_t q_stride_t, q_stride_h;
+  int64_t k_stride_t, k_stride_h;
+  int64_t v_stride_t, v_stride_h;
+  int64_t g_stride_t, g_stride_h;
+  int64_t out_stride_t, out_stride_h;
+  int64_t state_stride_slot, state_stride_h;
+  int64_t meta_state_stride_h;
+  int32_t g_dtype;
+  int32_t state_dtype;
+  int32_t gate_mode;
+  float scale;
+  float gate_normalizer;
+  float gate_clamp;
+  float out_norm_eps;
+} hymeta_gla_prefill_args;
+
+int hymeta_gla_prefill_varlen(const hymeta_gla_prefill_args* args, hymeta_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Paged KV write.  Replaces torch.ops._C_cache_ops.reshape_and_cache_flash as
+ * called at vllm_hymeta/attention/meta_attention.py:790-799 (kv_cache_dtype
+ * "auto": a byte copy).  Token t goes to
+ *   cache[slot / block_size, slot % block_size, :, :],  slot = slot_mapping[t];
+ * a negative slot (PAD_SLOT_ID) writes nothing.  Bit-exact.
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_reshape_and_cache_args {
+  const void* key;          /* [num_tokens, num_kv_heads, head_dim] */
+  const void* value;
+  void* key_cache;          /* [num_blocks, block_size, num_kv_heads, head_dim] */
+  void* value_cache;
+  const int64_t* slot_mapping;  /* [num_tokens] */
+  int32_t num_tokens;
+  int32_t num_kv_heads;
+  int32_t head_dim;
+  int32_t block_size;
+  int32_t elem_bytes;       /* 2 for bf16 / fp16 */
+  int64_t num_blocks;       /* slots >= num_blocks * block_size are skipped as out of range */
+  int64_t key_stride_t, key_stride_h;
+  int64_t value_stride_t, value_stride_h;
+  int64_t cache_stride_block, cache_stride_pos, cache_stride_h;  /* same for both caches */
+} hymeta_reshape_and_cache_args;
+
+int hymeta_reshape_and_cache(const hymeta_reshape_and_cache_args* args, hymeta_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Single-query paged decode attention: sliding window over the paged real
+ * keys plus dense attention over the always-visible meta keys, one softmax.
+ * Replaces FlashAttentionWithMetaToken.forward
+ * (vllm_hymeta/attention/fa_kernel_metatoken.py:124-194), i.e. the sequence
+ * flash_attn fwd_kvcache (:157-168) + _flash_attn_forward over the meta keys
+ * (:174-188) + _update_out_and_lse (:110-122), as dispatched from
+ * vllm_hymeta/attention/meta_attention.py:954-981.  With num_meta == 0 it is
+ * the stock paged sliding-window decode of the 7B SWA layer
+ * (vllm_hymeta/model_for_7B/modeling_gla_swa.py:193-218).
+ *
+ * Sequence b has cache_seqlens[b] keys, the decoded token's own key included
+ * (written beforehand by hymeta_reshape_and_cache); key position p lives at
+ * cache[block_tables[b, p / block_size], p % block_size].  The query sits at
+ * position L-1 and sees positions max(0, L-1-window_left) .. L-1
+ * (window_left < 0: all), plus every meta key.
+ *
+ * Split-KV: the key range of a sequence is cut into at most `num_splits`
+ * parts handled by different workgroups; parts are merged by a second kernel
+ * through `workspace`.  hymeta_meta_swa_paged_decode_workspace_bytes() gives
+ * the size needed for (batch, num_heads, head_dim, num_splits).
+ * num_splits <= 0 lets the library choose from batch, num_kv_heads and
+ * max_seqlen_k; pass the same value to the size query.
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_paged_decode_args {
+  const void* q;            /* bf16 [batch, num_heads, head_dim] */
+  void* out;                /* bf16 [batch, num_heads, head_dim] */
+  const void* key_cache;    /* bf16 [num_blocks, block_size, num_kv_heads, head_dim] */
+  const void* value_cache;
+  const int32_t* block_tables;   /* [batch, max_blocks_per_seq] */
+  const int32_t* cache_seqlens;  /* [batch] */
+  const void* meta_key;     /* bf16 [num_meta, num_kv_heads, head_dim] or NULL */
+  const void* meta_value;
+  void* workspace;
+  size_t workspace_bytes;
+  int32_t batch;
+  int32_t num_heads;
+  int32_t num_kv_heads;
+  int32_t head_dim;         /* 128 */
+  int32_t block_size;       /* multiple of 16 */
+  int32_t max_blocks_per_seq;
+  int32_t num_meta;         /* multiple of 32 (128 in the reference) or 0 */
+  int32_t window_left;      /* flash-attn left window; < 0 = unbounded */
+  int32_t max_seqlen_k;     /* upper bound on cache_seqlens; <= 0: max_blocks_per_seq * block_size */
+  int32_t num_splits;
+  int64_t q_stride_b, q_stride_h;
+  int64_t out_stride_b, out_stride_h;
+  int64_t cache_stride_block, cache_stride_pos, cache_stride_h;
+  int64_t block_table_stride;
+  int64_t meta_stride_t, meta_stride_h;
+  float scale;              /* <= 0 selects head_dim^-0.5 */
+} hymeta_paged_decode_args;
+
+size_t hymeta_meta_swa_paged_decode_workspace_bytes(int32_t batch, int32_t num_heads,
+                                                    int32_t head_dim, int32_t num_splits);
+int hymeta_meta_swa_paged_decode_splits(int32_t batch, int32_t num_kv_heads,
+                                        int32_t max_seqlen_k, int32_t window_left,
+                                        int32_t num_meta);
+int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args, hymeta_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Varlen prefill attention: causal sliding window over the real keys plus
+ * dense attention over the meta keys, one softmax; optional meta-query rows.
+ * Replaces FlashAttentionVarlenWithMetaToken.forward
+ * (vllm_hymeta/attention/fa_kernel_metatoken.py:198-285): the sequence
+ * _flash_attn_varlen_forward (:235-253) + _flash_attn_forward over the meta
+ * keys (:261-275) + _update_out_and_lse (:277) + the concat that puts the
+ * meta-query rows first (:283); dispatched from
+ * vllm_hymeta/attention/meta_attention.py:866-884 (no cache) and :900-919 /
+ * :933-953 (through the block table).  Semantics as the dense-mask
+ * naive_metatoken_flash_attn (:377-410).
+ *
+ * Sequence i: queries cu_seqlens_q[i] .. cu_seqlens_q[i+1]-1; keys either
+ *  - un-paged: rows cu_seqlens_k[i] .. cu_seqlens_k[i+1]-1 of key/value, or
+ *  - paged (block_tables != NULL): seq_lens_k[i] positions read through
+ *    block_tables[i] from key_cache/value_cache (chunk already written).
+ * Query r of Lq sits at position Lk - Lq + r and sees positions
+ * [pos - window_left, pos] (window_left < 0: [0, pos]) and every meta key.
+ * Output rows: if meta_query != NULL, rows 0..num_meta-1 are the meta
+ * queries (they see the meta keys only), followed by the real rows.
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_swa_prefill_args {
+  const void* q;            /* bf16 [total_q, num_heads, head_dim] */
+  const void* key;          /* bf16 [total_k, num_kv_heads, head_dim] (un-paged) or NULL */
+  const void* value;
+  const void* key_cache;    /* paged form, as in hymeta_paged_decode_args, or NULL */
+  const void* value_cache;
+  const int32_t* block_tables;  /* [num_seqs, max_blocks_per_seq] or NULL */
+  const int32_t* cu_seqlens_q;  /* [num_seqs + 1] */
+  const int32_t* cu_seqlens_k;  /* [num_seqs + 1], un-paged form */
+  const int32_t* seq_lens_k;    /* [num_seqs], paged form */
+  const void* meta_query;   /* bf16 [num_meta, num_heads, head_dim] or NULL */
+  const void* meta_key;     /* bf16 [num_meta, num_kv_heads, head_dim] or NULL */
+  const void* meta_value;
+  void* out;                /* bf16 [(num_meta if meta_query) + total_q, num_heads, head_dim] */
+  int32_t num_seqs;
+  int32_t total_q;
+  int32_t max_seqlen_q;     /* upper bound on any query length in this call */
+  int32_t num_heads;
+  int32_t num_kv_heads;
+  int32_t head_dim;         /* 128 */
+  int32_t num_meta;         /* multiple of 32 or 0 */
+  int32_t window_left;
+  int32_t block_size;
+  int32_t max_blocks_per_seq;
+  int64_t q_stride_t, q_stride_h;
+  int64_t k_stride_t, k_stride_h;
+  int64_t v_stride_t, v_stride_h;
+  int64_t out_stride_t, out_stride_h;
+  int64_t cache_stride_block, cache_stride_pos, cache_stride_h;
+  int64_t block_table_stride;
+  int64_t meta_q_stride_t, meta_q_stride_h;
+  int64_t meta_stride_t, meta_stride_h;
+  float scale;
+} hymeta_swa_prefill_args;
+
+int hymeta_meta_swa_prefill(const hymeta_swa_prefill_args* args, hymeta_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYMETA_HIP_H */

@@ -1,0 +1,147 @@
+"""GLA decode kernel vs the CPU restatement, through the C ABI (ctypes)."""
+import pytest
+import torch
+
+from _util import assert_bf16_close, assert_bf16_ulp, gen, randn_bf16
+
+pytestmark = pytest.mark.gpu
+
+D = 128
+
+
+def _inputs(seed, B, H, Hkv, g_dtype, slots):
+    g_ = gen(seed)
+    q = randn_bf16(g_, B, H, D)
+    k = randn_bf16(g_, B, Hkv, D)
+    v = randn_bf16(g_, B, Hkv, D)
+    # log-decay in (-0.2, 0): logsigmoid(N(0,1)) / 16, as the 7B gate produces
+    g = (torch.nn.functional.logsigmoid(torch.randn(B, Hkv, D, generator=g_)) / 16).to(g_dtype)
+    state = randn_bf16(g_, slots, H, D, D, scale=0.1)
+    return q, k, v, g, state
+
+
+@pytest.mark.parametrize("B,H,Hkv,g_dtype", [
+    (3, 4, 4, torch.float32),     # 70B-style: k/v/g already per q-head, fp32 gate
+    (3, 28, 4, torch.bfloat16),   # 7B: GQA 7:1, bf16 gate
+    (5, 7, 1, torch.float32),     # 70B TP=4 shard
+    (40, 28, 4, torch.bfloat16),  # >= 1024 (seq, head) units: unsplit kernel
+])
+def test_gla_decode_steps(B, H, Hkv, g_dtype):
+    from oracle import gla_decode_step_ref
+    from vllm_hymeta import hip_ops
+
+    slots = B + 2
+    q, k, v, g, state = _inputs(0, B, H, Hkv, g_dtype, slots)
+    perm = torch.randperm(slots, generator=gen(1))[:B].to(torch.int32)
+    perm[1] = -1  # one padded sequence
+    state_ref = state.clone()
+    state_dev = state.cuda()
+    slot_dev = perm.cuda()
+    for step in range(4):
+        g_ = gen(100 + step)
+        q = randn_bf16(g_, B, H, D)
+        k = randn_bf16(g_, B, Hkv, D)
+        v = randn_bf16(g_, B, Hkv, D)
+        o_ref = gla_decode_step_ref(q, k, v, g, state_ref, perm)
+        out = torch.full((B, H, D), 7.0, dtype=torch.bfloat16, device="cuda")
+        hip_ops.gla_decode(q.cuda(), k.cuda(), v.cuda(), g.cuda(), state_dev, slot_dev, out=out)
+        torch.cuda.synchronize()
+        live = perm >= 0
+        assert_bf16_close(out.cpu()[live], o_ref[live], f"gla_decode step {step}")
+        # skipped sequence: output row untouched
+        assert (out.cpu()[~live] == 7.0).all()
+        assert_bf16_ulp(state_dev.cpu(), state_ref, f"gla state after step {step}")
+    # untouched slots are bit-identical to the initial state
+    used = set(int(s) for s in perm if s >= 0)
+    for s in range(slots):
+        if s not in used:
+            assert torch.equal(state_dev.cpu()[s], state[s])
+
+
+def test_gla_decode_strided_views_and_fp32_state():
+    """q/k/v as views into one fused projection buffer; fp32 state option."""
+    from oracle import gla_decode_step_ref
+    from vllm_hymeta import hip_ops
+
+    B, H, Hkv = 4, 28, 4
+    g_ = gen(3)
+    qkv = randn_bf16(g_, B, (H + 2 * Hkv) * D)
+    q = qkv[:, : H * D].view(B, H, D)
+    k = qkv[:, H * D:(H + Hkv) * D].view(B, Hkv, D)
+    v = qkv[:, (H + Hkv) * D:].view(B, Hkv, D)
+    g = (torch.nn.functional.logsigmoid(torch.randn(B, Hkv, D, generator=g_)) / 16).to(torch.bfloat16)
+    state = (torch.randn(B, H, D, D, generator=g_) * 0.1)
+    slot = torch.arange(B, dtype=torch.int32)
+    ref_state = state.clone()
+    o_ref = gla_decode_step_ref(q, k, v, g, ref_state, slot)
+    qkv_d = qkv.cuda()
+    qd = qkv_d[:, : H * D].view(B, H, D)
+    kd = qkv_d[:, H * D:(H + Hkv) * D].view(B, Hkv, D)
+    vd = qkv_d[:, (H + Hkv) * D:].view(B, Hkv, D)
+    sd = state.cuda()
+    out = hip_ops.gla_decode(qd, kd, vd, g.cuda(), sd, slot.cuda())
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), o_ref, "gla_decode strided")
+    assert torch.allclose(sd.cpu(), ref_state, rtol=1e-5, atol=1e-6)
+
+
+def test_gla_decode_fused_7b_gate_and_norm():
+    """Fused prologue (relu, logsigmoid/16) and epilogue (per-head RMS norm)."""
+    from oracle import gla_decode_step_ref
+    from oracle.layers import gate_7b_ref, rms_norm_ref
+    from vllm_hymeta import hip_ops, _C
+
+    B, H, Hkv = 6, 28, 4
+    g_ = gen(5)
+    q, k, v = randn_bf16(g_, B, H, D), randn_bf16(g_, B, Hkv, D), randn_bf16(g_, B, Hkv, D)
+    gk = randn_bf16(g_, B, Hkv, D, scale=2.0)
+    w = (1 + 0.1 * torch.randn(D, generator=g_)).to(torch.bfloat16)
+    state = randn_bf16(g_, B, H, D, D, scale=0.1)
+    slot = torch.arange(B, dtype=torch.int32)
+    qg, kg, gg = gate_7b_ref(q, k, gk)
+    ref_state = state.clone()
+    o_ref = rms_norm_ref(gla_decode_step_ref(qg, kg, v, gg, ref_state, slot), w, 1e-6)
+    sd = state.cuda()
+    out = hip_ops.gla_decode(q.cuda(), k.cuda(), v.cuda(), gk.cuda(), sd, slot.cuda(),
+                             gate_mode=_C.GATE_7B, out_norm_weight=w.cuda(), out_norm_eps=1e-6)
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), o_ref, "gla_decode fused 7B gate + g_norm", rel=8e-3)
+    assert_bf16_ulp(sd.cpu(), ref_state, "state (fused 7B gate)", ulps=2)
+
+
+@pytest.mark.parametrize("first_layer", [True, False])
+def test_gla_decode_fused_70b_gate(first_layer):
+    from oracle import gla_decode_step_ref
+    from oracle.layers import gate_70b_ref
+    from vllm_hymeta import hip_ops, _C
+
+    B, H, Hkv = 5, 7, 1
+    g_ = gen(9)
+    q, k, v = randn_bf16(g_, B, H, D), randn_bf16(g_, B, Hkv, D), randn_bf16(g_, B, Hkv, D)
+    lb = torch.rand(H, D, generator=g_) * 0.5
+    state = randn_bf16(g_, B, H, D, D, scale=0.1)
+    slot = torch.arange(B, dtype=torch.int32)
+    k_rep = k.repeat_interleave(H // Hkv, dim=1)
+    v_rep = v.repeat_interleave(H // Hkv, dim=1)
+    qg, kg, gg = gate_70b_ref(q, k_rep, lb, first_layer)
+    ref_state = state.clone()
+    o_ref = gla_decode_step_ref(qg, kg, v_rep, gg, ref_state, slot)
+    sd = state.cuda()
+    mode = _C.GATE_70B_CLAMP if first_layer else _C.GATE_70B_LOWER_BOUND
+    out = hip_ops.gla_decode(q.cuda(), k.cuda(), v.cuda(), None, sd, slot.cuda(), gate_mode=mode,
+                             lower_bound=lb.cuda())
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), o_ref, "gla_decode fused 70B gate")
+    assert_bf16_ulp(sd.cpu(), ref_state, "state (fused 70B gate)", ulps=2)
+
+
+def test_gla_decode_rejects_bad_arguments():
+    from vllm_hymeta import hip_ops
+
+    q = torch.zeros(2, 4, 64, dtype=torch.bfloat16, device="cuda")  # head_dim 64 unsupported
+    st = torch.zeros(2, 4, 64, 64, dtype=torch.bfloat16, device="cuda")
+    slot = torch.zeros(2, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError):
+        hip_ops.gla_decode(q, q, q, q, st, slot)
+    with pytest.raises(ValueError):
+        hip_ops.gla_decode(q.float(), q, q, q, st, slot)

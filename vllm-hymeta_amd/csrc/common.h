@@ -1,0 +1,54 @@
+// Shared device helpers for the gfx950 kernels of libhymeta_hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hymeta_hip.h"
+
+namespace hymeta {
+
+constexpr int kWave = 64;        // CDNA wavefront width
+constexpr int kHeadDim = 128;    // the only head size the Hymeta models use
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));  // MFMA A/B fragment (8 bf16)
+
+__device__ __forceinline__ float bf2f(uint16_t x) {
+  return __uint_as_float(static_cast<uint32_t>(x) << 16);
+}
+
+// Round-to-nearest-even fp32 -> bf16 (plain cast: v_cvt_pk_bf16_f32, NaN-safe).
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  __bf16 b = static_cast<__bf16>(f);
+  return __builtin_bit_cast(uint16_t, b);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16);
+}
+
+__device__ __forceinline__ float bf16_round(float f) { return bf2f(f2bf(f)); }
+
+// Low / high bf16 of a packed dword as fp32.
+__device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ u32x4 ld16(const void* p) {
+  return *reinterpret_cast<const u32x4*>(p);
+}
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+__device__ __forceinline__ float logsigmoidf(float x) {
+  // log(sigmoid(x)) = min(x, 0) - log1p(exp(-|x|))
+  return fminf(x, 0.f) - log1pf(__expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+
+inline int launch_status() {
+  return hipGetLastError() == hipSuccess ? HYMETA_OK : HYMETA_ERR_LAUNCH;
+}
+
+}  // namespace hymeta

@@ -1,0 +1,380 @@
+// Single-query paged decode attention with a sliding window over the paged
+// real keys and an always-visible tile of meta keys, one softmax (split-KV).
+//
+// HBM-bound: each (sequence, kv-head) streams its visible K and V rows once
+// (256 B per row) and the q-heads that share the kv-head ride along as the 16
+// columns of an MFMA tile, so the arithmetic costs nothing next to the loads.
+// Nothing goes through LDS on the way in:
+//   * S^T = K Q^T with v_mfma_f32_16x16x32_bf16: the A operand wants, per lane,
+//     16 contiguous bytes of one key row -- exactly a coalesced global load.
+//   * The S^T accumulator has the q-head on the lane and keys in registers,
+//     which is already the A-operand layout of P for O += P V (the k-slots
+//     are a fixed permutation of the tile's 32 keys; V is loaded through the
+//     same permutation).
+//   * V must be the B operand with the KEY index packed inside a lane, but is
+//     stored with the channel index contiguous.  Each lane loads 8 key rows x
+//     16 bytes and transposes the 8x8 block of 16-bit values in registers
+//     (32 v_perm_b32), which yields the B fragments of 8 MFMAs at once.
+// A workgroup (4 waves) owns one (sequence, kv-head, split); its waves take
+// alternate 32-key tiles and merge their online-softmax states through LDS.
+// With more than one split the un-normalised partial results go to a
+// workspace and a second kernel merges them.
+#include "common.h"
+
+namespace hymeta {
+
+namespace {
+
+constexpr int kTile = 32;          // keys per tile (two 16-key MFMA sub-tiles)
+constexpr int kMaxGroup = 16;      // q-heads per kv-head handled by one workgroup
+constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 as_frag(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+struct SplitGeom {
+  int L;        // keys of this sequence
+  int kstart;   // first visible real position
+  int t0;       // absolute index of the first real tile
+  int nreal;    // real tiles
+  int ntiles;   // meta tiles + real tiles
+  int lo, hi;   // tile range of this split
+};
+
+__device__ __forceinline__ SplitGeom split_geom(int L, int window_left, int meta_tiles,
+                                                int split, int num_splits) {
+  SplitGeom g;
+  g.L = L;
+  g.kstart = (window_left >= 0 && L - 1 - window_left > 0) ? L - 1 - window_left : 0;
+  g.t0 = g.kstart / kTile;
+  g.nreal = L > 0 ? (L - 1) / kTile - g.t0 + 1 : 0;
+  g.ntiles = meta_tiles + g.nreal;
+  const int per = (g.ntiles + num_splits - 1) / num_splits;
+  g.lo = split * per;
+  g.hi = g.lo + per < g.ntiles ? g.lo + per : g.ntiles;
+  return g;
+}
+
+}  // namespace
+
+// grid.x = batch * num_kv_heads * head_groups, grid.y = num_splits, 256 threads.
+__global__ __launch_bounds__(256) void paged_decode_split_kernel(hymeta_paged_decode_args a,
+                                                                 int num_splits, int head_groups,
+                                                                 float scale_log2) {
+  constexpr int D = kHeadDim;
+  __shared__ float s_o[4][kMaxGroup][D];  // per-wave partial outputs
+  __shared__ float s_m[4][kMaxGroup];
+  __shared__ float s_l[4][kMaxGroup];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int lane = tid % kWave;
+  const int c = lane >> 4;   // lane group: k-slot block of the MFMA operands
+  const int n = lane & 15;   // MFMA row/column index carried by the lane
+
+  int bid = blockIdx.x;
+  const int hg = bid % head_groups; bid /= head_groups;
+  const int kvh = bid % a.num_kv_heads;
+  const int b = bid / a.num_kv_heads;
+  const int split = blockIdx.y;
+  const int group = a.num_heads / a.num_kv_heads;
+  const int head0 = kvh * group + hg * kMaxGroup;        // first q-head of this workgroup
+  const int nheads = min(kMaxGroup, group - hg * kMaxGroup);
+
+  const int meta_tiles = a.meta_key != nullptr ? a.num_meta / kTile : 0;
+  const SplitGeom geo = split_geom(a.cache_seqlens[b], a.window_left, meta_tiles, split, num_splits);
+
+  // Q as the B operand of S^T = K Q^T: lane holds Q[head n][32*ks + 8c .. +7].
+  bf16x8 qf[4];
+  {
+    const uint16_t* qp = reinterpret_cast<const uint16_t*>(a.q) + b * a.q_stride_b +
+                         static_cast<int64_t>(head0 + n) * a.q_stride_h + 8 * c;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (n < nheads) raw = ld16(qp + 32 * ks);
+      qf[ks] = as_frag(raw);
+    }
+  }
+
+  f32x4 o[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) o[t] = {0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY;  // running max (log2 domain) of head n, replicated over lane groups
+  float l_run = 0.f;        // this lane's share of the running denominator
+
+  const uint16_t* kc = reinterpret_cast<const uint16_t*>(a.key_cache) + static_cast<int64_t>(kvh) * a.cache_stride_h;
+  const uint16_t* vc = reinterpret_cast<const uint16_t*>(a.value_cache) + static_cast<int64_t>(kvh) * a.cache_stride_h;
+  const int32_t* bt = a.block_tables + static_cast<int64_t>(b) * a.block_table_stride;
+
+  for (int tile = geo.lo + wave; tile < geo.hi; tile += 4) {
+    const bool is_meta = tile < meta_tiles;
+    // Row pointers of the two 16-key sub-tiles (wave-uniform).
+    const uint16_t* krow[2];
+    const uint16_t* vrow[2];
+    int64_t row_stride;
+    int pos0 = 0;          // position of the tile's first key (real tiles)
+    bool sub_ok[2] = {true, true};
+    if (is_meta) {
+      row_stride = a.meta_stride_t;
+      const int64_t off = static_cast<int64_t>(tile) * kTile * a.meta_stride_t + static_cast<int64_t>(kvh) * a.meta_stride_h;
+      krow[0] = reinterpret_cast<const uint16_t*>(a.meta_key) + off;
+      vrow[0] = reinterpret_cast<const uint16_t*>(a.meta_value) + off;
+      krow[1] = krow[0] + 16 * row_stride;
+      vrow[1] = vrow[0] + 16 * row_stride;
+    } else {
+      row_stride = a.cache_stride_pos;
+      pos0 = (geo.t0 + tile - meta_tiles) * kTile;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int p = pos0 + 16 * s;
+        sub_ok[s] = p < geo.L && p + 15 >= geo.kstart;  // any visible key in the sub-tile
+        int64_t off = 0;
+        if (sub_ok[s]) {
+          const int blk = bt[p / a.block_size];
+          off = static_cast<int64_t>(blk) * a.cache_stride_block + static_cast<int64_t>(p % a.block_size) * a.cache_stride_pos;
+        }
+        krow[s] = kc + off;
+        vrow[s] = vc + off;
+      }
+    }
+    const bool full = is_meta || (pos0 >= geo.kstart && pos0 + kTile <= geo.L);
+
+    // ---- loads: K as A-operand rows, V as 8 key rows x 16 bytes per lane ----
+    u32x4 kraw[2][4];
+    u32x4 vraw[8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const uint16_t* kp = krow[s] + static_cast<int64_t>(n) * row_stride + 8 * c;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kraw[s][ks] = sub_ok[s] ? ld16(kp + 32 * ks) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int s = j >> 2;
+      const uint16_t* vp = vrow[s] + static_cast<int64_t>(4 * c + (j & 3)) * row_stride + 8 * n;
+      vraw[j] = sub_ok[s] ? ld16(vp) : u32x4{0u, 0u, 0u, 0u};
+    }
+
+    // ---- S^T = K Q^T : st[s][r] = score(key 16s + 4c + r, head n) ----
+    f32x4 st[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      st[s] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) st[s] = mfma16(as_frag(kraw[s][ks]), qf[ks], st[s]);
+    }
+
+    float sc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sc[j] = st[j >> 2][j & 3] * scale_log2;
+    if (!full) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int p = pos0 + 16 * (j >> 2) + 4 * c + (j & 3);
+        const bool ok = p >= geo.kstart && p < geo.L;
+        sc[j] = ok ? sc[j] : -INFINITY;
+        // Rows outside the sequence may hold anything (NaN included): a zero
+        // probability does not neutralise them inside the MFMA, so clear them.
+        if (!ok) vraw[j] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+
+    // ---- online softmax over the tile ----
+    float tmax = sc[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) tmax = fmaxf(tmax, sc[j]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;  // fully masked so far: p = 0
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+    float p[8];
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      p[j] = __builtin_amdgcn_exp2f(sc[j] - m_use);
+      psum += p[j];
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+
+    if (!__all(alpha == 1.f)) {
+      // o[t][r] belongs to head 4c + r; its factor lives on the lanes with n == 4c + r.
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ar = __shfl(alpha, 4 * c + r);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o[t][r] *= ar;
+      }
+    }
+
+    u32x4 pw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pw[i] = pack_bf16x2(p[2 * i], p[2 * i + 1]);
+    const bf16x8 pf = as_frag(pw);
+
+    // ---- O += P V : in-register 8x8 transpose of V, then 8 MFMAs ----
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      u32x4 vt;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t x = vraw[2 * w][t >> 1];
+        const uint32_t y = vraw[2 * w + 1][t >> 1];
+        vt[w] = (t & 1) ? __builtin_amdgcn_perm(y, x, 0x07060302u) : __builtin_amdgcn_perm(y, x, 0x05040100u);
+      }
+      o[t] = mfma16(pf, as_frag(vt), o[t]);
+    }
+  }
+
+  // ---- merge the four waves ----
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  if (lane < kMaxGroup) {
+    s_m[wave][lane] = m_run;
+    s_l[wave][lane] = l_run;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_o[wave][4 * c + r][8 * n + t] = o[t][r];
+  }
+  __syncthreads();
+
+  const int hh = tid >> 4;          // head within the group
+  const int d0 = (tid & 15) * 8;    // 8 channels per thread
+  if (hh >= nheads) return;
+  float mw[4], m_tot = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    mw[w] = s_m[w][hh];
+    m_tot = fmaxf(m_tot, mw[w]);
+  }
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  float l_tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float f = mw[w] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw[w] - m_tot);
+    l_tot += f * s_l[w][hh];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += f * s_o[w][hh][d0 + i];
+  }
+  const int head = head0 + hh;
+  if (num_splits == 1) {
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(acc[2 * i] * inv, acc[2 * i + 1] * inv);
+    st16(reinterpret_cast<uint16_t*>(a.out) + b * a.out_stride_b + static_cast<int64_t>(head) * a.out_stride_h + d0, w);
+  } else {
+    float* wo = reinterpret_cast<float*>(a.workspace);
+    const int64_t unit = (static_cast<int64_t>(b) * a.num_heads + head) * num_splits + split;
+    float* po = wo + unit * D + d0;
+    *reinterpret_cast<f32x4*>(po) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4*>(po + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    if ((tid & 15) == 0) {
+      float* ml = wo + static_cast<int64_t>(a.batch) * a.num_heads * num_splits * D + unit * 2;
+      ml[0] = m_tot;
+      ml[1] = l_tot;
+    }
+  }
+}
+
+// grid.x = batch * num_heads, 128 threads: one channel per thread.
+__global__ __launch_bounds__(128) void paged_decode_merge_kernel(hymeta_paged_decode_args a, int num_splits) {
+  constexpr int D = kHeadDim;
+  const int d = threadIdx.x;
+  const int b = blockIdx.x / a.num_heads;
+  const int head = blockIdx.x % a.num_heads;
+  const float* wo = reinterpret_cast<const float*>(a.workspace);
+  const int64_t unit0 = static_cast<int64_t>(blockIdx.x) * num_splits;
+  const float* ml = wo + static_cast<int64_t>(a.batch) * a.num_heads * num_splits * D + unit0 * 2;
+  float m_tot = -INFINITY;
+  for (int s = 0; s < num_splits; ++s) m_tot = fmaxf(m_tot, ml[2 * s]);
+  float acc = 0.f, l_tot = 0.f;
+  for (int s = 0; s < num_splits; ++s) {
+    const float ms = ml[2 * s];
+    const float f = ms == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms - m_tot);
+    l_tot += f * ml[2 * s + 1];
+    acc += f * wo[(unit0 + s) * D + d];
+  }
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  reinterpret_cast<uint16_t*>(a.out)[b * a.out_stride_b + static_cast<int64_t>(head) * a.out_stride_h + d] = f2bf(acc * inv);
+}
+
+}  // namespace hymeta
+
+using namespace hymeta;
+
+extern "C" size_t hymeta_meta_swa_paged_decode_workspace_bytes(int32_t batch, int32_t num_heads,
+                                                               int32_t head_dim, int32_t num_splits) {
+  if (batch <= 0 || num_heads <= 0 || head_dim <= 0 || num_splits <= 1) return 0;
+  return static_cast<size_t>(batch) * num_heads * num_splits * (head_dim + 2) * sizeof(float);
+}
+
+extern "C" int hymeta_meta_swa_paged_decode_splits(int32_t batch, int32_t num_kv_heads,
+                                                   int32_t max_seqlen_k, int32_t window_left,
+                                                   int32_t num_meta) {
+  if (batch <= 0 || num_kv_heads <= 0) return 1;
+  int64_t keys = max_seqlen_k > 0 ? max_seqlen_k : 0;
+  if (window_left >= 0 && keys > static_cast<int64_t>(window_left) + 1) keys = static_cast<int64_t>(window_left) + 1;
+  const int64_t tiles = (num_meta > 0 ? num_meta / kTile : 0) + (keys + kTile - 1) / kTile + 1;
+  const int64_t units = static_cast<int64_t>(batch) * num_kv_heads;
+  int64_t want = (2048 + units - 1) / units;    // aim for ~2048 workgroups (8 per CU)
+  const int64_t cap = tiles / 8 > 1 ? tiles / 8 : 1;  // at least 8 tiles (2 per wave) per split
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  return static_cast<int>(want);
+}
+
+extern "C" int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  hymeta_paged_decode_args a = *args;
+  if (a.batch < 0 || a.num_heads <= 0 || a.num_kv_heads <= 0 || a.block_size <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.batch == 0) return HYMETA_OK;
+  if (!a.q || !a.out || !a.key_cache || !a.value_cache || !a.block_tables || !a.cache_seqlens) return HYMETA_ERR_INVALID_ARG;
+  if (a.head_dim != kHeadDim) return HYMETA_ERR_UNSUPPORTED;
+  if (a.num_heads % a.num_kv_heads != 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.block_size % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((a.meta_key == nullptr) != (a.meta_value == nullptr)) return HYMETA_ERR_INVALID_ARG;
+  if (a.meta_key == nullptr) a.num_meta = 0;
+  if (a.num_meta < 0 || a.num_meta % kTile != 0) return HYMETA_ERR_UNSUPPORTED;
+  const int64_t strides[] = {a.q_stride_b, a.q_stride_h, a.out_stride_b, a.out_stride_h, a.cache_stride_block,
+                             a.cache_stride_pos, a.cache_stride_h, a.meta_stride_t, a.meta_stride_h};
+  for (int64_t st : strides)
+    if (st % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  uintptr_t ptrs = reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.out) |
+                   reinterpret_cast<uintptr_t>(a.key_cache) | reinterpret_cast<uintptr_t>(a.value_cache) |
+                   reinterpret_cast<uintptr_t>(a.meta_key) | reinterpret_cast<uintptr_t>(a.meta_value);
+  if (ptrs % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+
+  const int max_k = a.max_seqlen_k > 0 ? a.max_seqlen_k : a.max_blocks_per_seq * a.block_size;
+  int splits = a.num_splits > 0 ? a.num_splits
+                                : hymeta_meta_swa_paged_decode_splits(a.batch, a.num_kv_heads, max_k, a.window_left, a.num_meta);
+  if (splits > 1) {
+    const size_t need = hymeta_meta_swa_paged_decode_workspace_bytes(a.batch, a.num_heads, a.head_dim, splits);
+    if (a.workspace == nullptr || a.workspace_bytes < need) return HYMETA_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(a.workspace) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  }
+  const float scale = a.scale > 0.f ? a.scale : 1.f / sqrtf(static_cast<float>(a.head_dim));
+  const int group = a.num_heads / a.num_kv_heads;
+  const int head_groups = (group + kMaxGroup - 1) / kMaxGroup;
+
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid(static_cast<unsigned>(a.batch) * a.num_kv_heads * head_groups, static_cast<unsigned>(splits));
+  hipLaunchKernelGGL(paged_decode_split_kernel, grid, dim3(256), 0, s, a, splits, head_groups, scale * kLog2e);
+  if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+  if (splits > 1) {
+    hipLaunchKernelGGL(paged_decode_merge_kernel, dim3(static_cast<unsigned>(a.batch) * a.num_heads), dim3(128), 0, s, a, splits);
+  }
+  return launch_status();
+}

@@ -1,0 +1,175 @@
+"""ctypes binding of libhymeta_hip.so (declarations: include/hymeta_hip.h).
+
+The library is the product path: if it is missing or a symbol cannot be bound,
+``load()`` raises -- there is no fallback implementation behind these ops.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_LIB_NAME = "libhymeta_hip.so"
+_lib: Optional[C.CDLL] = None
+
+HYMETA_OK = 0
+HYMETA_BF16 = 0
+HYMETA_F32 = 1
+
+GATE_NONE = 0
+GATE_7B = 1
+GATE_70B_CLAMP = 2
+GATE_70B_LOWER_BOUND = 3
+
+ABI_VERSION = 1
+
+_i32, _i64, _f32, _ptr, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+
+class GlaDecodeArgs(C.Structure):
+    _fields_ = [
+        ("q", _ptr), ("k", _ptr), ("v", _ptr), ("g", _ptr), ("out", _ptr), ("state", _ptr),
+        ("slot_idx", _ptr), ("lower_bound", _ptr), ("out_norm_weight", _ptr),
+        ("batch", _i32), ("num_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
+        ("q_stride_b", _i64), ("q_stride_h", _i64),
+        ("k_stride_b", _i64), ("k_stride_h", _i64),
+        ("v_stride_b", _i64), ("v_stride_h", _i64),
+        ("g_stride_b", _i64), ("g_stride_h", _i64),
+        ("out_stride_b", _i64), ("out_stride_h", _i64),
+        ("state_stride_slot", _i64), ("state_stride_h", _i64),
+        ("g_dtype", _i32), ("state_dtype", _i32), ("gate_mode", _i32),
+        ("scale", _f32), ("gate_normalizer", _f32), ("gate_clamp", _f32), ("out_norm_eps", _f32),
+    ]
+
+
+class GlaPrefillArgs(C.Structure):
+    _fields_ = [
+        ("q", _ptr), ("k", _ptr), ("v", _ptr), ("g", _ptr), ("out", _ptr), ("state", _ptr),
+        ("slot_idx", _ptr), ("cu_seqlens", _ptr), ("context_lens", _ptr), ("meta_state", _ptr),
+        ("lower_bound", _ptr), ("out_norm_weight", _ptr),
+        ("num_seqs", _i32), ("total_tokens", _i32), ("max_seqlen", _i32),
+        ("num_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
+        ("q_stride_t", _i64), ("q_stride_h", _i64),
+        ("k_stride_t", _i64), ("k_stride_h", _i64),
+        ("v_stride_t", _i64), ("v_stride_h", _i64),
+        ("g_stride_t", _i64), ("g_stride_h", _i64),
+        ("out_stride_t", _i64), ("out_stride_h", _i64),
+        ("state_stride_slot", _i64), ("state_stride_h", _i64),
+        ("meta_state_stride_h", _i64),
+        ("g_dtype", _i32), ("state_dtype", _i32), ("gate_mode", _i32),
+        ("scale", _f32), ("gate_normalizer", _f32), ("gate_clamp", _f32), ("out_norm_eps", _f32),
+    ]
+
+
+class ReshapeAndCacheArgs(C.Structure):
+    _fields_ = [
+        ("key", _ptr), ("value", _ptr), ("key_cache", _ptr), ("value_cache", _ptr),
+        ("slot_mapping", _ptr),
+        ("num_tokens", _i32), ("num_kv_heads", _i32), ("head_dim", _i32), ("block_size", _i32),
+        ("elem_bytes", _i32),
+        ("num_blocks", _i64),
+        ("key_stride_t", _i64), ("key_stride_h", _i64),
+        ("value_stride_t", _i64), ("value_stride_h", _i64),
+        ("cache_stride_block", _i64), ("cache_stride_pos", _i64), ("cache_stride_h", _i64),
+    ]
+
+
+class PagedDecodeArgs(C.Structure):
+    _fields_ = [
+        ("q", _ptr), ("out", _ptr), ("key_cache", _ptr), ("value_cache", _ptr),
+        ("block_tables", _ptr), ("cache_seqlens", _ptr), ("meta_key", _ptr), ("meta_value", _ptr),
+        ("workspace", _ptr), ("workspace_bytes", _sz),
+        ("batch", _i32), ("num_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
+        ("block_size", _i32), ("max_blocks_per_seq", _i32), ("num_meta", _i32),
+        ("window_left", _i32), ("max_seqlen_k", _i32), ("num_splits", _i32),
+        ("q_stride_b", _i64), ("q_stride_h", _i64),
+        ("out_stride_b", _i64), ("out_stride_h", _i64),
+        ("cache_stride_block", _i64), ("cache_stride_pos", _i64), ("cache_stride_h", _i64),
+        ("block_table_stride", _i64),
+        ("meta_stride_t", _i64), ("meta_stride_h", _i64),
+        ("scale", _f32),
+    ]
+
+
+class SwaPrefillArgs(C.Structure):
+    _fields_ = [
+        ("q", _ptr), ("key", _ptr), ("value", _ptr), ("key_cache", _ptr), ("value_cache", _ptr),
+        ("block_tables", _ptr), ("cu_seqlens_q", _ptr), ("cu_seqlens_k", _ptr), ("seq_lens_k", _ptr),
+        ("meta_query", _ptr), ("meta_key", _ptr), ("meta_value", _ptr), ("out", _ptr),
+        ("num_seqs", _i32), ("total_q", _i32), ("max_seqlen_q", _i32),
+        ("num_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
+        ("num_meta", _i32), ("window_left", _i32), ("block_size", _i32), ("max_blocks_per_seq", _i32),
+        ("q_stride_t", _i64), ("q_stride_h", _i64),
+        ("k_stride_t", _i64), ("k_stride_h", _i64),
+        ("v_stride_t", _i64), ("v_stride_h", _i64),
+        ("out_stride_t", _i64), ("out_stride_h", _i64),
+        ("cache_stride_block", _i64), ("cache_stride_pos", _i64), ("cache_stride_h", _i64),
+        ("block_table_stride", _i64),
+        ("meta_q_stride_t", _i64), ("meta_q_stride_h", _i64),
+        ("meta_stride_t", _i64), ("meta_stride_h", _i64),
+        ("scale", _f32),
+    ]
+
+
+# symbol -> (restype, argtypes); every function include/hymeta_hip.h declares.
+_SIGNATURES = {
+    "hymeta_strerror": (C.c_char_p, [C.c_int]),
+    "hymeta_abi_version": (C.c_int, []),
+    "hymeta_gla_decode": (C.c_int, [C.POINTER(GlaDecodeArgs), _ptr]),
+    "hymeta_gla_prefill_varlen": (C.c_int, [C.POINTER(GlaPrefillArgs), _ptr]),
+    "hymeta_reshape_and_cache": (C.c_int, [C.POINTER(ReshapeAndCacheArgs), _ptr]),
+    "hymeta_meta_swa_paged_decode_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "hymeta_meta_swa_paged_decode_splits": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
+    "hymeta_meta_swa_paged_decode": (C.c_int, [C.POINTER(PagedDecodeArgs), _ptr]),
+    "hymeta_meta_swa_prefill": (C.c_int, [C.POINTER(SwaPrefillArgs), _ptr]),
+}
+
+STRUCTS = {
+    "hymeta_gla_decode_args": GlaDecodeArgs,
+    "hymeta_gla_prefill_args": GlaPrefillArgs,
+    "hymeta_reshape_and_cache_args": ReshapeAndCacheArgs,
+    "hymeta_paged_decode_args": PagedDecodeArgs,
+    "hymeta_swa_prefill_args": SwaPrefillArgs,
+}
+
+
+def library_path() -> str:
+    return os.environ.get("HYMETA_HIP_LIB") or os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load() -> C.CDLL:
+    """Load the library once and bind every declared symbol; raise if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{_LIB_NAME} not found at {path}: build it with `make -C vllm-hymeta_amd` "
+            "(or __graft_entry__.build()); the Hymeta ops have no non-HIP fallback")
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError names the missing symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    version = lib.hymeta_abi_version()
+    if version != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {version}, binding expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+class HymetaError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str) -> None:
+    if code != HYMETA_OK:
+        msg = load().hymeta_strerror(code).decode()
+        raise HymetaError(f"{what}: {msg} (status {code})")

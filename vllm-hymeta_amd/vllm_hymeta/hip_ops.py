@@ -1,0 +1,412 @@
+"""Torch-tensor front end of the C ABI: checks tensors on the host, fills the
+argument structs and enqueues the kernels on torch's current HIP stream.
+
+torch is used for device memory and the stream handle only; every op below
+runs in libhymeta_hip.so.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _C
+
+_DT = {torch.bfloat16: _C.HYMETA_BF16, torch.float32: _C.HYMETA_F32}
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _require(cond: bool, msg: str) -> None:
+    if not cond:
+        raise ValueError(msg)
+
+
+def _dev(*ts):
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        _require(t.is_cuda, "hymeta ops need HIP device tensors")
+        dev = dev or t.device
+        _require(t.device == dev, "all tensors must live on one device")
+    return dev
+
+
+def _inner_contig(t: torch.Tensor, name: str) -> None:
+    _require(t.stride(-1) == 1, f"{name}: innermost dimension must be contiguous")
+
+
+# ---------------------------------------------------------------------------
+# GLA decode
+# ---------------------------------------------------------------------------
+def gla_decode(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    g: Optional[torch.Tensor],
+    state: torch.Tensor,
+    slot_idx: torch.Tensor,
+    scale: Optional[float] = None,
+    out: Optional[torch.Tensor] = None,
+    gate_mode: int = _C.GATE_NONE,
+    lower_bound: Optional[torch.Tensor] = None,
+    gate_normalizer: float = 16.0,
+    gate_clamp: float = 0.95,
+    out_norm_weight: Optional[torch.Tensor] = None,
+    out_norm_eps: float = 1e-6,
+) -> torch.Tensor:
+    """q [B,H,D]; k, v, g [B,Hkv,D]; state [slots,H,D,D] updated in place; slot_idx [B] int32.
+
+    Returns out [B,H,D] bf16 (rows of skipped sequences, slot -1, are left as they were).
+    """
+    _dev(q, k, v, g, state, slot_idx, lower_bound, out_norm_weight)
+    B, H, D = q.shape
+    Hkv = k.shape[1]
+    _require(q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16,
+             "q, k, v must be bfloat16")
+    _require(k.shape == (B, Hkv, D) and v.shape == (B, Hkv, D), "k, v must be [B, Hkv, D]")
+    _require(g is None or g.shape == (B, Hkv, D), "g must be [B, Hkv, D]")
+    _require(state.dim() == 4 and state.shape[1:] == (H, D, D), "state must be [slots, H, D, D]")
+    _require(state.stride(3) == 1 and state.stride(2) == D, "state (Dk, Dv) blocks must be contiguous")
+    _require(state.dtype in _DT, "state must be bfloat16 or float32")
+    _require(slot_idx.dtype == torch.int32 and slot_idx.shape == (B,) and slot_idx.is_contiguous(),
+             "slot_idx must be contiguous int32 [B]")
+    for name, t in (("q", q), ("k", k), ("v", v), ("g", g)):
+        if t is not None:
+            _inner_contig(t, name)
+    if out is None:
+        out = torch.empty(B, H, D, dtype=torch.bfloat16, device=q.device)
+    _require(out.shape == (B, H, D) and out.dtype == torch.bfloat16 and out.stride(-1) == 1,
+             "out must be bf16 [B, H, D]")
+    if lower_bound is not None:
+        _require(lower_bound.dtype == torch.float32 and lower_bound.is_contiguous()
+                 and lower_bound.numel() == H * D, "lower_bound must be contiguous fp32 [H*D]")
+    if out_norm_weight is not None:
+        _require(out_norm_weight.dtype == torch.bfloat16 and out_norm_weight.is_contiguous()
+                 and out_norm_weight.numel() == D, "out_norm_weight must be contiguous bf16 [D]")
+    a = _C.GlaDecodeArgs()
+    a.q, a.k, a.v, a.g, a.out, a.state = _p(q), _p(k), _p(v), _p(g), _p(out), _p(state)
+    a.slot_idx, a.lower_bound, a.out_norm_weight = _p(slot_idx), _p(lower_bound), _p(out_norm_weight)
+    a.batch, a.num_heads, a.num_kv_heads, a.head_dim = B, H, Hkv, D
+    a.q_stride_b, a.q_stride_h = q.stride(0), q.stride(1)
+    a.k_stride_b, a.k_stride_h = k.stride(0), k.stride(1)
+    a.v_stride_b, a.v_stride_h = v.stride(0), v.stride(1)
+    if g is not None:
+        a.g_stride_b, a.g_stride_h = g.stride(0), g.stride(1)
+        _require(g.dtype in _DT, "g must be bfloat16 or float32")
+        a.g_dtype = _DT[g.dtype]
+    a.out_stride_b, a.out_stride_h = out.stride(0), out.stride(1)
+    a.state_stride_slot, a.state_stride_h = state.stride(0), state.stride(1)
+    a.state_dtype = _DT[state.dtype]
+    a.gate_mode = gate_mode
+    a.scale = float(scale) if scale is not None else 0.0
+    a.gate_normalizer, a.gate_clamp, a.out_norm_eps = gate_normalizer, gate_clamp, out_norm_eps
+    _C.check(_C.load().hymeta_gla_decode(C.byref(a), _stream(q)), "hymeta_gla_decode")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# GLA varlen prefill
+# ---------------------------------------------------------------------------
+def gla_prefill_varlen(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    g: Optional[torch.Tensor],
+    state: torch.Tensor,
+    slot_idx: torch.Tensor,
+    cu_seqlens: torch.Tensor,
+    max_seqlen: int,
+    context_lens: Optional[torch.Tensor] = None,
+    meta_state: Optional[torch.Tensor] = None,
+    scale: Optional[float] = None,
+    out: Optional[torch.Tensor] = None,
+    gate_mode: int = _C.GATE_NONE,
+    lower_bound: Optional[torch.Tensor] = None,
+    gate_normalizer: float = 16.0,
+    gate_clamp: float = 0.95,
+    out_norm_weight: Optional[torch.Tensor] = None,
+    out_norm_eps: float = 1e-6,
+) -> torch.Tensor:
+    """q [T,H,D]; k, v, g [T,Hkv,D]; cu_seqlens int32 [nseq+1]; state updated in place."""
+    _dev(q, k, v, g, state, slot_idx, cu_seqlens, context_lens, meta_state, lower_bound, out_norm_weight)
+    T, H, D = q.shape
+    Hkv = k.shape[1]
+    nseq = cu_seqlens.numel() - 1
+    _require(q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16,
+             "q, k, v must be bfloat16")
+    _require(k.shape == (T, Hkv, D) and v.shape == (T, Hkv, D), "k, v must be [T, Hkv, D]")
+    _require(g is None or g.shape == (T, Hkv, D), "g must be [T, Hkv, D]")
+    _require(state.dim() == 4 and state.shape[1:] == (H, D, D), "state must be [slots, H, D, D]")
+    _require(state.stride(3) == 1 and state.stride(2) == D, "state (Dk, Dv) blocks must be contiguous")
+    _require(state.dtype in _DT, "state must be bfloat16 or float32")
+    for name, t, n in (("slot_idx", slot_idx, nseq), ("cu_seqlens", cu_seqlens, nseq + 1),
+                       ("context_lens", context_lens, nseq)):
+        if t is not None:
+            _require(t.dtype == torch.int32 and t.is_contiguous() and t.numel() == n,
+                     f"{name} must be contiguous int32 [{n}]")
+    for name, t in (("q", q), ("k", k), ("v", v), ("g", g)):
+        if t is not None:
+            _inner_contig(t, name)
+    if meta_state is not None:
+        _require(meta_state.shape == (H, D, D) and meta_state.dtype == state.dtype
+                 and meta_state.stride(2) == 1 and meta_state.stride(1) == D,
+                 "meta_state must be [H, D, D] in the state dtype with contiguous blocks")
+    if out is None:
+        out = torch.empty(T, H, D, dtype=torch.bfloat16, device=q.device)
+    _require(out.shape == (T, H, D) and out.dtype == torch.bfloat16 and out.stride(-1) == 1,
+             "out must be bf16 [T, H, D]")
+    a = _C.GlaPrefillArgs()
+    a.q, a.k, a.v, a.g, a.out, a.state = _p(q), _p(k), _p(v), _p(g), _p(out), _p(state)
+    a.slot_idx, a.cu_seqlens, a.context_lens = _p(slot_idx), _p(cu_seqlens), _p(context_lens)
+    a.meta_state, a.lower_bound, a.out_norm_weight = _p(meta_state), _p(lower_bound), _p(out_norm_weight)
+    a.num_seqs, a.total_tokens, a.max_seqlen = nseq, T, int(max_seqlen)
+    a.num_heads, a.num_kv_heads, a.head_dim = H, Hkv, D
+    a.q_stride_t, a.q_stride_h = q.stride(0), q.stride(1)
+    a.k_stride_t, a.k_stride_h = k.stride(0), k.stride(1)
+    a.v_stride_t, a.v_stride_h = v.stride(0), v.stride(1)
+    if g is not None:
+        _require(g.dtype in _DT, "g must be bfloat16 or float32")
+        a.g_stride_t, a.g_stride_h = g.stride(0), g.stride(1)
+        a.g_dtype = _DT[g.dtype]
+    a.out_stride_t, a.out_stride_h = out.stride(0), out.stride(1)
+    a.state_stride_slot, a.state_stride_h = state.stride(0), state.stride(1)
+    if meta_state is not None:
+        a.meta_state_stride_h = meta_state.stride(0)
+    a.state_dtype = _DT[state.dtype]
+    a.gate_mode = gate_mode
+    a.scale = float(scale) if scale is not None else 0.0
+    a.gate_normalizer, a.gate_clamp, a.out_norm_eps = gate_normalizer, gate_clamp, out_norm_eps
+    _C.check(_C.load().hymeta_gla_prefill_varlen(C.byref(a), _stream(q)), "hymeta_gla_prefill_varlen")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Paged KV write
+# ---------------------------------------------------------------------------
+def reshape_and_cache(
+    key: torch.Tensor,
+    value: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    slot_mapping: torch.Tensor,
+) -> None:
+    """key/value [T,Hkv,D] -> caches [nblk,bs,Hkv,D] at slot_mapping [<=T] int64 (negative: skip)."""
+    _dev(key, value, key_cache, value_cache, slot_mapping)
+    _require(key.dtype == value.dtype == key_cache.dtype == value_cache.dtype,
+             "key, value and both caches must share a dtype (kv_cache_dtype 'auto')")
+    _require(key_cache.shape == value_cache.shape and key_cache.stride() == value_cache.stride(),
+             "key and value caches must have identical layout")
+    nblk, bs, Hkv, D = key_cache.shape
+    _require(key.shape[1:] == (Hkv, D) and value.shape == key.shape, "key/value must be [T, Hkv, D]")
+    _require(slot_mapping.dtype == torch.int64 and slot_mapping.is_contiguous(), "slot_mapping must be int64")
+    n = slot_mapping.numel()
+    _require(n <= key.shape[0], "slot_mapping longer than key")
+    for name, t in (("key", key), ("value", value), ("key_cache", key_cache)):
+        _inner_contig(t, name)
+    a = _C.ReshapeAndCacheArgs()
+    a.key, a.value, a.key_cache, a.value_cache = _p(key), _p(value), _p(key_cache), _p(value_cache)
+    a.slot_mapping = _p(slot_mapping)
+    a.num_tokens, a.num_kv_heads, a.head_dim, a.block_size = n, Hkv, D, bs
+    a.elem_bytes = key.element_size()
+    a.num_blocks = nblk
+    a.key_stride_t, a.key_stride_h = key.stride(0), key.stride(1)
+    a.value_stride_t, a.value_stride_h = value.stride(0), value.stride(1)
+    a.cache_stride_block, a.cache_stride_pos, a.cache_stride_h = (
+        key_cache.stride(0), key_cache.stride(1), key_cache.stride(2))
+    _C.check(_C.load().hymeta_reshape_and_cache(C.byref(a), _stream(key)), "hymeta_reshape_and_cache")
+
+
+# ---------------------------------------------------------------------------
+# Paged decode attention (sliding window + meta keys)
+# ---------------------------------------------------------------------------
+_workspaces = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Grow-only per-device scratch for split-KV partials (stream-ordered reuse)."""
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def paged_decode_splits(batch: int, num_kv_heads: int, max_seqlen_k: int, window_left: int,
+                        num_meta: int) -> int:
+    return int(_C.load().hymeta_meta_swa_paged_decode_splits(batch, num_kv_heads, max_seqlen_k,
+                                                             window_left, num_meta))
+
+
+def meta_swa_paged_decode(
+    q: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    cache_seqlens: torch.Tensor,
+    block_tables: torch.Tensor,
+    meta_key: Optional[torch.Tensor] = None,
+    meta_value: Optional[torch.Tensor] = None,
+    window_left: int = -1,
+    scale: Optional[float] = None,
+    max_seqlen_k: int = 0,
+    num_splits: int = 0,
+    out: Optional[torch.Tensor] = None,
+    workspace: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """q [B,H,D]; caches [nblk,bs,Hkv,D]; cache_seqlens int32 [B]; block_tables int32 [B,maxblk];
+    meta_key/meta_value [M,Hkv,D] or None.  Returns out [B,H,D] bf16."""
+    _dev(q, key_cache, value_cache, cache_seqlens, block_tables, meta_key, meta_value, out, workspace)
+    B, H, D = q.shape
+    nblk, bs, Hkv, Dc = key_cache.shape
+    _require(q.dtype == torch.bfloat16 and key_cache.dtype == torch.bfloat16
+             and value_cache.dtype == torch.bfloat16, "q and the KV cache must be bfloat16")
+    _require(Dc == D and value_cache.shape == key_cache.shape
+             and value_cache.stride() == key_cache.stride(), "key/value cache layout mismatch")
+    _require(cache_seqlens.dtype == torch.int32 and cache_seqlens.is_contiguous()
+             and cache_seqlens.numel() == B, "cache_seqlens must be contiguous int32 [B]")
+    _require(block_tables.dtype == torch.int32 and block_tables.dim() == 2
+             and block_tables.shape[0] == B and block_tables.stride(1) == 1,
+             "block_tables must be int32 [B, max_blocks]")
+    _inner_contig(q, "q")
+    _inner_contig(key_cache, "key_cache")
+    M = 0
+    if meta_key is not None:
+        _require(meta_value is not None and meta_key.shape == meta_value.shape
+                 and meta_key.stride() == meta_value.stride(), "meta key/value layout mismatch")
+        _require(meta_key.dtype == torch.bfloat16 and meta_key.shape[1:] == (Hkv, D)
+                 and meta_key.stride(-1) == 1, "meta_key must be bf16 [M, Hkv, D]")
+        M = meta_key.shape[0]
+    if out is None:
+        out = torch.empty(B, H, D, dtype=torch.bfloat16, device=q.device)
+    _require(out.shape == (B, H, D) and out.dtype == torch.bfloat16 and out.stride(-1) == 1,
+             "out must be bf16 [B, H, D]")
+    max_blocks = block_tables.shape[1]
+    if max_seqlen_k <= 0:
+        max_seqlen_k = max_blocks * bs
+    lib = _C.load()
+    if num_splits <= 0:
+        num_splits = lib.hymeta_meta_swa_paged_decode_splits(B, Hkv, max_seqlen_k, window_left, M)
+    need = lib.hymeta_meta_swa_paged_decode_workspace_bytes(B, H, D, num_splits)
+    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        workspace = _workspace(q.device, need)
+    a = _C.PagedDecodeArgs()
+    a.q, a.out, a.key_cache, a.value_cache = _p(q), _p(out), _p(key_cache), _p(value_cache)
+    a.block_tables, a.cache_seqlens = _p(block_tables), _p(cache_seqlens)
+    a.meta_key, a.meta_value = _p(meta_key), _p(meta_value)
+    a.workspace = _p(workspace) if need else None
+    a.workspace_bytes = workspace.numel() * workspace.element_size() if need else 0
+    a.batch, a.num_heads, a.num_kv_heads, a.head_dim = B, H, Hkv, D
+    a.block_size, a.max_blocks_per_seq, a.num_meta = bs, max_blocks, M
+    a.window_left, a.max_seqlen_k, a.num_splits = int(window_left), int(max_seqlen_k), int(num_splits)
+    a.q_stride_b, a.q_stride_h = q.stride(0), q.stride(1)
+    a.out_stride_b, a.out_stride_h = out.stride(0), out.stride(1)
+    a.cache_stride_block, a.cache_stride_pos, a.cache_stride_h = (
+        key_cache.stride(0), key_cache.stride(1), key_cache.stride(2))
+    a.block_table_stride = block_tables.stride(0)
+    if meta_key is not None:
+        a.meta_stride_t, a.meta_stride_h = meta_key.stride(0), meta_key.stride(1)
+    a.scale = float(scale) if scale is not None else 0.0
+    _C.check(lib.hymeta_meta_swa_paged_decode(C.byref(a), _stream(q)), "hymeta_meta_swa_paged_decode")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Varlen prefill attention (sliding window + meta keys)
+# ---------------------------------------------------------------------------
+def meta_swa_prefill(
+    q: torch.Tensor,
+    cu_seqlens_q: torch.Tensor,
+    max_seqlen_q: int,
+    key: Optional[torch.Tensor] = None,
+    value: Optional[torch.Tensor] = None,
+    cu_seqlens_k: Optional[torch.Tensor] = None,
+    key_cache: Optional[torch.Tensor] = None,
+    value_cache: Optional[torch.Tensor] = None,
+    block_tables: Optional[torch.Tensor] = None,
+    seq_lens_k: Optional[torch.Tensor] = None,
+    meta_query: Optional[torch.Tensor] = None,
+    meta_key: Optional[torch.Tensor] = None,
+    meta_value: Optional[torch.Tensor] = None,
+    window_left: int = -1,
+    scale: Optional[float] = None,
+    out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """q [T,H,D].  Un-paged keys: key/value [Tk,Hkv,D] + cu_seqlens_k; paged keys: caches +
+    block_tables + seq_lens_k.  Returns [(M if meta_query)+T, H, D] bf16, meta rows first."""
+    _dev(q, cu_seqlens_q, key, value, cu_seqlens_k, key_cache, value_cache, block_tables,
+         seq_lens_k, meta_query, meta_key, meta_value, out)
+    T, H, D = q.shape
+    nseq = cu_seqlens_q.numel() - 1
+    paged = block_tables is not None
+    _require(q.dtype == torch.bfloat16, "q must be bfloat16")
+    _inner_contig(q, "q")
+    _require(cu_seqlens_q.dtype == torch.int32 and cu_seqlens_q.is_contiguous(), "cu_seqlens_q must be int32")
+    a = _C.SwaPrefillArgs()
+    if paged:
+        _require(key_cache is not None and value_cache is not None and seq_lens_k is not None,
+                 "paged prefill needs key_cache, value_cache and seq_lens_k")
+        nblk, bs, Hkv, Dc = key_cache.shape
+        _require(Dc == D and key_cache.dtype == torch.bfloat16 and value_cache.shape == key_cache.shape
+                 and value_cache.stride() == key_cache.stride() and key_cache.stride(-1) == 1,
+                 "key/value cache layout mismatch")
+        _require(block_tables.dtype == torch.int32 and block_tables.shape[0] == nseq
+                 and block_tables.stride(1) == 1, "block_tables must be int32 [nseq, max_blocks]")
+        _require(seq_lens_k.dtype == torch.int32 and seq_lens_k.is_contiguous()
+                 and seq_lens_k.numel() == nseq, "seq_lens_k must be contiguous int32 [nseq]")
+        a.key_cache, a.value_cache = _p(key_cache), _p(value_cache)
+        a.block_tables, a.seq_lens_k = _p(block_tables), _p(seq_lens_k)
+        a.block_size, a.max_blocks_per_seq = bs, block_tables.shape[1]
+        a.cache_stride_block, a.cache_stride_pos, a.cache_stride_h = (
+            key_cache.stride(0), key_cache.stride(1), key_cache.stride(2))
+        a.block_table_stride = block_tables.stride(0)
+    else:
+        _require(key is not None and value is not None and cu_seqlens_k is not None,
+                 "un-paged prefill needs key, value and cu_seqlens_k")
+        Hkv = key.shape[1]
+        _require(key.dtype == torch.bfloat16 and value.dtype == torch.bfloat16
+                 and key.shape[1:] == (Hkv, D) and value.shape == key.shape, "key/value must be bf16 [Tk, Hkv, D]")
+        _inner_contig(key, "key")
+        _inner_contig(value, "value")
+        _require(cu_seqlens_k.dtype == torch.int32 and cu_seqlens_k.is_contiguous()
+                 and cu_seqlens_k.numel() == nseq + 1, "cu_seqlens_k must be contiguous int32 [nseq+1]")
+        a.key, a.value, a.cu_seqlens_k = _p(key), _p(value), _p(cu_seqlens_k)
+        a.k_stride_t, a.k_stride_h = key.stride(0), key.stride(1)
+        a.v_stride_t, a.v_stride_h = value.stride(0), value.stride(1)
+    M = 0
+    if meta_key is not None:
+        _require(meta_value is not None and meta_key.shape == meta_value.shape
+                 and meta_key.stride() == meta_value.stride(), "meta key/value layout mismatch")
+        _require(meta_key.dtype == torch.bfloat16 and meta_key.shape[1:] == (Hkv, D)
+                 and meta_key.stride(-1) == 1, "meta_key must be bf16 [M, Hkv, D]")
+        M = meta_key.shape[0]
+        a.meta_key, a.meta_value = _p(meta_key), _p(meta_value)
+        a.meta_stride_t, a.meta_stride_h = meta_key.stride(0), meta_key.stride(1)
+    rows = T
+    if meta_query is not None:
+        _require(M > 0 and meta_query.shape == (M, H, D) and meta_query.dtype == torch.bfloat16
+                 and meta_query.stride(-1) == 1, "meta_query must be bf16 [M, H, D]")
+        a.meta_query = _p(meta_query)
+        a.meta_q_stride_t, a.meta_q_stride_h = meta_query.stride(0), meta_query.stride(1)
+        rows += M
+    if out is None:
+        out = torch.empty(rows, H, D, dtype=torch.bfloat16, device=q.device)
+    _require(out.shape == (rows, H, D) and out.dtype == torch.bfloat16 and out.stride(-1) == 1,
+             f"out must be bf16 [{rows}, H, D]")
+    a.q, a.cu_seqlens_q, a.out = _p(q), _p(cu_seqlens_q), _p(out)
+    a.num_seqs, a.total_q, a.max_seqlen_q = nseq, T, int(max_seqlen_q)
+    a.num_heads, a.num_kv_heads, a.head_dim = H, Hkv, D
+    a.num_meta, a.window_left = M, int(window_left)
+    a.q_stride_t, a.q_stride_h = q.stride(0), q.stride(1)
+    a.out_stride_t, a.out_stride_h = out.stride(0), out.stride(1)
+    a.scale = float(scale) if scale is not None else 0.0
+    _C.check(_C.load().hymeta_meta_swa_prefill(C.byref(a), _stream(q)), "hymeta_meta_swa_prefill")
+    return out
