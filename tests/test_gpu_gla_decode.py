@@ -34,15 +34,18 @@ def test_gla_decode_steps(B, H, Hkv, g_dtype):
     q, k, v, g, state = _inputs(0, B, H, Hkv, g_dtype, slots)
     perm = torch.randperm(slots, generator=gen(1))[:B].to(torch.int32)
     perm[1] = -1  # one padded sequence
-    state_ref = state.clone()
+    state_free = state.clone()  # evolves on the oracle side only: bounds the 4-step drift
     state_dev = state.cuda()
     slot_dev = perm.cuda()
     for step in range(4):
+        # each step is checked from identical inputs: the oracle starts from the device state
+        state_ref = state_dev.cpu().clone()
         g_ = gen(100 + step)
         q = randn_bf16(g_, B, H, D)
         k = randn_bf16(g_, B, Hkv, D)
         v = randn_bf16(g_, B, Hkv, D)
         o_ref = gla_decode_step_ref(q, k, v, g, state_ref, perm)
+        gla_decode_step_ref(q, k, v, g, state_free, perm)
         out = torch.full((B, H, D), 7.0, dtype=torch.bfloat16, device="cuda")
         hip_ops.gla_decode(q.cuda(), k.cuda(), v.cuda(), g.cuda(), state_dev, slot_dev, out=out)
         torch.cuda.synchronize()
@@ -51,6 +54,8 @@ def test_gla_decode_steps(B, H, Hkv, g_dtype):
         # skipped sequence: output row untouched
         assert (out.cpu()[~live] == 7.0).all()
         assert_bf16_ulp(state_dev.cpu(), state_ref, f"gla state after step {step}")
+    # independent 4-step evolution: bf16 re-rounding each step lets the two drift apart a little
+    assert_bf16_close(state_dev.cpu(), state_free, "gla state drift over 4 steps", rel=2e-3, frac=2.0 ** -7)
     # untouched slots are bit-identical to the initial state
     used = set(int(s) for s in perm if s >= 0)
     for s in range(slots):
