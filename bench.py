@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Benchmark of the Hymeta attention hot path on MI355X.
+
+Workload at N=1 (BASELINE.json configs[1]): Hymeta-7B bf16 TP=1, context 8192,
+block_size 256, greedy decode of a batch of sequences.  One step = one decode
+token for every sequence through the attention hot path of all 28 layers:
+
+  14 GLA layers : fused gate (relu, logsigmoid/16) + recurrent state update +
+                  per-head RMS norm                     (hymeta_gla_decode)
+  14 SWA layers : paged KV write of the new token       (hymeta_reshape_and_cache)
+                  + paged sliding-window decode, 4097 keys (hymeta_meta_swa_paged_decode)
+
+The projections / MLP around the attention kernels are outside the hot path and
+are not run.  Inputs are synthetic (seeded) and resident in HBM before timing.
+
+N>1 (python -m torch.distributed.run ... bench.py --gpus N): the path shards by
+sequence with no data-path collective, so every rank runs the same per-GPU
+batch on its own KV cache / state ("weak" scaling); time = max over ranks.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vllm-hymeta_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# Hymeta-7B geometry (vllm_hymeta/model_for_7B/configuration_gla_swa.py:15-43 in the reference)
+H, HKV, D = 28, 4, 128
+N_GLA, N_SWA = 14, 14
+WINDOW = 4096          # 7B attends to W+1 keys: flash window_left = W (hf_7B_model/window_attention.py:215)
+BLOCK = 256
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="decode sequences per GPU")
+    ap.add_argument("--ctx", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build_workload(args, dev, total_steps):
+    from vllm_hymeta import hip_ops  # noqa: F401  (fails loudly if the HIP library is missing)
+
+    B, ctx = args.batch, args.ctx
+    g = torch.Generator(device="cpu")
+    g.manual_seed(0)
+    blocks_per_seq = (ctx + total_steps + BLOCK - 1) // BLOCK
+    nblk = B * blocks_per_seq
+    w = {}
+    # one KV cache per SWA layer, [2, nblk, bs, Hkv, D] (meta_attention.py:81-92)
+    w["kv"] = [torch.randn(2, nblk, BLOCK, HKV, D, device=dev, dtype=torch.bfloat16) for _ in range(N_SWA)]
+    perm = torch.randperm(nblk, generator=g).to(torch.int32)
+    w["block_tables"] = perm.view(B, blocks_per_seq).to(dev)
+    # per-step metadata, precomputed: sequence length incl. the new token, and its slot
+    seq_lens, slots = [], []
+    bt_cpu = perm.view(B, blocks_per_seq).long()
+    for s in range(total_steps):
+        pos = ctx + s  # position of the token decoded at step s
+        seq_lens.append(torch.full((B,), pos + 1, dtype=torch.int32))
+        slots.append(bt_cpu[:, pos // BLOCK] * BLOCK + pos % BLOCK)
+    w["seq_lens"] = [t.to(dev) for t in seq_lens]
+    w["slot_mapping"] = [t.to(dev) for t in slots]
+    # GLA recurrent state per layer [slots, H, D, D] bf16 (gla_cache.py:9-33)
+    w["state"] = [(torch.randn(B, H, D, D, device=dev, dtype=torch.float32) * 0.1).to(torch.bfloat16)
+                  for _ in range(N_GLA)]
+    w["slot_idx"] = torch.arange(B, dtype=torch.int32, device=dev)
+    w["g_norm"] = torch.ones(D, dtype=torch.bfloat16, device=dev)
+    # fused qkv(+gk) projection outputs of the step (synthetic), one buffer per layer kind
+    w["qkv_gla"] = torch.randn(B, (H + 2 * HKV) * D, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    w["gk"] = torch.randn(B, HKV, D, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    w["qkv_swa"] = torch.randn(B, (H + 2 * HKV) * D, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    w["out"] = torch.empty(B, H, D, device=dev, dtype=torch.bfloat16)
+    max_k = ctx + total_steps
+    w["max_seqlen_k"] = max_k
+    w["splits"] = hip_ops.paged_decode_splits(B, HKV, max_k, WINDOW, 0)
+    return w
+
+
+def split_qkv(buf, B):
+    q = buf[:, : H * D].view(B, H, D)
+    k = buf[:, H * D:(H + HKV) * D].view(B, HKV, D)
+    v = buf[:, (H + HKV) * D:].view(B, HKV, D)
+    return q, k, v
+
+
+def run_step(w, s, B, events=None):
+    from vllm_hymeta import _C, hip_ops
+
+    q, k, v = split_qkv(w["qkv_gla"], B)
+    for layer in range(N_GLA):
+        hip_ops.gla_decode(q, k, v, w["gk"], w["state"][layer], w["slot_idx"], out=w["out"],
+                           gate_mode=_C.GATE_7B, out_norm_weight=w["g_norm"], out_norm_eps=1e-6)
+    q, k, v = split_qkv(w["qkv_swa"], B)
+    for layer in range(N_SWA):
+        kv = w["kv"][layer]
+        hip_ops.reshape_and_cache(k, v, kv[0], kv[1], w["slot_mapping"][s])
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        hip_ops.meta_swa_paged_decode(q, kv[0], kv[1], w["seq_lens"][s], w["block_tables"],
+                                      window_left=WINDOW, max_seqlen_k=w["max_seqlen_k"],
+                                      num_splits=w["splits"], out=w["out"])
+        if events is not None:
+            e1.record()
+            events.append((e0, e1))
+
+
+def cpu_baseline(args):
+    """The CPU restatement (oracle/) of the same step on the host cores, on a bounded sample:
+    a 2-sequence batch, full 28-layer hot path, context 8192."""
+    from oracle import gla_decode_step_ref, meta_swa_paged_decode_ref, reshape_and_cache_ref
+    from oracle.layers import gate_7b_ref, rms_norm_ref
+
+    Bc, ctx = 2, args.ctx
+    torch.manual_seed(0)
+    nb = (ctx + 8 + BLOCK - 1) // BLOCK
+    kc = torch.randn(Bc * nb, BLOCK, HKV, D).to(torch.bfloat16)
+    vc = torch.randn(Bc * nb, BLOCK, HKV, D).to(torch.bfloat16)
+    bt = torch.arange(Bc * nb, dtype=torch.int32).view(Bc, nb)
+    state = (torch.randn(Bc, H, D, D) * 0.1).to(torch.bfloat16)
+    q = torch.randn(Bc, H, D).to(torch.bfloat16)
+    k, v, gk = (torch.randn(Bc, HKV, D).to(torch.bfloat16) for _ in range(3))
+    w = torch.ones(D, dtype=torch.bfloat16)
+    slot = torch.arange(Bc, dtype=torch.int32)
+
+    def step(s):
+        for _ in range(N_GLA):
+            qg, kg, gg = gate_7b_ref(q, k, gk)
+            rms_norm_ref(gla_decode_step_ref(qg, kg, v, gg, state, slot), w)
+        pos = ctx + s
+        slots = bt[:, pos // BLOCK].long() * BLOCK + pos % BLOCK
+        for _ in range(N_SWA):
+            reshape_and_cache_ref(k, v, kc, vc, slots)
+            meta_swa_paged_decode_ref(q, kc, vc, [pos + 1] * Bc, bt, None, None, WINDOW)
+
+    step(0)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step(1 + n)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n >= 6:
+            break
+    return {"value": round(Bc * n / el, 3), "unit": "tokens/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle/ (torch CPU, {torch.get_num_threads()} threads) on {Bc} sequences x {n} decode "
+                      f"steps of the same 28-layer hot path at ctx {ctx}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP kernels are the product path; there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+
+    B = args.batch
+    total = args.warmup + args.steps
+    w = build_workload(args, dev, total)
+    torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        run_step(w, s, B)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    events = []
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total):
+        run_step(w, s, B, events)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: the paged sliding-window decode (split-KV kernel; + its merge when split)
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(len(events), 1)
+    keys = min(args.ctx + 1, WINDOW + 1)
+    alg_bytes = B * (2 * HKV * D * 2 * keys + H * D * 4)   # K and V rows + q and o, per launch
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_paged_decode.json")
+    if os.path.exists(tpath):
+        try:
+            rec = json.load(open(tpath))
+            if rec.get("batch") == B and rec.get("ctx") == args.ctx:
+                traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    tokens = world * B * args.steps
+    line = {
+        "metric": "decode output tokens/s (attention hot path)",
+        "value": round(tokens / elapsed, 1),
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"Hymeta-7B bf16 TP=1 decode, ctx {args.ctx}, block_size {BLOCK}, {B} sequences/GPU; "
+                        "step = 14 x GLA decode (fused gate + g_norm) + 14 x (paged KV write + "
+                        f"sliding-window paged decode over {keys} keys); projections/MLP not in the hot path",
+            "batch_per_gpu": B,
+            "ctx": args.ctx,
+            "parallelism": "replicas" if world > 1 else "single GPU",
+        },
+        "roofline": {
+            "kernel": "paged_decode_split_kernel" + (" (+ paged_decode_merge_kernel)" if w["splits"] > 1 else ""),
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_ms": round(kern_ms, 5),
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,24 +95,32 @@ __global__ __launch_bounds__(256) void gla_decode_kernel(hymeta_gla_decode_args 
   for (int c = 0; c < 8; ++c) acc[c] = 0.f;
 
   if constexpr (!STATE_F32) {
+    // Rows go through in batches of at most 4 passes: 16 VGPRs of loads in flight per lane keep
+    // the kernel at <= 64 VGPRs, so 8 workgroups fit on a CU and 2048 (sequence, head) units
+    // are resident at once.
+    constexpr int PB = NPASS < 4 ? NPASS : 4;
     uint16_t* sp = reinterpret_cast<uint16_t*>(a.state) + sbase + col0;
-    u32x4 raw[NPASS];
+    u32x4 raw[PB];
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) raw[i] = ld16(sp + (r0 + RPP * i) * D);
+    for (int i = 0; i < PB; ++i) raw[i] = ld16(sp + (r0 + RPP * i) * D);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-      const int row = r0 + RPP * i;
-      const float kr = s_k[row], dr = s_dec[row], qr = s_q[row];
-      float s[8];
-      StateIO<uint16_t>::unpack(raw[i], s);
+    for (int hb = 0; hb < NPASS; hb += PB) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float kv = bf16_round(kr * vf[c]);  // outer product is formed in bf16
-        s[c] = fmaf(dr, s[c], kv);
-        acc[c] = fmaf(qr, s[c], acc[c]);
+      for (int i = 0; i < PB; ++i) {
+        const int row = r0 + RPP * (hb + i);
+        const float kr = s_k[row], dr = s_dec[row], qr = s_q[row];
+        float s[8];
+        StateIO<uint16_t>::unpack(raw[i], s);
+        if (hb + PB < NPASS) raw[i] = ld16(sp + (row + RPP * PB) * D);  // next batch, same register
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float kv = bf16_round(kr * vf[c]);  // outer product is formed in bf16
+          s[c] = fmaf(dr, s[c], kv);
+          acc[c] = fmaf(qr, s[c], acc[c]);
+        }
+        StateIO<uint16_t>::store8(sp + row * D, s);
       }
-      StateIO<uint16_t>::store8(sp + row * D, s);
     }
   } else {
     float* sp = reinterpret_cast<float*>(a.state) + sbase + col0;

@@ -19,6 +19,8 @@
 // alternate 32-key tiles and merge their online-softmax states through LDS.
 // With more than one split the un-normalised partial results go to a
 // workspace and a second kernel merges them.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace hymeta {
@@ -60,14 +62,15 @@ __device__ __forceinline__ SplitGeom split_geom(int L, int window_left, int meta
 
 }  // namespace
 
-// grid.x = batch * num_kv_heads * head_groups, grid.y = num_splits, 256 threads.
-__global__ __launch_bounds__(256) void paged_decode_split_kernel(hymeta_paged_decode_args a,
+// grid.x = batch * num_kv_heads * head_groups, grid.y = num_splits, NW waves per workgroup.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_paged_decode_args a,
                                                                  int num_splits, int head_groups,
                                                                  float scale_log2) {
   constexpr int D = kHeadDim;
-  __shared__ float s_o[4][kMaxGroup][D];  // per-wave partial outputs
-  __shared__ float s_m[4][kMaxGroup];
-  __shared__ float s_l[4][kMaxGroup];
+  __shared__ float s_o[NW][kMaxGroup][D];  // per-wave partial outputs
+  __shared__ float s_m[NW][kMaxGroup];
+  __shared__ float s_l[NW][kMaxGroup];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void paged_decode_split_kernel(hymeta_paged_de
   const uint16_t* vc = reinterpret_cast<const uint16_t*>(a.value_cache) + static_cast<int64_t>(kvh) * a.cache_stride_h;
   const int32_t* bt = a.block_tables + static_cast<int64_t>(b) * a.block_table_stride;
 
-  for (int tile = geo.lo + wave; tile < geo.hi; tile += 4) {
+  for (int tile = geo.lo + wave; tile < geo.hi; tile += NW) {
     const bool is_meta = tile < meta_tiles;
     // Row pointers of the two 16-key sub-tiles (wave-uniform).
     const uint16_t* krow[2];
@@ -247,12 +250,13 @@ __global__ __launch_bounds__(256) void paged_decode_split_kernel(hymeta_paged_de
   }
   __syncthreads();
 
+  if (tid >= 256) return;
   const int hh = tid >> 4;          // head within the group
   const int d0 = (tid & 15) * 8;    // 8 channels per thread
   if (hh >= nheads) return;
-  float mw[4], m_tot = -INFINITY;
+  float mw[NW], m_tot = -INFINITY;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NW; ++w) {
     mw[w] = s_m[w][hh];
     m_tot = fmaxf(m_tot, mw[w]);
   }
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void paged_decode_split_kernel(hymeta_paged_de
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   float l_tot = 0.f;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NW; ++w) {
     const float f = mw[w] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw[w] - m_tot);
     l_tot += f * s_l[w][hh];
 #pragma unroll
@@ -328,7 +332,10 @@ extern "C" int hymeta_meta_swa_paged_decode_splits(int32_t batch, int32_t num_kv
   if (window_left >= 0 && keys > static_cast<int64_t>(window_left) + 1) keys = static_cast<int64_t>(window_left) + 1;
   const int64_t tiles = (num_meta > 0 ? num_meta / kTile : 0) + (keys + kTile - 1) / kTile + 1;
   const int64_t units = static_cast<int64_t>(batch) * num_kv_heads;
-  int64_t want = (2048 + units - 1) / units;    // aim for ~2048 workgroups (8 per CU)
+  // One workgroup per CU already streams at the rate this access pattern allows (measured:
+  // 256 workgroups = 5.2 TB/s, more splits only add merge traffic), so split just enough to
+  // put a workgroup on every CU.
+  int64_t want = (256 + units - 1) / units;
   const int64_t cap = tiles / 8 > 1 ? tiles / 8 : 1;  // at least 8 tiles (2 per wave) per split
   if (want > cap) want = cap;
   if (want < 1) want = 1;
@@ -371,7 +378,10 @@ extern "C" int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args
 
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(static_cast<unsigned>(a.batch) * a.num_kv_heads * head_groups, static_cast<unsigned>(splits));
-  hipLaunchKernelGGL(paged_decode_split_kernel, grid, dim3(256), 0, s, a, splits, head_groups, scale * kLog2e);
+  const char* nw_env = getenv("HYMETA_PAGED_NW");
+  const int nw = nw_env ? atoi(nw_env) : 4;
+  if (nw == 8) hipLaunchKernelGGL((paged_decode_split_kernel<8>), grid, dim3(512), 0, s, a, splits, head_groups, scale * kLog2e);
+  else hipLaunchKernelGGL((paged_decode_split_kernel<4>), grid, dim3(256), 0, s, a, splits, head_groups, scale * kLog2e);
   if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
   if (splits > 1) {
     hipLaunchKernelGGL(paged_decode_merge_kernel, dim3(static_cast<unsigned>(a.batch) * a.num_heads), dim3(128), 0, s, a, splits);
