@@ -312,6 +312,71 @@ typedef struct hymeta_swa_prefill_args {
 
 int hymeta_meta_swa_prefill(const hymeta_swa_prefill_args* args, hymeta_stream_t stream);
 
+
+/* ------------------------------------------------------------------------
+ * NeoX (rotate-half) rotary embedding, in place on q and k.
+ * Replaces vllm._custom_ops.rotary_embedding as called from
+ * HymetaRotaryEmbedding.forward (vllm_hymeta/models/modeling_hymeta.py:220-234)
+ * and the stock get_rope of the 7B SWA layer
+ * (vllm_hymeta/model_for_7B/modeling_gla_swa.py:89-90,204-218).
+ * For token t at position p = positions[t] + position_offset and pair
+ * (i, i + rot_dim/2):  x' = x cos - y sin ;  y' = y cos + x sin, with
+ * cos = cache[p, i], sin = cache[p, rot_dim/2 + i]; every product and the
+ * sum are rounded to bf16, as the bf16 instantiation of the vLLM op does.
+ * position_offset carries the +num_meta_tokens shift of the 70B model
+ * (vllm_hymeta/models/modeling_hymeta.py:1314-1323).
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_rope_args {
+  void* q;                   /* bf16 [num_tokens, num_heads,    head_dim] */
+  void* k;                   /* bf16 [num_tokens, num_kv_heads, head_dim] or NULL */
+  const int64_t* positions;  /* [num_tokens] */
+  const void* cos_sin_cache; /* bf16 [max_position, rot_dim] */
+  int32_t num_tokens;
+  int32_t num_heads;
+  int32_t num_kv_heads;
+  int32_t head_dim;
+  int32_t rot_dim;           /* == head_dim for the Hymeta models */
+  int32_t max_position;      /* rows of the cache; positions beyond it are an error of the caller */
+  int64_t position_offset;
+  int64_t q_stride_t, q_stride_h;
+  int64_t k_stride_t, k_stride_h;
+} hymeta_rope_args;
+
+int hymeta_rope_neox(const hymeta_rope_args* args, hymeta_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 70B branch combine: y = bf16( (RMSNorm1(o_attn) + RMSNorm2(o_lin)) / 2 ).
+ * Replaces HymetaRMSNormTP._forward x2 + the average
+ * (vllm_hymeta/models/modeling_hymeta.py:151-173, 909-919); eager form
+ * hf_model/modeling_hymeta.py:127-128.  RMS statistics are over the FULL
+ * hidden size; under tensor parallelism each rank holds hidden/tp columns.
+ *
+ *  hymeta_rms_sumsq2      : stats[t, 0|1] = mean over the LOCAL columns of
+ *                           o_attn[t]^2 | o_lin[t]^2  (fp32).  The caller
+ *                           all-reduces(sum) stats and divides by tp
+ *                           (:158-160) -- one [T,2] message instead of the
+ *                           reference's two [T,1] ones.
+ *  hymeta_hybrid_combine  : applies both norms with the given statistics
+ *                           (stats == NULL: computes them locally, tp = 1)
+ *                           and averages.  Per element, as the reference:
+ *                           xn = bf16(x * rsqrt(var + eps)); y = bf16((xn1*w1 + xn2*w2) / 2).
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_combine_args {
+  const void* o_attn;    /* bf16 [num_tokens, hidden_local] */
+  const void* o_lin;     /* bf16 [num_tokens, hidden_local] */
+  const float* weight1;  /* fp32 [hidden_local] (norm1, softmax branch) */
+  const float* weight2;  /* fp32 [hidden_local] (norm2, linear branch) */
+  float* stats;          /* fp32 [num_tokens, 2]: out of sumsq2, in (nullable) of combine */
+  void* out;             /* bf16 [num_tokens, hidden_local] */
+  int32_t num_tokens;
+  int32_t hidden_local;  /* multiple of 8 */
+  int64_t attn_stride_t, lin_stride_t, out_stride_t;
+  float eps;
+} hymeta_combine_args;
+
+int hymeta_rms_sumsq2(const hymeta_combine_args* args, hymeta_stream_t stream);
+int hymeta_hybrid_combine(const hymeta_combine_args* args, hymeta_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,17 +100,17 @@ def rope_neox_ref(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
                   cos_sin_cache: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """NeoX (rotate-half) RoPE as vLLM's ``rotary_embedding`` op applies it in
     place (call site ``vllm_hymeta/models/modeling_hymeta.py:230-231``; eager
-    form ``hf_7B_model/window_attention.py:49-79``): per pair ``(x1, x2) =
-    (x[i], x[i + D/2])``: ``x1*cos - x2*sin``, ``x2*cos + x1*sin``, computed in
-    fp32 from the cache dtype's values and rounded to the activation dtype.
-    q ``[T,H,D]``, k ``[T,Hkv,D]``."""
+    form ``hf_7B_model/window_attention.py:49-79``): per pair ``(x, y) =
+    (v[i], v[i + D/2])``: ``x*cos - y*sin``, ``y*cos + x*sin``.  The op is
+    instantiated for the activation dtype, so each product and the sum are
+    rounded to bf16 -- reproduced here by doing the arithmetic on bf16 tensors.
+    q ``[T,H,D]``, k ``[T,Hkv,D]``; ``cos_sin_cache [max_pos, D]`` (cos | sin)."""
     D = q.shape[-1]
-    cs = cos_sin_cache[positions.long()].float()
+    cs = cos_sin_cache[positions.long()].to(q.dtype)
     cos, sin = cs[:, None, : D // 2], cs[:, None, D // 2:]
 
     def rot(x):
-        xf = x.float()
-        x1, x2 = xf[..., : D // 2], xf[..., D // 2:]
-        return torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), dim=-1).to(x.dtype)
+        x1, x2 = x[..., : D // 2], x[..., D // 2:]
+        return torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), dim=-1)
 
     return rot(q), rot(k)

@@ -1,0 +1,72 @@
+"""RoPE and the 70B two-branch norm combine vs the CPU restatement."""
+import pytest
+import torch
+
+from _util import assert_bf16_close, gen, randn_bf16
+
+pytestmark = pytest.mark.gpu
+D = 128
+
+
+def test_rope_neox_in_place_with_meta_offset():
+    from oracle.layers import rope_cos_sin_cache_ref, rope_neox_ref
+    from vllm_hymeta import hip_ops
+
+    T, H, Hkv, M = 37, 7, 1, 128
+    g_ = gen(0)
+    qkv = randn_bf16(g_, T, (H + 2 * Hkv) * D)
+    cache = rope_cos_sin_cache_ref(D, 4096, 1e6)
+    pos = torch.randint(0, 3000, (T,), generator=g_)
+    q = qkv[:, : H * D].view(T, H, D)
+    k = qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
+    q_ref, k_ref = rope_neox_ref(pos + M, q, k, cache)
+    dev = qkv.cuda()
+    qd = dev[:, : H * D].view(T, H, D)
+    kd = dev[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
+    hip_ops.rope_neox_(pos.cuda(), qd, kd, cache.cuda(), position_offset=M)
+    torch.cuda.synchronize()
+    # same bf16 arithmetic on both sides: exact up to fused-multiply-add contraction of the sum
+    assert (qd.cpu().float() - q_ref.float()).abs().max() <= 2.0 ** -7 * q_ref.float().abs().max()
+    assert_bf16_close(qd.cpu(), q_ref, "rope q", rel=2e-3)
+    assert_bf16_close(kd.cpu(), k_ref, "rope k", rel=2e-3)
+    # v (the rest of the fused buffer) untouched
+    assert torch.equal(dev.cpu()[:, (H + Hkv) * D:], qkv[:, (H + Hkv) * D:])
+
+
+@pytest.mark.parametrize("tp", [1, 4])
+def test_hybrid_combine(tp):
+    from oracle.layers import hybrid_combine_ref, rms_norm_tp_ref
+    from vllm_hymeta import hip_ops
+
+    T, hidden = 19, 3584
+    g_ = gen(1)
+    o1, o2 = randn_bf16(g_, T, hidden), randn_bf16(g_, T, hidden, scale=3.0)
+    w1 = 1 + 0.1 * torch.randn(hidden, generator=g_)
+    w2 = 1 + 0.1 * torch.randn(hidden, generator=g_)
+    if tp == 1:
+        ref = hybrid_combine_ref(o1, o2, w1, w2, 1e-6)
+        out = hip_ops.hybrid_combine(o1.cuda(), o2.cuda(), w1.cuda(), w2.cuda(), 1e-6)
+        torch.cuda.synchronize()
+        assert_bf16_close(out.cpu(), ref, "hybrid combine tp=1", rel=3e-3)
+        return
+    # tensor parallel: each rank norms its hidden/tp columns with the all-reduced variance
+    loc = hidden // tp
+    var1 = o1.float().pow(2).mean(-1, keepdim=True)
+    var2 = o2.float().pow(2).mean(-1, keepdim=True)
+    stats_sum = torch.zeros(T, 2, device="cuda")
+    shards = []
+    for r in range(tp):
+        sl = slice(r * loc, (r + 1) * loc)
+        a, b = o1[:, sl].contiguous().cuda(), o2[:, sl].contiguous().cuda()
+        shards.append((a, b, w1[sl].contiguous().cuda(), w2[sl].contiguous().cuda()))
+        stats_sum += hip_ops.rms_sumsq2(a, b)          # what the all-reduce(sum) would produce
+    stats = stats_sum / tp
+    torch.cuda.synchronize()
+    assert torch.allclose(stats.cpu(), torch.cat([var1, var2], dim=1), rtol=1e-5)
+    for r, (a, b, wa, wb) in enumerate(shards):
+        sl = slice(r * loc, (r + 1) * loc)
+        ref = ((rms_norm_tp_ref(o1[:, sl], w1[sl], 1e-6, var1) + rms_norm_tp_ref(o2[:, sl], w2[sl], 1e-6, var2)) / 2
+               ).to(torch.bfloat16)
+        out = hip_ops.hybrid_combine(a, b, wa, wb, 1e-6, stats=stats)
+        torch.cuda.synchronize()
+        assert_bf16_close(out.cpu(), ref, f"hybrid combine shard {r}", rel=3e-3)

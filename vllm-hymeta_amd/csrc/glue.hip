@@ -1,0 +1,158 @@
+// Element-wise glue of the attention layers: NeoX rotary embedding and the
+// 70B two-branch RMS-norm combine.  HBM-bound; 16-byte accesses throughout.
+#include "common.h"
+
+namespace hymeta {
+
+// One workgroup of 256 threads per token; thread i < heads*8 handles 8 pairs (x[8j..], x[64+8j..]).
+__global__ __launch_bounds__(256) void rope_neox_kernel(hymeta_rope_args a) {
+  const int t = blockIdx.x;
+  const int half = a.rot_dim / 2;
+  const int chunks = half / 8;                 // 16-byte chunks per half head
+  const int64_t pos = a.positions[t] + a.position_offset;
+  const uint16_t* cs = reinterpret_cast<const uint16_t*>(a.cos_sin_cache) + pos * a.rot_dim;
+  const int total_heads = a.num_heads + (a.k != nullptr ? a.num_kv_heads : 0);
+  for (int w = threadIdx.x; w < total_heads * chunks; w += blockDim.x) {
+    const int head = w / chunks, ch = w % chunks;
+    uint16_t* x = head < a.num_heads
+        ? reinterpret_cast<uint16_t*>(a.q) + t * a.q_stride_t + head * a.q_stride_h
+        : reinterpret_cast<uint16_t*>(a.k) + t * a.k_stride_t + (head - a.num_heads) * a.k_stride_h;
+    const u32x4 xv = ld16(x + 8 * ch), yv = ld16(x + half + 8 * ch);
+    const u32x4 cv = ld16(cs + 8 * ch), sv = ld16(cs + half + 8 * ch);
+    u32x4 xo, yo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float r[2][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float xf = e ? hi_bf(xv[i]) : lo_bf(xv[i]);
+        const float yf = e ? hi_bf(yv[i]) : lo_bf(yv[i]);
+        const float c = e ? hi_bf(cv[i]) : lo_bf(cv[i]);
+        const float s = e ? hi_bf(sv[i]) : lo_bf(sv[i]);
+        // bf16 arithmetic: every product and the sum round to bf16
+        r[0][e] = bf16_round(xf * c) - bf16_round(yf * s);
+        r[1][e] = bf16_round(yf * c) + bf16_round(xf * s);
+      }
+      xo[i] = pack_bf16x2(r[0][0], r[0][1]);
+      yo[i] = pack_bf16x2(r[1][0], r[1][1]);
+    }
+    st16(x + 8 * ch, xo);
+    st16(x + half + 8 * ch, yo);
+  }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) v += __shfl_xor(v, off);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_red[wave] = v;
+  __syncthreads();
+  const float r = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  __syncthreads();
+  return r;
+}
+
+// One workgroup per token.  MODE 0: write the two local mean-squares.  MODE 1: combine.
+template <int MODE>
+__global__ __launch_bounds__(256) void hybrid_combine_kernel(hymeta_combine_args a) {
+  __shared__ float s_red[4];
+  const int t = blockIdx.x;
+  const uint16_t* xa = reinterpret_cast<const uint16_t*>(a.o_attn) + t * a.attn_stride_t;
+  const uint16_t* xl = reinterpret_cast<const uint16_t*>(a.o_lin) + t * a.lin_stride_t;
+  const int chunks = a.hidden_local / 8;
+  float var1, var2;
+  if (MODE == 0 || a.stats == nullptr) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+      const u32x4 v1 = ld16(xa + 8 * c), v2 = ld16(xl + 8 * c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a0 = lo_bf(v1[i]), a1 = hi_bf(v1[i]), b0 = lo_bf(v2[i]), b1 = hi_bf(v2[i]);
+        s1 += a0 * a0 + a1 * a1;
+        s2 += b0 * b0 + b1 * b1;
+      }
+    }
+    var1 = block_sum_256(s1, s_red) / a.hidden_local;
+    var2 = block_sum_256(s2, s_red) / a.hidden_local;
+    if (MODE == 0) {
+      if (threadIdx.x == 0) {
+        a.stats[2 * t] = var1;
+        a.stats[2 * t + 1] = var2;
+      }
+      return;
+    }
+  } else {
+    var1 = a.stats[2 * t];
+    var2 = a.stats[2 * t + 1];
+  }
+  const float r1 = rsqrtf(var1 + a.eps), r2 = rsqrtf(var2 + a.eps);
+  uint16_t* out = reinterpret_cast<uint16_t*>(a.out) + t * a.out_stride_t;
+  for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+    const u32x4 v1 = ld16(xa + 8 * c), v2 = ld16(xl + 8 * c);
+    const f32x4 w1a = *reinterpret_cast<const f32x4*>(a.weight1 + 8 * c);
+    const f32x4 w1b = *reinterpret_cast<const f32x4*>(a.weight1 + 8 * c + 4);
+    const f32x4 w2a = *reinterpret_cast<const f32x4*>(a.weight2 + 8 * c);
+    const f32x4 w2b = *reinterpret_cast<const f32x4*>(a.weight2 + 8 * c + 4);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float y[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * i + e;
+        const float x1 = e ? hi_bf(v1[i]) : lo_bf(v1[i]);
+        const float x2 = e ? hi_bf(v2[i]) : lo_bf(v2[i]);
+        const float w1 = j < 4 ? w1a[j] : w1b[j - 4];
+        const float w2 = j < 4 ? w2a[j] : w2b[j - 4];
+        y[e] = (bf16_round(x1 * r1) * w1 + bf16_round(x2 * r2) * w2) * 0.5f;
+      }
+      o[i] = pack_bf16x2(y[0], y[1]);
+    }
+    st16(out + 8 * c, o);
+  }
+}
+
+}  // namespace hymeta
+
+using namespace hymeta;
+
+extern "C" int hymeta_rope_neox(const hymeta_rope_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_rope_args& a = *args;
+  if (a.num_tokens < 0 || a.num_heads <= 0 || a.num_kv_heads < 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.num_tokens == 0) return HYMETA_OK;
+  if (!a.q || !a.positions || !a.cos_sin_cache) return HYMETA_ERR_INVALID_ARG;
+  if (a.rot_dim != a.head_dim || a.rot_dim % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((a.q_stride_t | a.q_stride_h | a.k_stride_t | a.k_stride_h) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k) |
+       reinterpret_cast<uintptr_t>(a.cos_sin_cache)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(rope_neox_kernel, dim3(a.num_tokens), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return launch_status();
+}
+
+static int check_combine(const hymeta_combine_args& a, bool need_out) {
+  if (a.num_tokens < 0 || a.hidden_local <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (!a.o_attn || !a.o_lin) return HYMETA_ERR_INVALID_ARG;
+  if (need_out && (!a.out || !a.weight1 || !a.weight2)) return HYMETA_ERR_INVALID_ARG;
+  if (!need_out && !a.stats) return HYMETA_ERR_INVALID_ARG;
+  if (a.hidden_local % 8 != 0 || (a.attn_stride_t | a.lin_stride_t | a.out_stride_t) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a.o_attn) | reinterpret_cast<uintptr_t>(a.o_lin) | reinterpret_cast<uintptr_t>(a.out) |
+       reinterpret_cast<uintptr_t>(a.weight1) | reinterpret_cast<uintptr_t>(a.weight2)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  return HYMETA_OK;
+}
+
+extern "C" int hymeta_rms_sumsq2(const hymeta_combine_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const int rc = check_combine(*args, false);
+  if (rc != HYMETA_OK || args->num_tokens == 0) return rc;
+  hipLaunchKernelGGL((hybrid_combine_kernel<0>), dim3(args->num_tokens), dim3(256), 0, static_cast<hipStream_t>(stream), *args);
+  return launch_status();
+}
+
+extern "C" int hymeta_hybrid_combine(const hymeta_combine_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const int rc = check_combine(*args, true);
+  if (rc != HYMETA_OK || args->num_tokens == 0) return rc;
+  hipLaunchKernelGGL((hybrid_combine_kernel<1>), dim3(args->num_tokens), dim3(256), 0, static_cast<hipStream_t>(stream), *args);
+  return launch_status();
+}

@@ -112,6 +112,26 @@ class SwaPrefillArgs(C.Structure):
     ]
 
 
+class RopeArgs(C.Structure):
+    _fields_ = [
+        ("q", _ptr), ("k", _ptr), ("positions", _ptr), ("cos_sin_cache", _ptr),
+        ("num_tokens", _i32), ("num_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
+        ("rot_dim", _i32), ("max_position", _i32),
+        ("position_offset", _i64),
+        ("q_stride_t", _i64), ("q_stride_h", _i64), ("k_stride_t", _i64), ("k_stride_h", _i64),
+    ]
+
+
+class CombineArgs(C.Structure):
+    _fields_ = [
+        ("o_attn", _ptr), ("o_lin", _ptr), ("weight1", _ptr), ("weight2", _ptr), ("stats", _ptr),
+        ("out", _ptr),
+        ("num_tokens", _i32), ("hidden_local", _i32),
+        ("attn_stride_t", _i64), ("lin_stride_t", _i64), ("out_stride_t", _i64),
+        ("eps", _f32),
+    ]
+
+
 # symbol -> (restype, argtypes); every function include/hymeta_hip.h declares.
 _SIGNATURES = {
     "hymeta_strerror": (C.c_char_p, [C.c_int]),
@@ -123,6 +143,9 @@ _SIGNATURES = {
     "hymeta_meta_swa_paged_decode_splits": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "hymeta_meta_swa_paged_decode": (C.c_int, [C.POINTER(PagedDecodeArgs), _ptr]),
     "hymeta_meta_swa_prefill": (C.c_int, [C.POINTER(SwaPrefillArgs), _ptr]),
+    "hymeta_rope_neox": (C.c_int, [C.POINTER(RopeArgs), _ptr]),
+    "hymeta_rms_sumsq2": (C.c_int, [C.POINTER(CombineArgs), _ptr]),
+    "hymeta_hybrid_combine": (C.c_int, [C.POINTER(CombineArgs), _ptr]),
 }
 
 STRUCTS = {
@@ -131,6 +154,8 @@ STRUCTS = {
     "hymeta_reshape_and_cache_args": ReshapeAndCacheArgs,
     "hymeta_paged_decode_args": PagedDecodeArgs,
     "hymeta_swa_prefill_args": SwaPrefillArgs,
+    "hymeta_rope_args": RopeArgs,
+    "hymeta_combine_args": CombineArgs,
 }
 
 

@@ -410,3 +410,75 @@ def meta_swa_prefill(
     a.scale = float(scale) if scale is not None else 0.0
     _C.check(_C.load().hymeta_meta_swa_prefill(C.byref(a), _stream(q)), "hymeta_meta_swa_prefill")
     return out
+
+
+# ---------------------------------------------------------------------------
+# Layer glue: rotary embedding and the 70B two-branch norm combine
+# ---------------------------------------------------------------------------
+def rope_neox_(positions: torch.Tensor, q: torch.Tensor, k: Optional[torch.Tensor],
+               cos_sin_cache: torch.Tensor, position_offset: int = 0) -> None:
+    """In-place NeoX rotary embedding.  positions int64 [T]; q [T,H,D]; k [T,Hkv,D] or None;
+    cos_sin_cache bf16 [max_pos, D] (cos | sin)."""
+    _dev(positions, q, k, cos_sin_cache)
+    T, H, D = q.shape
+    _require(q.dtype == torch.bfloat16 and (k is None or k.dtype == torch.bfloat16), "q, k must be bfloat16")
+    _require(positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == T,
+             "positions must be contiguous int64 [T]")
+    _require(cos_sin_cache.dtype == torch.bfloat16 and cos_sin_cache.is_contiguous()
+             and cos_sin_cache.shape[1] == D, "cos_sin_cache must be contiguous bf16 [max_pos, D]")
+    _inner_contig(q, "q")
+    a = _C.RopeArgs()
+    a.q, a.positions, a.cos_sin_cache = _p(q), _p(positions), _p(cos_sin_cache)
+    a.num_tokens, a.num_heads, a.head_dim, a.rot_dim = T, H, D, D
+    a.max_position = cos_sin_cache.shape[0]
+    a.position_offset = int(position_offset)
+    a.q_stride_t, a.q_stride_h = q.stride(0), q.stride(1)
+    if k is not None:
+        _require(k.shape[0] == T and k.shape[2] == D, "k must be [T, Hkv, D]")
+        _inner_contig(k, "k")
+        a.k, a.num_kv_heads = _p(k), k.shape[1]
+        a.k_stride_t, a.k_stride_h = k.stride(0), k.stride(1)
+    _C.check(_C.load().hymeta_rope_neox(C.byref(a), _stream(q)), "hymeta_rope_neox")
+
+
+def _combine_args(o_attn, o_lin, weight1, weight2, stats, out, eps):
+    T, Hd = o_attn.shape
+    _require(o_lin.shape == (T, Hd) and o_attn.dtype == torch.bfloat16 and o_lin.dtype == torch.bfloat16,
+             "o_attn, o_lin must be bf16 [T, hidden_local]")
+    _require(o_attn.stride(1) == 1 and o_lin.stride(1) == 1, "branch outputs must be row-contiguous")
+    a = _C.CombineArgs()
+    a.o_attn, a.o_lin, a.stats, a.out = _p(o_attn), _p(o_lin), _p(stats), _p(out)
+    a.weight1, a.weight2 = _p(weight1), _p(weight2)
+    a.num_tokens, a.hidden_local = T, Hd
+    a.attn_stride_t, a.lin_stride_t = o_attn.stride(0), o_lin.stride(0)
+    if out is not None:
+        a.out_stride_t = out.stride(0)
+    a.eps = eps
+    return a
+
+
+def rms_sumsq2(o_attn: torch.Tensor, o_lin: torch.Tensor) -> torch.Tensor:
+    """Local mean of squares of both branches: fp32 [T, 2] (all-reduce it, divide by tp)."""
+    _dev(o_attn, o_lin)
+    stats = torch.empty(o_attn.shape[0], 2, dtype=torch.float32, device=o_attn.device)
+    a = _combine_args(o_attn, o_lin, None, None, stats, None, 0.0)
+    _C.check(_C.load().hymeta_rms_sumsq2(C.byref(a), _stream(o_attn)), "hymeta_rms_sumsq2")
+    return stats
+
+
+def hybrid_combine(o_attn: torch.Tensor, o_lin: torch.Tensor, weight1: torch.Tensor, weight2: torch.Tensor,
+                   eps: float = 1e-6, stats: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16((RMSNorm1(o_attn) + RMSNorm2(o_lin)) / 2); ``stats`` = all-reduced mean squares or None (tp=1)."""
+    _dev(o_attn, o_lin, weight1, weight2, stats, out)
+    for w in (weight1, weight2):
+        _require(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == o_attn.shape[1],
+                 "norm weights must be contiguous fp32 [hidden_local]")
+    if stats is not None:
+        _require(stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape == (o_attn.shape[0], 2),
+                 "stats must be contiguous fp32 [T, 2]")
+    if out is None:
+        out = torch.empty_like(o_attn)
+    a = _combine_args(o_attn, o_lin, weight1, weight2, stats, out, eps)
+    _C.check(_C.load().hymeta_hybrid_combine(C.byref(a), _stream(o_attn)), "hymeta_hybrid_combine")
+    return out
