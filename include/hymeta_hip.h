@@ -44,7 +44,7 @@ enum hymeta_status {
   HYMETA_ERR_LAUNCH = -4        /* hipGetLastError() != hipSuccess after launch */
 };
 
-enum hymeta_dtype { HYMETA_BF16 = 0, HYMETA_F32 = 1 };
+enum hymeta_dtype { HYMETA_BF16 = 0, HYMETA_F32 = 1, HYMETA_F16 = 2 };
 
 /* Fused gate prologue applied to the raw projections before the recurrence. */
 enum hymeta_gate_mode {
@@ -376,6 +376,72 @@ typedef struct hymeta_combine_args {
 
 int hymeta_rms_sumsq2(const hymeta_combine_args* args, hymeta_stream_t stream);
 int hymeta_hybrid_combine(const hymeta_combine_args* args, hymeta_stream_t stream);
+
+
+/* ------------------------------------------------------------------------
+ * Fused dequant-GEMM for GPTQ checkpoints: out = x W (+ bias), W dequantised on
+ * the fly from the gptqmodel / AutoGPTQ tensors.  Replaces the vLLM quantised
+ * linear method behind every *ParallelLinear(quant_config=...) of the Hymeta
+ * layers (vllm_hymeta/models/modeling_hymeta.py:249-262,422-430,724-732,858-861;
+ * vllm_hymeta/model_for_7B/gla_attention.py:147-176, modeling_gla_swa.py:108-121,
+ * 177-192) for checkpoints produced by hf_7B_model/quant_7B.py:32-36 (8-bit,
+ * group 64) and the module lists of hf_7B_model/gla_swa_gptq.py:18-24 /
+ * hf_model/hymeta_gptq.py:22-35.  The arithmetic itself lives in vLLM 0.10.0
+ * (third-party): parity unpinned.
+ *
+ * Tensor format (GPTQ v1): pack = 32 / bits;
+ *   qweight int32 [K / pack, N]   : row r holds k = r*pack .. r*pack+pack-1 of each column,
+ *                                   value j in bits [bits*j, bits*(j+1));
+ *   qzeros  int32 [K / group, N / pack] : zero of column n in bits [bits*(n%pack), ...) of entry n/pack,
+ *                                   stored minus zero_offset (1 in the v1 format);
+ *   scales  [K / group, N]  fp16 or bf16;
+ *   w[k, n] = scales[k/group, n] * (q[k, n] - (qzeros[k/group, n] + zero_offset)).
+ * Rows are in natural order (g_idx[k] = k / group; act-order checkpoints are not supported).
+ * Split-K: when split_k > 1 the partial sums meet in `workspace` (fp32 [M, N]).
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_gptq_gemm_args {
+  const void* x;          /* bf16 [M, K] */
+  const int32_t* qweight;
+  const int32_t* qzeros;
+  const void* scales;
+  const void* bias;       /* bf16 [N] or NULL */
+  void* out;              /* bf16 [M, N] */
+  float* workspace;       /* fp32 [M, N] or NULL (needed when the library splits K) */
+  size_t workspace_bytes;
+  int32_t M, K, N;
+  int32_t bits;           /* 4 or 8 */
+  int32_t group_size;     /* 32, 64 or 128 */
+  int32_t scales_dtype;   /* HYMETA_F16 or HYMETA_BF16 */
+  int32_t zero_offset;    /* 1 for the v1 format, 0 for v2 */
+  int32_t split_k;        /* <= 0: library chooses; pass the result of hymeta_gptq_gemm_split_k to size the workspace */
+  int64_t x_stride_m, out_stride_m;
+} hymeta_gptq_gemm_args;
+
+int hymeta_gptq_gemm_split_k(int32_t M, int32_t K, int32_t N, int32_t group_size);
+int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * W8A8 int8 linear: per-output-channel int8 weights, dynamic per-token int8
+ * activations (compressed-tensors "W8A8" as written by hf_model/quant_w8a8.py:121-132
+ * with llmcompressor; executed in the reference by vLLM's scaled_int8_quant +
+ * scaled_mm -- third-party arithmetic, parity unpinned):
+ *   s_x[m] = max|x[m,:]| / 127 ; xq = clamp(rint(x / s_x), -128, 127)
+ *   out[m, n] = bf16( (sum_k xq[m,k] wq[n,k]) * s_x[m] * w_scale[n] + bias[n] )
+ * xq / x_scale are caller-owned scratch ([M, K] int8, [M] fp32).
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_w8a8_gemm_args {
+  const void* x;           /* bf16 [M, K] */
+  const int8_t* qweight;   /* int8 [N, K] */
+  const float* w_scale;    /* fp32 [N] */
+  const void* bias;        /* bf16 [N] or NULL */
+  void* out;               /* bf16 [M, N] */
+  int8_t* xq;              /* scratch int8 [M, K] */
+  float* x_scale;          /* scratch fp32 [M] */
+  int32_t M, K, N;
+  int64_t x_stride_m, out_stride_m;
+} hymeta_w8a8_gemm_args;
+
+int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream);
 
 #ifdef __cplusplus
 }

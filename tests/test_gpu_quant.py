@@ -1,0 +1,85 @@
+"""Fused dequant-GEMMs (GPTQ 4/8-bit, W8A8) vs the CPU restatement of the tensor formats."""
+import pytest
+import torch
+
+from _util import assert_bf16_close, gen, randn_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def _gptq_problem(seed, K, N, bits, group, scales_dtype):
+    g_ = gen(seed)
+    from oracle.quant import gptq_pack_ref
+
+    w_int = torch.randint(0, 2 ** bits, (K, N), generator=g_)
+    zeros = torch.randint(1, 2 ** bits, (K // group, N), generator=g_)   # stored as z - 1 >= 0
+    scales = (torch.rand(K // group, N, generator=g_) * 0.02 + 0.005).to(scales_dtype)
+    qw, qz = gptq_pack_ref(w_int, zeros, bits)
+    return qw, qz, scales
+
+
+@pytest.mark.parametrize("bits,group,M,K,N,scales_dtype,split_k", [
+    (4, 128, 1, 512, 256, torch.float16, 0),
+    (4, 64, 7, 1024, 128, torch.float16, 1),
+    (4, 64, 16, 1024, 128, torch.bfloat16, 4),
+    (8, 64, 3, 512, 192, torch.float16, 0),      # the reference recipe: 8-bit, group 64
+    (8, 64, 40, 768, 64, torch.float16, 2),
+    (4, 128, 100, 512, 128, torch.float16, 1),   # several 64-row passes
+    (4, 32, 5, 256, 64, torch.float16, 0),
+])
+def test_gptq_gemm(bits, group, M, K, N, scales_dtype, split_k):
+    from oracle.quant import gptq_gemm_ref
+    from vllm_hymeta import hip_ops
+
+    qw, qz, scales = _gptq_problem(0, K, N, bits, group, scales_dtype)
+    g_ = gen(1)
+    x = randn_bf16(g_, M, K)
+    bias = randn_bf16(g_, N)
+    ref = gptq_gemm_ref(x, qw, qz, scales, bits, group, bias)
+    out = hip_ops.gptq_gemm(x.cuda(), qw.cuda(), qz.cuda(), scales.cuda(), bits, group, bias=bias.cuda(),
+                            split_k=split_k)
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), ref, f"gptq gemm bits={bits} g={group} M={M} split={split_k}")
+
+
+def test_gptq_gemm_7b_qkv_shape_and_strided_input():
+    """qkv projection of the 7B layer (3584 -> 4608), input rows taken from a wider buffer."""
+    from oracle.quant import gptq_gemm_ref
+    from vllm_hymeta import hip_ops
+
+    K, N, M = 3584, 4608, 4
+    qw, qz, scales = _gptq_problem(2, K, N, 4, 128, torch.float16)
+    xbuf = randn_bf16(gen(3), M, K + 64)
+    x = xbuf[:, :K]
+    ref = gptq_gemm_ref(x, qw, qz, scales, 4, 128)
+    out = hip_ops.gptq_gemm(xbuf.cuda()[:, :K], qw.cuda(), qz.cuda(), scales.cuda(), 4, 128)
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), ref, "gptq qkv 7B")
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 256, 64), (9, 1024, 192), (70, 512, 128), (4, 3584, 4608)])
+def test_w8a8_gemm(M, K, N):
+    from oracle.quant import w8a8_gemm_ref
+    from vllm_hymeta import hip_ops
+
+    g_ = gen(4)
+    x = randn_bf16(g_, M, K)
+    wq = torch.randint(-127, 128, (N, K), generator=g_).to(torch.int8)
+    ws = torch.rand(N, generator=g_) * 0.01 + 0.001
+    bias = randn_bf16(g_, N)
+    ref = w8a8_gemm_ref(x, wq, ws, bias)
+    out = hip_ops.w8a8_gemm(x.cuda(), wq.cuda(), ws.cuda(), bias=bias.cuda())
+    torch.cuda.synchronize()
+    # a product x/s that lands within fp32 rounding of .5 may quantise one step differently
+    assert_bf16_close(out.cpu(), ref, f"w8a8 gemm M={M} K={K} N={N}", rel=6e-3)
+
+
+def test_quant_gemm_rejects_unsupported():
+    from vllm_hymeta import hip_ops
+
+    x = torch.zeros(2, 128, dtype=torch.bfloat16, device="cuda")
+    qw = torch.zeros(16, 48, dtype=torch.int32, device="cuda")      # N not a multiple of 64
+    qz = torch.zeros(1, 6, dtype=torch.int32, device="cuda")
+    sc = torch.ones(1, 48, dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError):
+        hip_ops.gptq_gemm(x, qw, qz, sc, 4, 128)

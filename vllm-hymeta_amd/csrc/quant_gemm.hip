@@ -1,0 +1,396 @@
+// Fused dequant-GEMMs for the quantised linears around the attention kernels:
+// GPTQ 4/8-bit (group-wise scales and zeros) and W8A8 int8.
+//
+// Decode-sized M (<= 64 rows per workgroup pass) is the design point: the weight
+// stream is read once, coalesced, and de-quantised in registers on its way into
+// the matrix cores; larger M re-runs the same body per 64-row block.
+//
+// GPTQ: a packed int32 of qweight holds consecutive k of ONE output column,
+// which is exactly what the MFMA B-operand wants per lane (8 k-slots of column
+// n), so weights go global -> VGPR -> MFMA with no LDS and no shuffles:
+//   4-bit: (q >> 4w) & 0x000F000F | 0x43004300 turns two nibbles into the bf16
+//          pair (128 + q_w, 128 + q_{w+4}) in ONE VALU op; the k-order this
+//          induces (0,4,1,5,2,6,3,7) is applied to the activation fragment too.
+//   8-bit: v_cvt_f32_ubyteN + a byte-permute keep the exact integer in bf16.
+// Scales and zeros are applied once per group, outside the MFMA chain:
+//   sum_k x w = s * ( sum_k x (c + q)  -  (c + z) * sum_k x ),   c = 128 (4-bit) or 0,
+// where sum_k x comes from one extra MFMA against an all-ones B fragment.
+#include "common.h"
+
+namespace hymeta {
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 as_frag(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+__device__ __forceinline__ float load_scale(const void* p, int64_t idx, int dtype) {
+  const uint16_t raw = reinterpret_cast<const uint16_t*>(p)[idx];
+  if (dtype == HYMETA_F16) return static_cast<float>(__builtin_bit_cast(_Float16, raw));
+  return bf2f(raw);
+}
+
+constexpr int kColsPerBlock = 64;  // output columns per workgroup: lane n owns columns 4n .. 4n+3
+
+}  // namespace
+
+// grid = (N / 64, ceil(M / (16 MT)), splits); 256 threads: the 4 waves take alternate groups.
+template <int BITS, int MT>
+__global__ __launch_bounds__(256) void gptq_gemm_kernel(hymeta_gptq_gemm_args a, int splits, int groups_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s_red = reinterpret_cast<float*>(smem_raw);  // [4 waves][16 MT rows][64 cols]
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int c = lane >> 4, n = lane & 15;
+  const int nb = blockIdx.x;
+  const int m0 = blockIdx.y * 16 * MT;
+  const int split = blockIdx.z;
+  const int G = a.K / a.group_size;
+  const int g_lo = split * groups_per_split;
+  const int g_hi = min(G, g_lo + groups_per_split);
+  const int ksteps = a.group_size / 32;
+  const int col0 = nb * kColsPerBlock + 4 * n;   // this lane's first output column
+  constexpr int PACK = 32 / BITS;
+
+  f32x4 acc_tot[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_tot[mt][i] = {0.f, 0.f, 0.f, 0.f};
+
+  const u32x4 ones_raw = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  const bf16x8 ones = as_frag(ones_raw);
+  const uint16_t* xbase = reinterpret_cast<const uint16_t*>(a.x);
+
+  for (int g = g_lo + wave; g < g_hi; g += 4) {
+    f32x4 acc_g[MT][4], acc_x[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      acc_x[mt] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc_g[mt][i] = {0.f, 0.f, 0.f, 0.f};
+    }
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int k0 = g * a.group_size + 32 * ks + 8 * c;   // this lane group's 8 k-values
+      // ---- weights: 8 k-values x 4 columns per lane
+      u32x4 bq[4];
+      if constexpr (BITS == 4) {
+        const u32x4 qw = ld16(a.qweight + static_cast<int64_t>(k0 / 8) * a.N + col0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) bq[i][w] = ((qw[i] >> (4 * w)) & 0x000F000Fu) | 0x43004300u;
+      } else {
+        const u32x4 qa = ld16(a.qweight + static_cast<int64_t>(k0 / 4) * a.N + col0);
+        const u32x4 qb = ld16(a.qweight + static_cast<int64_t>(k0 / 4 + 1) * a.N + col0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t lohi[2] = {qa[i], qb[i]};
+#pragma unroll
+          for (int hw = 0; hw < 2; ++hw) {
+            const float f0 = static_cast<float>(lohi[hw] & 0xffu);
+            const float f1 = static_cast<float>((lohi[hw] >> 8) & 0xffu);
+            const float f2 = static_cast<float>((lohi[hw] >> 16) & 0xffu);
+            const float f3 = static_cast<float>(lohi[hw] >> 24);
+            // integers <= 255 are exact in bf16: keep the high halves
+            bq[i][2 * hw] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+            bq[i][2 * hw + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
+          }
+        }
+      }
+      // ---- activations: 16 rows x 8 k per m-tile
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = m0 + 16 * mt + n;
+        u32x4 xr = {0u, 0u, 0u, 0u};
+        if (row < a.M) xr = ld16(xbase + static_cast<int64_t>(row) * a.x_stride_m + k0);
+        if constexpr (BITS == 4) {
+          // k-slot order (0,4,1,5,2,6,3,7), the order the nibble trick emits
+          u32x4 xp;
+          xp[0] = __builtin_amdgcn_perm(xr[2], xr[0], 0x05040100u);
+          xp[1] = __builtin_amdgcn_perm(xr[2], xr[0], 0x07060302u);
+          xp[2] = __builtin_amdgcn_perm(xr[3], xr[1], 0x05040100u);
+          xp[3] = __builtin_amdgcn_perm(xr[3], xr[1], 0x07060302u);
+          xr = xp;
+        }
+        const bf16x8 af = as_frag(xr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc_g[mt][i] = mfma16(af, as_frag(bq[i]), acc_g[mt][i]);
+        acc_x[mt] = mfma16(af, ones, acc_x[mt]);
+      }
+    }
+    // ---- group epilogue: scales and zeros of this lane's 4 columns
+    float sc[4], zf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sc[i] = load_scale(a.scales, static_cast<int64_t>(g) * a.N + col0 + i, a.scales_dtype);
+    {
+      const uint32_t zw = static_cast<uint32_t>(a.qzeros[static_cast<int64_t>(g) * (a.N / PACK) + col0 / PACK]);
+      const int first = col0 % PACK;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t z = (zw >> (BITS * (first + i))) & ((1u << BITS) - 1u);
+        zf[i] = static_cast<float>(z + a.zero_offset) + (BITS == 4 ? 128.f : 0.f);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc_tot[mt][i][r] += sc[i] * (acc_g[mt][i][r] - zf[i] * acc_x[mt][r]);
+  }
+
+  // ---- reduce the 4 waves: s_red[wave][row][col], row = 16 mt + 4c + r, col = 4n + i
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* p = s_red + (static_cast<size_t>(wave) * 16 * MT + 16 * mt + 4 * c + r) * kColsPerBlock + 4 * n;
+      *reinterpret_cast<f32x4*>(p) = f32x4{acc_tot[mt][0][r], acc_tot[mt][1][r], acc_tot[mt][2][r], acc_tot[mt][3][r]};
+    }
+  __syncthreads();
+  const int cg = tid & 15;          // 4 columns per thread
+  for (int row = tid >> 4; row < 16 * MT; row += 16) {
+    const int grow = m0 + row;
+    if (grow >= a.M) break;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      s += *reinterpret_cast<const f32x4*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kColsPerBlock + 4 * cg);
+    const int col = nb * kColsPerBlock + 4 * cg;
+    if (splits == 1) {
+      if (a.bias != nullptr) {
+        const u32x2 bw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.bias) + col);
+        s[0] += lo_bf(bw[0]); s[1] += hi_bf(bw[0]); s[2] += lo_bf(bw[1]); s[3] += hi_bf(bw[1]);
+      }
+      u32x2 o = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
+      *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(grow) * a.out_stride_m + col) = o;
+    } else {
+      float* w = a.workspace + static_cast<int64_t>(grow) * a.N + col;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(w + i, s[i]);
+    }
+  }
+}
+
+// out = bf16(workspace + bias), 4 columns per thread.
+__global__ __launch_bounds__(256) void gptq_finalize_kernel(hymeta_gptq_gemm_args a) {
+  const int64_t total = static_cast<int64_t>(a.M) * (a.N / 4);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t row = i / (a.N / 4);
+    const int col = static_cast<int>(i % (a.N / 4)) * 4;
+    f32x4 s = *reinterpret_cast<const f32x4*>(a.workspace + row * a.N + col);
+    if (a.bias != nullptr) {
+      const u32x2 bw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.bias) + col);
+      s[0] += lo_bf(bw[0]); s[1] += hi_bf(bw[0]); s[2] += lo_bf(bw[1]); s[3] += hi_bf(bw[1]);
+    }
+    u32x2 o = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
+    *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + row * a.out_stride_m + col) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// W8A8
+// ---------------------------------------------------------------------------------------------
+// One workgroup per token row: s = max|x| / 127, xq = clamp(rint(x / s)).
+__global__ __launch_bounds__(256) void w8a8_quant_kernel(hymeta_w8a8_gemm_args a) {
+  __shared__ float s_red[4];
+  const int m = blockIdx.x;
+  const uint16_t* x = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(m) * a.x_stride_m;
+  const int chunks = a.K / 8;
+  float mx = 0.f;
+  for (int ch = threadIdx.x; ch < chunks; ch += blockDim.x) {
+    const u32x4 v = ld16(x + 8 * ch);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mx = fmaxf(mx, fmaxf(fabsf(lo_bf(v[i])), fabsf(hi_bf(v[i]))));
+  }
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  const float scale = fmaxf(mx, 1e-10f) / 127.f;
+  if (threadIdx.x == 0) a.x_scale[m] = scale;
+  const float inv = 1.f / scale;
+  int8_t* q = a.xq + static_cast<int64_t>(m) * a.K;
+  for (int ch = threadIdx.x; ch < chunks; ch += blockDim.x) {
+    const u32x4 v = ld16(x + 8 * ch);
+    uint32_t w[2] = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float f[2] = {lo_bf(v[i]), hi_bf(v[i])};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int qi = static_cast<int>(fminf(fmaxf(rintf(f[e] * inv), -128.f), 127.f));
+        const int j = 2 * i + e;
+        w[j >> 2] |= (static_cast<uint32_t>(qi) & 0xffu) << (8 * (j & 3));
+      }
+    }
+    *reinterpret_cast<u32x2*>(q + 8 * ch) = u32x2{w[0], w[1]};
+  }
+}
+
+// grid = (N / 64, ceil(M / (16 MT))); the 4 waves take alternate 64-deep k-steps.
+template <int MT>
+__global__ __launch_bounds__(256) void w8a8_gemm_kernel(hymeta_w8a8_gemm_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int* s_red = reinterpret_cast<int*>(smem_raw);  // [4 waves][16 MT rows][64 cols]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int c = lane >> 4, n = lane & 15;
+  const int nb = blockIdx.x;
+  const int m0 = blockIdx.y * 16 * MT;
+
+  i32x4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[mt][i] = {0, 0, 0, 0};
+
+  const int ksteps = a.K / 64;
+  for (int ks = wave; ks < ksteps; ks += 4) {
+    const int k0 = 64 * ks + 16 * c;
+    i32x4 bfrag[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // n-tile i: output channels 64 nb + 16 i + n
+      const int8_t* wp = a.qweight + static_cast<int64_t>(nb * kColsPerBlock + 16 * i + n) * a.K + k0;
+      bfrag[i] = __builtin_bit_cast(i32x4, ld16(wp));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = m0 + 16 * mt + n;
+      i32x4 afrag = {0, 0, 0, 0};
+      if (row < a.M) afrag = __builtin_bit_cast(i32x4, ld16(a.xq + static_cast<int64_t>(row) * a.K + k0));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[mt][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag, bfrag[i], acc[mt][i], 0, 0, 0);
+    }
+  }
+  // acc[mt][i][r] = C[row 16 mt + 4c + r][col 16 i + n]
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        s_red[(static_cast<size_t>(wave) * 16 * MT + 16 * mt + 4 * c + r) * kColsPerBlock + 16 * i + n] = acc[mt][i][r];
+  __syncthreads();
+  const int cg = tid & 15;
+  for (int row = tid >> 4; row < 16 * MT; row += 16) {
+    const int grow = m0 + row;
+    if (grow >= a.M) break;
+    i32x4 s = {0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      s += *reinterpret_cast<const i32x4*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kColsPerBlock + 4 * cg);
+    const int col = nb * kColsPerBlock + 4 * cg;
+    const float xs = a.x_scale[grow];
+    const f32x4 ws = *reinterpret_cast<const f32x4*>(a.w_scale + col);
+    float y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = static_cast<float>(s[i]) * xs * ws[i];
+    if (a.bias != nullptr) {
+      const u32x2 bw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.bias) + col);
+      y[0] += lo_bf(bw[0]); y[1] += hi_bf(bw[0]); y[2] += lo_bf(bw[1]); y[3] += hi_bf(bw[1]);
+    }
+    u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+    *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(grow) * a.out_stride_m + col) = o;
+  }
+}
+
+}  // namespace hymeta
+
+using namespace hymeta;
+
+static int mt_for(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : 4); }
+
+extern "C" int hymeta_gptq_gemm_split_k(int32_t M, int32_t K, int32_t N, int32_t group_size) {
+  if (M <= 0 || K <= 0 || N <= 0 || group_size <= 0) return 1;
+  const int mt = mt_for(M);
+  int64_t blocks = static_cast<int64_t>(N / kColsPerBlock) * ((M + 16 * mt - 1) / (16 * mt));
+  if (blocks < 1) blocks = 1;
+  const int G = K / group_size;
+  int64_t want = (512 + blocks - 1) / blocks;      // enough workgroups to cover the chip twice
+  const int64_t cap = G / 4 > 1 ? G / 4 : 1;       // every wave of a workgroup gets at least one group
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  return static_cast<int>(want);
+}
+
+extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  hymeta_gptq_gemm_args a = *args;
+  if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.M == 0) return HYMETA_OK;
+  if (!a.x || !a.qweight || !a.qzeros || !a.scales || !a.out) return HYMETA_ERR_INVALID_ARG;
+  if (a.bits != 4 && a.bits != 8) return HYMETA_ERR_UNSUPPORTED;
+  if (a.group_size != 32 && a.group_size != 64 && a.group_size != 128) return HYMETA_ERR_UNSUPPORTED;
+  if (a.K % a.group_size != 0 || a.N % kColsPerBlock != 0) return HYMETA_ERR_UNSUPPORTED;
+  if (a.scales_dtype != HYMETA_F16 && a.scales_dtype != HYMETA_BF16) return HYMETA_ERR_UNSUPPORTED;
+  if (a.zero_offset != 0 && a.zero_offset != 1) return HYMETA_ERR_INVALID_ARG;
+  if ((a.x_stride_m | a.out_stride_m) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.qweight) | reinterpret_cast<uintptr_t>(a.out) |
+       reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.workspace)) % 16 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  const int G = a.K / a.group_size;
+  int splits = a.split_k > 0 ? a.split_k : hymeta_gptq_gemm_split_k(a.M, a.K, a.N, a.group_size);
+  if (splits > G) splits = G;
+  if (splits > 1) {
+    const size_t need = static_cast<size_t>(a.M) * a.N * sizeof(float);
+    if (a.workspace == nullptr || a.workspace_bytes < need) return HYMETA_ERR_WORKSPACE;
+  }
+  const int gps = (G + splits - 1) / splits;
+  splits = (G + gps - 1) / gps;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (splits > 1 && hipMemsetAsync(a.workspace, 0, static_cast<size_t>(a.M) * a.N * sizeof(float), s) != hipSuccess)
+    return HYMETA_ERR_LAUNCH;
+  const int mt = mt_for(a.M);
+  dim3 grid(a.N / kColsPerBlock, (a.M + 16 * mt - 1) / (16 * mt), splits), block(256);
+  const size_t lds = static_cast<size_t>(4) * 16 * mt * kColsPerBlock * sizeof(float);
+#define HYMETA_LAUNCH_GPTQ(B, T) hipLaunchKernelGGL((gptq_gemm_kernel<B, T>), grid, block, lds, s, a, splits, gps)
+  if (a.bits == 4) {
+    if (mt == 1) HYMETA_LAUNCH_GPTQ(4, 1); else if (mt == 2) HYMETA_LAUNCH_GPTQ(4, 2); else HYMETA_LAUNCH_GPTQ(4, 4);
+  } else {
+    if (mt == 1) HYMETA_LAUNCH_GPTQ(8, 1); else if (mt == 2) HYMETA_LAUNCH_GPTQ(8, 2); else HYMETA_LAUNCH_GPTQ(8, 4);
+  }
+#undef HYMETA_LAUNCH_GPTQ
+  if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+  if (splits > 1) {
+    const int64_t total = static_cast<int64_t>(a.M) * (a.N / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gptq_finalize_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
+  }
+  return launch_status();
+}
+
+extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_w8a8_gemm_args& a = *args;
+  if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.M == 0) return HYMETA_OK;
+  if (!a.x || !a.qweight || !a.w_scale || !a.out || !a.xq || !a.x_scale) return HYMETA_ERR_INVALID_ARG;
+  if (a.K % 64 != 0 || a.N % kColsPerBlock != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((a.x_stride_m | a.out_stride_m) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.qweight) | reinterpret_cast<uintptr_t>(a.out) |
+       reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.xq) | reinterpret_cast<uintptr_t>(a.w_scale)) % 16 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
+  if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+  const int mt = mt_for(a.M);
+  dim3 grid(a.N / kColsPerBlock, (a.M + 16 * mt - 1) / (16 * mt)), block(256);
+  const size_t lds = static_cast<size_t>(4) * 16 * mt * kColsPerBlock * sizeof(int);
+  if (mt == 1) hipLaunchKernelGGL((w8a8_gemm_kernel<1>), grid, block, lds, s, a);
+  else if (mt == 2) hipLaunchKernelGGL((w8a8_gemm_kernel<2>), grid, block, lds, s, a);
+  else hipLaunchKernelGGL((w8a8_gemm_kernel<4>), grid, block, lds, s, a);
+  return launch_status();
+}

@@ -16,6 +16,7 @@ _lib: Optional[C.CDLL] = None
 HYMETA_OK = 0
 HYMETA_BF16 = 0
 HYMETA_F32 = 1
+HYMETA_F16 = 2
 
 GATE_NONE = 0
 GATE_7B = 1
@@ -132,6 +133,25 @@ class CombineArgs(C.Structure):
     ]
 
 
+class GptqGemmArgs(C.Structure):
+    _fields_ = [
+        ("x", _ptr), ("qweight", _ptr), ("qzeros", _ptr), ("scales", _ptr), ("bias", _ptr), ("out", _ptr),
+        ("workspace", _ptr), ("workspace_bytes", _sz),
+        ("M", _i32), ("K", _i32), ("N", _i32), ("bits", _i32), ("group_size", _i32),
+        ("scales_dtype", _i32), ("zero_offset", _i32), ("split_k", _i32),
+        ("x_stride_m", _i64), ("out_stride_m", _i64),
+    ]
+
+
+class W8A8GemmArgs(C.Structure):
+    _fields_ = [
+        ("x", _ptr), ("qweight", _ptr), ("w_scale", _ptr), ("bias", _ptr), ("out", _ptr),
+        ("xq", _ptr), ("x_scale", _ptr),
+        ("M", _i32), ("K", _i32), ("N", _i32),
+        ("x_stride_m", _i64), ("out_stride_m", _i64),
+    ]
+
+
 # symbol -> (restype, argtypes); every function include/hymeta_hip.h declares.
 _SIGNATURES = {
     "hymeta_strerror": (C.c_char_p, [C.c_int]),
@@ -146,6 +166,9 @@ _SIGNATURES = {
     "hymeta_rope_neox": (C.c_int, [C.POINTER(RopeArgs), _ptr]),
     "hymeta_rms_sumsq2": (C.c_int, [C.POINTER(CombineArgs), _ptr]),
     "hymeta_hybrid_combine": (C.c_int, [C.POINTER(CombineArgs), _ptr]),
+    "hymeta_gptq_gemm_split_k": (C.c_int, [_i32, _i32, _i32, _i32]),
+    "hymeta_gptq_gemm": (C.c_int, [C.POINTER(GptqGemmArgs), _ptr]),
+    "hymeta_w8a8_gemm": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),
 }
 
 STRUCTS = {
@@ -156,6 +179,8 @@ STRUCTS = {
     "hymeta_swa_prefill_args": SwaPrefillArgs,
     "hymeta_rope_args": RopeArgs,
     "hymeta_combine_args": CombineArgs,
+    "hymeta_gptq_gemm_args": GptqGemmArgs,
+    "hymeta_w8a8_gemm_args": W8A8GemmArgs,
 }
 
 

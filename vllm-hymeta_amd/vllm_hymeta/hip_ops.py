@@ -482,3 +482,70 @@ def hybrid_combine(o_attn: torch.Tensor, o_lin: torch.Tensor, weight1: torch.Ten
     a = _combine_args(o_attn, o_lin, weight1, weight2, stats, out, eps)
     _C.check(_C.load().hymeta_hybrid_combine(C.byref(a), _stream(o_attn)), "hymeta_hybrid_combine")
     return out
+
+
+# ---------------------------------------------------------------------------
+# Quantised linears
+# ---------------------------------------------------------------------------
+def gptq_gemm(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+              bits: int, group_size: int, bias: Optional[torch.Tensor] = None, zero_offset: int = 1,
+              split_k: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x bf16 [M,K] @ GPTQ(qweight int32 [K/pack,N], qzeros int32 [K/group,N/pack], scales fp16|bf16
+    [K/group,N]) (+ bias bf16 [N]) -> bf16 [M,N]."""
+    _dev(x, qweight, qzeros, scales, bias, out)
+    M, K = x.shape
+    N = qweight.shape[1]
+    pack = 32 // bits
+    _require(x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [M, K]")
+    _require(qweight.dtype == torch.int32 and qweight.is_contiguous() and qweight.shape[0] * pack == K,
+             "qweight must be contiguous int32 [K/pack, N]")
+    _require(qzeros.dtype == torch.int32 and qzeros.is_contiguous()
+             and qzeros.shape == (K // group_size, N // pack), "qzeros must be contiguous int32 [K/group, N/pack]")
+    _require(scales.dtype in (torch.float16, torch.bfloat16) and scales.is_contiguous()
+             and scales.shape == (K // group_size, N), "scales must be contiguous fp16/bf16 [K/group, N]")
+    if bias is not None:
+        _require(bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N, "bias must be bf16 [N]")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _require(out.shape == (M, N) and out.dtype == torch.bfloat16 and out.stride(1) == 1, "out must be bf16 [M, N]")
+    lib = _C.load()
+    if split_k <= 0:
+        split_k = lib.hymeta_gptq_gemm_split_k(M, K, N, group_size)
+    a = _C.GptqGemmArgs()
+    ws = None
+    if split_k > 1:
+        ws = _workspace(x.device, M * N * 4)
+        a.workspace, a.workspace_bytes = _p(ws), ws.numel()
+    a.x, a.qweight, a.qzeros, a.scales, a.bias, a.out = _p(x), _p(qweight), _p(qzeros), _p(scales), _p(bias), _p(out)
+    a.M, a.K, a.N, a.bits, a.group_size = M, K, N, bits, group_size
+    a.scales_dtype = _C.HYMETA_F16 if scales.dtype == torch.float16 else _C.HYMETA_BF16
+    a.zero_offset, a.split_k = zero_offset, split_k
+    a.x_stride_m, a.out_stride_m = x.stride(0), out.stride(0)
+    _C.check(lib.hymeta_gptq_gemm(C.byref(a), _stream(x)), "hymeta_gptq_gemm")
+    return out
+
+
+def w8a8_gemm(x: torch.Tensor, qweight: torch.Tensor, w_scale: torch.Tensor,
+              bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x bf16 [M,K] -> dynamic per-token int8; qweight int8 [N,K]; w_scale fp32 [N] -> bf16 [M,N]."""
+    _dev(x, qweight, w_scale, bias, out)
+    M, K = x.shape
+    N = qweight.shape[0]
+    _require(x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [M, K]")
+    _require(qweight.dtype == torch.int8 and qweight.is_contiguous() and qweight.shape == (N, K),
+             "qweight must be contiguous int8 [N, K]")
+    _require(w_scale.dtype == torch.float32 and w_scale.is_contiguous() and w_scale.numel() == N,
+             "w_scale must be contiguous fp32 [N]")
+    if bias is not None:
+        _require(bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N, "bias must be bf16 [N]")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    xq = torch.empty(M, K, dtype=torch.int8, device=x.device)
+    xs = torch.empty(M, dtype=torch.float32, device=x.device)
+    a = _C.W8A8GemmArgs()
+    a.x, a.qweight, a.w_scale, a.bias, a.out, a.xq, a.x_scale = (
+        _p(x), _p(qweight), _p(w_scale), _p(bias), _p(out), _p(xq), _p(xs))
+    a.M, a.K, a.N = M, K, N
+    a.x_stride_m, a.out_stride_m = x.stride(0), out.stride(0)
+    _C.check(_C.load().hymeta_w8a8_gemm(C.byref(a), _stream(x)), "hymeta_w8a8_gemm")
+    return out
