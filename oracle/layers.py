@@ -114,3 +114,120 @@ def rope_neox_ref(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
         return torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), dim=-1)
 
     return rot(q), rot(k)
+
+
+# --------------------------------------------------------------------------- whole layers (eager restatement)
+def _linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 linear the way an eager bf16 ``nn.Linear`` computes it: fp32 accumulation, one
+    rounding to the activation dtype."""
+    y = x.float() @ w.float().t()
+    if b is not None:
+        y = y + b.float()
+    return y.to(x.dtype)
+
+
+def gla_layer_7b_ref(x: torch.Tensor, p: dict, num_heads: int, num_kv_heads: int,
+                     initial_state: Optional[torch.Tensor] = None,
+                     norm_eps: float = 1e-6) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One 7B GLA attention layer on one sequence (``hf_7B_model/gla_attention.py:129-173``):
+    q/k/v projections with bias, rank-16 gate projection, relu feature map, ``logsigmoid/16``,
+    GQA, the GLA recurrence, per-head RMS norm (``g_norm``), output projection.
+
+    x ``[T, hidden]`` bf16; ``p`` holds ``q_proj.weight/bias``, ``k_proj.*``, ``v_proj.*``,
+    ``gk_proj.0.weight``, ``gk_proj.1.weight/bias``, ``g_norm.weight``, ``o_proj.weight``.
+    Returns ``(out [T, hidden] bf16, final_state [H, D, D] fp64)``."""
+    from .gla import gla_recurrent_ref
+
+    T = x.shape[0]
+    D = p["q_proj.weight"].shape[0] // num_heads
+    q = _linear(x, p["q_proj.weight"], p["q_proj.bias"]).view(T, num_heads, D)
+    k = _linear(x, p["k_proj.weight"], p["k_proj.bias"]).view(T, num_kv_heads, D)
+    v = _linear(x, p["v_proj.weight"], p["v_proj.bias"]).view(T, num_kv_heads, D)
+    gk = _linear(_linear(x, p["gk_proj.0.weight"]), p["gk_proj.1.weight"], p["gk_proj.1.bias"])
+    q, k, g = gate_7b_ref(q, k, gk.view(T, num_kv_heads, D))
+    o, state = gla_recurrent_ref(q, k, v, g, initial_state)
+    o = rms_norm_ref(o.to(x.dtype), p["g_norm.weight"], norm_eps)
+    return _linear(o.reshape(T, num_heads * D), p["o_proj.weight"]), state
+
+
+def swa_layer_7b_ref(x: torch.Tensor, positions: torch.Tensor, p: dict, num_heads: int,
+                     num_kv_heads: int, sliding_window: int, rope_theta: float = 1e6,
+                     max_position: int = 131072) -> torch.Tensor:
+    """One 7B sliding-window attention layer on one sequence, prefill form
+    (``hf_7B_model/window_attention.py:151-221``): projections with bias, NeoX RoPE, causal
+    attention over the last ``sliding_window + 1`` keys (``window_size=(W, 0)``, ``:215``),
+    output projection.  RoPE uses the vLLM path's bf16 cos/sin table."""
+    from .meta_swa import meta_swa_dense_ref
+
+    T = x.shape[0]
+    D = p["q_proj.weight"].shape[0] // num_heads
+    q = _linear(x, p["q_proj.weight"], p["q_proj.bias"]).view(T, num_heads, D)
+    k = _linear(x, p["k_proj.weight"], p["k_proj.bias"]).view(T, num_kv_heads, D)
+    v = _linear(x, p["v_proj.weight"], p["v_proj.bias"]).view(T, num_kv_heads, D)
+    cache = rope_cos_sin_cache_ref(D, max_position, rope_theta)
+    q, k = rope_neox_ref(positions, q, k, cache)
+    o, _ = meta_swa_dense_ref(q, k, v, None, None, None, sliding_window)
+    return _linear(o.to(x.dtype).reshape(T, num_heads * D), p["o_proj.weight"])
+
+
+def xavier_linear_params_ref(gen: torch.Generator, out_features: int, in_features: int, bias: bool,
+                             gain: float = 2 ** -2.5, dtype=torch.bfloat16) -> dict:
+    """Random init of the eager layers (``hf_7B_model/gla_attention.py:93-100``):
+    ``xavier_uniform_(gain=2**-2.5)`` weights, zero biases."""
+    bound = gain * (6.0 / (in_features + out_features)) ** 0.5
+    w = (torch.rand(out_features, in_features, generator=gen) * 2 - 1) * bound
+    out = {"weight": w.to(dtype)}
+    if bias:
+        out["bias"] = torch.zeros(out_features, dtype=dtype)
+    return out
+
+
+def hybrid_layer_70b_ref(x: torch.Tensor, meta_x: torch.Tensor, positions: torch.Tensor, p: dict,
+                         num_heads: int, num_kv_heads: int, sliding_window: Optional[int],
+                         lower_bound: Optional[torch.Tensor], first_layer: bool,
+                         rope_theta: float = 1e6, max_position: int = 131072,
+                         norm_eps: float = 1e-6) -> torch.Tensor:
+    """One 70B intra-hybrid attention block on ONE sequence, prefill form, with the meta tokens
+    already "cached": the softmax branch sees the roped K/V of ``meta_x`` (positions 0..M-1) as
+    always-visible keys and ropes the real tokens at ``positions + M``; the GLA branch starts from
+    the state left by the meta tokens.  (``hf_model/modeling_hymeta.py:89-130``,
+    ``hf_model/attention.py:155-263``, ``hf_model/linear_attention.py:124-181``; vLLM path
+    ``vllm_hymeta/models/modeling_hymeta.py:580-659,747-815,865-933``.)
+
+    ``p``: ``vanilla_attn.{q,k,v}_proj.{weight,bias}``, ``linear_attn.{q,k,v}_proj.{weight,bias}``,
+    ``norm1.weight``, ``norm2.weight`` (fp32), ``out_proj.weight``.  ``sliding_window`` = W keys
+    including the query (None: full attention).  Returns ``[T, hidden]`` bf16."""
+    from .gla import gla_recurrent_ref
+    from .meta_swa import meta_swa_dense_ref
+
+    T, M = x.shape[0], meta_x.shape[0]
+    D = p["vanilla_attn.q_proj.weight"].shape[0] // num_heads
+    rep = num_heads // num_kv_heads
+    cache = rope_cos_sin_cache_ref(D, max_position, rope_theta)
+
+    def qkv(prefix, h):
+        n = h.shape[0]
+        return (_linear(h, p[f"{prefix}.q_proj.weight"], p[f"{prefix}.q_proj.bias"]).view(n, num_heads, D),
+                _linear(h, p[f"{prefix}.k_proj.weight"], p[f"{prefix}.k_proj.bias"]).view(n, num_kv_heads, D),
+                _linear(h, p[f"{prefix}.v_proj.weight"], p[f"{prefix}.v_proj.bias"]).view(n, num_kv_heads, D))
+
+    # softmax branch
+    q2, k2, v2 = qkv("vanilla_attn", meta_x)
+    _, k2 = rope_neox_ref(torch.arange(M), q2, k2, cache)
+    q, k, v = qkv("vanilla_attn", x)
+    q, k = rope_neox_ref(positions + M, q, k, cache)
+    wl = -1 if not sliding_window else sliding_window - 1
+    o_attn, _ = meta_swa_dense_ref(q, k, v, k2, v2, None, wl)
+    o_attn = o_attn.to(x.dtype).reshape(T, num_heads * D)
+
+    # GLA branch: meta tokens first (zero state), then the sequence from the meta state
+    def gla(h, init):
+        ql, kl, vl = qkv("linear_attn", h)
+        qg, kg, gg = gate_70b_ref(ql, kl.repeat_interleave(rep, dim=1), lower_bound, first_layer)
+        return gla_recurrent_ref(qg, kg, vl.repeat_interleave(rep, dim=1), gg, init)
+
+    _, meta_state = gla(meta_x, None)
+    o_lin, _ = gla(x, meta_state.to(x.dtype))          # the shared meta state is stored in bf16
+    o_lin = o_lin.to(x.dtype).reshape(T, num_heads * D)
+    y = hybrid_combine_ref(o_attn, o_lin, p["norm1.weight"], p["norm2.weight"], norm_eps)
+    return _linear(y, p["out_proj.weight"])

@@ -1,0 +1,51 @@
+"""Linear layers of the attention blocks: bf16 (hipBLASLt through torch) or one of the fused
+dequant-GEMMs (GPTQ 4/8-bit, W8A8).  Stands where the reference puts vLLM's
+``QKVParallelLinear`` / ``RowParallelLinear`` / ``ReplicatedLinear`` with a ``quant_config``
+(``vllm_hymeta/model_for_7B/gla_attention.py:147-176``): a tensor-parallel shard is simply a
+``HymetaLinear`` built from the shard's rows (column parallel) or columns (row parallel)."""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import hip_ops
+
+
+class HymetaLinear(torch.nn.Module):
+    """y = x W^T + b with W in one of three storage formats."""
+
+    def __init__(self, kind: str = "bf16", **tensors):
+        super().__init__()
+        assert kind in ("bf16", "gptq", "w8a8")
+        self.kind = kind
+        self.meta = {k: tensors.pop(k) for k in ("bits", "group_size", "zero_offset") if k in tensors}
+        for name, t in tensors.items():
+            if t is not None:
+                self.register_buffer(name, t, persistent=True)
+        self.bias = tensors.get("bias")
+
+    @classmethod
+    def from_weight(cls, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> "HymetaLinear":
+        """weight bf16 [out, in]."""
+        return cls("bf16", weight=weight, bias=bias)
+
+    @classmethod
+    def from_gptq(cls, qweight, qzeros, scales, bits: int, group_size: int, bias=None,
+                  zero_offset: int = 1) -> "HymetaLinear":
+        return cls("gptq", qweight=qweight, qzeros=qzeros, scales=scales, bias=bias, bits=bits,
+                   group_size=group_size, zero_offset=zero_offset)
+
+    @classmethod
+    def from_w8a8(cls, qweight, w_scale, bias=None) -> "HymetaLinear":
+        return cls("w8a8", qweight=qweight, w_scale=w_scale, bias=bias)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.kind == "bf16":
+            return torch.nn.functional.linear(x, self.weight, self.bias)
+        if self.kind == "gptq":
+            return hip_ops.gptq_gemm(x, self.qweight, self.qzeros, self.scales, self.meta["bits"],
+                                     self.meta["group_size"], bias=self.bias,
+                                     zero_offset=self.meta.get("zero_offset", 1))
+        return hip_ops.w8a8_gemm(x, self.qweight, self.w_scale, bias=self.bias)

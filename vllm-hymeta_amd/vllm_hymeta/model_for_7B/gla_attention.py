@@ -1,0 +1,64 @@
+"""7B gated-linear-attention layer on the HIP kernels.
+
+Reference: ``vllm_hymeta/model_for_7B/gla_attention.py:90-283`` (vLLM layer) and
+``hf_7B_model/gla_attention.py:36-173`` (eager).  Differences in mechanism, not in result: the
+gate (relu, logsigmoid/16), GQA head mapping and per-head ``g_norm`` run inside the GLA kernels;
+all prefill sequences go through one launch; nothing is copied, transposed or repeated.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _C, hip_ops
+from ..linear import HymetaLinear
+from ..parallel import HeadShard, all_reduce_sum, shard_heads
+
+
+class GatedLinearAttention(torch.nn.Module):
+    def __init__(self, hidden_size: int, num_heads: int, num_key_value_heads: int,
+                 qkv_proj: HymetaLinear, gk_proj0: HymetaLinear, gk_proj1: HymetaLinear,
+                 o_proj: HymetaLinear, g_norm_weight: torch.Tensor, norm_eps: float = 1e-6,
+                 gate_logit_normalizer: int = 16, shard: Optional[HeadShard] = None, tp_group=None):
+        """``qkv_proj`` maps hidden -> [q | k | v] of THIS rank's heads (with bias); ``gk_proj0``
+        hidden -> 16 (no bias) and ``gk_proj1`` 16 -> kv_heads * head_dim of this rank (with bias)
+        form the low-rank gate projection, which the reference leaves unquantised
+        (``gla_attention.py:157-166``); ``o_proj`` maps this rank's heads back to hidden (no bias)."""
+        super().__init__()
+        self.shard = shard or shard_heads(num_heads, num_key_value_heads, 1, 0)
+        self.head_dim = hidden_size // num_heads
+        self.qkv_proj, self.gk_proj0, self.gk_proj1, self.o_proj = qkv_proj, gk_proj0, gk_proj1, o_proj
+        self.register_buffer("g_norm_weight", g_norm_weight)
+        self.norm_eps = norm_eps
+        self.gate_logit_normalizer = float(gate_logit_normalizer)
+        self.tp_group = tp_group
+
+    def forward(self, hidden_states: torch.Tensor, gla_cache: torch.Tensor,
+                state_indices_tensor: torch.Tensor, attn_metadata) -> torch.Tensor:
+        """hidden_states ``[T, hidden]`` (prefill tokens first, then one token per decode sequence);
+        ``gla_cache [slots, H_local, D, D]`` of this layer; ``state_indices_tensor`` one slot per
+        sequence in batch order.  Returns ``[T, hidden]``."""
+        H, Hkv, D = self.shard.num_heads, self.shard.num_kv_heads, self.head_dim
+        T = hidden_states.shape[0]
+        qkv = self.qkv_proj(hidden_states)
+        q = qkv[:, : H * D].view(T, H, D)
+        k = qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
+        v = qkv[:, (H + Hkv) * D:].view(T, Hkv, D)
+        gk = self.gk_proj1(self.gk_proj0(hidden_states)).view(T, Hkv, D)
+        out = torch.empty(T, H, D, dtype=hidden_states.dtype, device=hidden_states.device)
+        n_pre = getattr(attn_metadata, "num_prefills", 0)
+        t_pre = getattr(attn_metadata, "num_prefill_tokens", 0)
+        gate = dict(gate_mode=_C.GATE_7B, gate_normalizer=self.gate_logit_normalizer,
+                    out_norm_weight=self.g_norm_weight, out_norm_eps=self.norm_eps)
+        if n_pre > 0:
+            hip_ops.gla_prefill_varlen(
+                q[:t_pre], k[:t_pre], v[:t_pre], gk[:t_pre], gla_cache, state_indices_tensor[:n_pre],
+                attn_metadata.query_start_loc[: n_pre + 1], attn_metadata.max_query_len or t_pre,
+                context_lens=attn_metadata.context_lens_tensor[:n_pre], out=out[:t_pre], **gate)
+        if T > t_pre:
+            hip_ops.gla_decode(q[t_pre:], k[t_pre:], v[t_pre:], gk[t_pre:], gla_cache,
+                               state_indices_tensor[n_pre:], out=out[t_pre:], **gate)
+        y = self.o_proj(out.view(T, H * D))
+        return all_reduce_sum(y, self.tp_group)
