@@ -130,6 +130,16 @@ int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stream_t stream
  *   context_lens[i] == 0, meta_state == NULL     : zeros           (7B)
  * Tokens: S_t = diag(exp g_t) S_{t-1} + k_t^T v_t ; o_t = (scale q_t) S_t.
  * The final state is stored to state[slot] rounded to state_dtype.
+ *
+ * When few (sequence, head) pairs carry long sequences the call can cut each
+ * sequence into num_segments runs that execute in parallel (three launches:
+ * per-segment state contributions, a scan over them, the outputs); this needs
+ * a device workspace of hymeta_gla_prefill_workspace_bytes().  Results equal
+ * the single-run form up to fp32 summation order of the state.
+ *   num_segments == 1                      : single run, workspace unused
+ *   num_segments == 0, workspace != NULL   : hymeta_gla_prefill_segments() decides
+ *   num_segments == 0, workspace == NULL   : single run
+ *   num_segments  > 1                      : as given (clamped to the chunk count)
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_gla_prefill_args {
   const void* q;            /* bf16 [total_tokens, num_heads,    head_dim] */
@@ -164,8 +174,15 @@ typedef struct hymeta_gla_prefill_args {
   float gate_normalizer;
   float gate_clamp;
   float out_norm_eps;
+  void* workspace;          /* device scratch, 16-byte aligned, or NULL */
+  size_t workspace_bytes;
+  int32_t num_segments;     /* see above */
 } hymeta_gla_prefill_args;
 
+/* Segment count the library would choose for this shape (1 = single run). */
+int hymeta_gla_prefill_segments(int32_t num_seqs, int32_t num_heads, int32_t max_seqlen);
+/* Workspace size for a call with that many segments (0 when num_segments <= 1). */
+size_t hymeta_gla_prefill_workspace_bytes(int32_t num_seqs, int32_t num_heads, int32_t num_segments);
 int hymeta_gla_prefill_varlen(const hymeta_gla_prefill_args* args, hymeta_stream_t stream);
 
 /* ------------------------------------------------------------------------

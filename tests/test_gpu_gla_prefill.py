@@ -167,3 +167,51 @@ def test_gla_prefill_fused_norm():
                                      out_norm_weight=w.cuda(), out_norm_eps=1e-6)
     torch.cuda.synchronize()
     assert_bf16_close(out.cpu(), o_ref, "gla prefill + g_norm", rel=8e-3)
+
+
+@pytest.mark.parametrize("nseg", [2, 5, 0])
+@pytest.mark.parametrize("mode", ["plain", "meta_norm_f32state"])
+def test_gla_prefill_segmented_runs_equal_oracle(nseg, mode):
+    """Sequences cut into parallel segments (state contributions, scan, outputs): ragged lengths so
+    that some sequences own fewer segments than the grid provides, one skipped slot, resume from a
+    stored state / the meta state, fused 7B gate + norm."""
+    from oracle import gla_prefill_varlen_ref
+    from oracle.layers import gate_7b_ref, rms_norm_ref
+    from vllm_hymeta import _C, hip_ops
+
+    lens = [700, 33, 1, 1024, 290]
+    H, Hkv = 4, 2
+    T, nseq = sum(lens), len(lens)
+    cu = torch.tensor(np.cumsum([0] + lens), dtype=torch.int32)
+    g_ = gen(11)
+    slot = torch.tensor([3, 0, -1, 5, 1], dtype=torch.int32)
+    if mode == "plain":
+        q, k, v, g = _gate_inputs(10, T, H, Hkv, torch.float32, True)
+        state = randn_bf16(g_, 6, H, D, D, scale=0.1)
+        ref_state = state.clone()
+        o_ref = gla_prefill_varlen_ref(q, k, v, g, ref_state, slot, cu)
+        sd = state.cuda()
+        out = hip_ops.gla_prefill_varlen(q.cuda(), k.cuda(), v.cuda(), g.cuda(), sd, slot.cuda(), cu.cuda(), max(lens),
+                                         num_segments=nseg)
+    else:
+        q, k, v = randn_bf16(g_, T, H, D), randn_bf16(g_, T, Hkv, D), randn_bf16(g_, T, Hkv, D)
+        gk = randn_bf16(g_, T, Hkv, D)
+        w = (1 + 0.1 * torch.randn(D, generator=g_)).to(torch.bfloat16)
+        meta = (0.1 * torch.randn(H, D, D, generator=g_)).float()
+        state = torch.full((6, H, D, D), 7.0)
+        ctx = torch.zeros(nseq, dtype=torch.int32)
+        rep = H // Hkv
+        qg, kg, gg = gate_7b_ref(q, k.repeat_interleave(rep, 1), gk.repeat_interleave(rep, 1))
+        ref_state = state.clone()
+        o_ref = gla_prefill_varlen_ref(qg, kg, v.repeat_interleave(rep, 1), gg, ref_state, slot, cu, ctx, meta)
+        o_ref = rms_norm_ref(o_ref.to(torch.bfloat16), w, 1e-5).float()
+        sd = state.cuda()
+        out = hip_ops.gla_prefill_varlen(q.cuda(), k.cuda(), v.cuda(), gk.cuda(), sd, slot.cuda(), cu.cuda(), max(lens),
+                                         context_lens=ctx.cuda(), meta_state=meta.cuda(), gate_mode=_C.GATE_7B,
+                                         out_norm_weight=w.cuda(), out_norm_eps=1e-5, num_segments=nseg)
+    torch.cuda.synchronize()
+    live = torch.ones(T, dtype=torch.bool)
+    live[cu[2]:cu[3]] = False
+    assert_bf16_close(out.cpu()[live].float(), o_ref[live].float(), f"segmented gla prefill out nseg={nseg}", rel=8e-3)
+    _state_close(sd.cpu().float(), ref_state.float(), "segmented gla prefill state")
+    assert torch.equal(sd.cpu()[2], state[2]) and torch.equal(sd.cpu()[4], state[4])   # untouched slots

@@ -49,7 +49,7 @@ def swa(lens, H, Hkv, M, wl):
     print(f"swa_prefill lens={lens} H={H} Hkv={Hkv} M={M} wl={wl}: {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
 
 
-def gla(lens, H, Hkv):
+def gla(lens, H, Hkv, nseg=0):
     dev = torch.device("cuda")
     T = sum(lens)
     q = torch.randn(T, H, D, device=dev).to(torch.bfloat16)
@@ -62,9 +62,9 @@ def gla(lens, H, Hkv):
     ctx = torch.zeros(len(lens), dtype=torch.int32, device=dev)
     out = torch.empty(T, H, D, dtype=torch.bfloat16, device=dev)
     us = bench(lambda: hip_ops.gla_prefill_varlen(q, k, v, gk, st, slot, cu, max(lens), context_lens=ctx, out=out,
-                                                  gate_mode=_C.GATE_7B))
+                                                  gate_mode=_C.GATE_7B, num_segments=nseg))
     nbytes = T * (H * D * 2 * 2 + 3 * Hkv * D * 2) + len(lens) * H * D * D * 2
-    print(f"gla_prefill lens={lens} H={H} Hkv={Hkv}: {us:9.1f} us  {nbytes / us / 1e3:8.1f} GB/s  "
+    print(f"gla_prefill lens={lens[0]}x{len(lens)} H={H} Hkv={Hkv} nseg={nseg}: {us:9.1f} us  {nbytes / us / 1e3:8.1f} GB/s  "
           f"{T / us:7.2f} tok/us", flush=True)
 
 
@@ -77,7 +77,11 @@ if __name__ == "__main__":
         swa([32768], 7, 1, 128, -1)
         swa([2048] * 8, 28, 4, 0, 4096)
     if "gla" in which:
-        gla([8192], 28, 4)
-        gla([32768], 28, 4)
-        gla([8192] * 8, 28, 4)
-        gla([2048] * 32, 28, 4)
+        for nseg in (1, 0, 9, 18, 27, 36, 64):
+            gla([32768], 28, 4, nseg)
+        for nseg in (1, 0, 9, 18):
+            gla([8192], 28, 4, nseg)
+        for nseg in (1, 0, 2, 4):
+            gla([8192] * 8, 28, 4, nseg)
+        gla([2048] * 32, 28, 4, 1)
+        gla([512] * 4, 28, 4, 0)

@@ -26,8 +26,13 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   return __builtin_bit_cast(uint16_t, b);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// Two fp32 -> packed bf16 pair, round-to-nearest-even, one v_cvt_pk_bf16_f32.
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16);
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
 __device__ __forceinline__ float bf16_round(float f) { return bf2f(f2bf(f)); }

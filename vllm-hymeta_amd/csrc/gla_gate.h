@@ -53,4 +53,47 @@ __device__ __forceinline__ void apply_gate(const GateParams& gp, float q_raw, fl
   }
 }
 
+// log(1 + e) for e in [0, 1]: series below 1/16 (error < e^5/5), v_log_f32 above; both well
+// inside half a bf16 ulp of the result, which is what the callers round to.
+__device__ __forceinline__ float log_normal(float x) {   // natural log of a positive normal number
+  return __builtin_amdgcn_logf(x) * 0.6931471805599453f;
+}
+__device__ __forceinline__ float log1p_unit(float e) {
+  const float series = e * (1.f + e * (-0.5f + e * (1.f / 3.f - 0.25f * e)));
+  const float big = log_normal(1.f + e);
+  // bitwise blend: keeps the two short paths straight-line instead of a divergent branch
+  const uint32_t m = e < 0.0625f ? 0xffffffffu : 0u;
+  return __uint_as_float((__float_as_uint(series) & m) | (__float_as_uint(big) & ~m));
+}
+
+// Branch-free, compile-time-mode form of apply_gate for the prefill producers, where the gate
+// math is the VALU budget: same formulas; the sigmoid uses the hardware reciprocal (1 ulp) and
+// the 7B normaliser is applied as a multiplication by 1/normalizer (exact for powers of two,
+// 16 in every published configuration).
+template <int GATE>
+__device__ __forceinline__ void apply_gate_fast(const GateParams& gp, float inv_normalizer, float q_raw, float k_raw,
+                                                float g_raw, float lb, float& qs, float& kb, float& g) {
+  if constexpr (GATE == HYMETA_GATE_7B) {
+    qs = fmaxf(q_raw, 0.f) * gp.scale;
+    kb = fmaxf(k_raw, 0.f);
+    const float ls = fminf(g_raw, 0.f) - log1p_unit(__expf(-fabsf(g_raw)));
+    g = bf16_round(bf16_round(ls) * inv_normalizer);
+  } else if constexpr (GATE == HYMETA_GATE_70B_CLAMP) {
+    qs = fmaxf(q_raw, 0.f) * gp.scale;
+    const float kt = fminf(__builtin_amdgcn_rcpf(1.f + __expf(-k_raw)), gp.clamp);
+    g = log_normal(1.f - kt);
+    kb = bf16_round(kt);
+  } else if constexpr (GATE == HYMETA_GATE_70B_LOWER_BOUND) {
+    qs = fmaxf(q_raw, 0.f) * gp.scale;
+    const float kt = __builtin_amdgcn_rcpf(1.f + __expf(-k_raw));
+    const float gl = 1.f - (1.f - lb) * kt;
+    g = log_normal(gl);
+    kb = bf16_round(1.f - gl);
+  } else {
+    qs = q_raw * gp.scale;
+    kb = k_raw;
+    g = g_raw;
+  }
+}
+
 }  // namespace hymeta

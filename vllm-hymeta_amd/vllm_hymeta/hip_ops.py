@@ -136,8 +136,11 @@ def gla_prefill_varlen(
     gate_clamp: float = 0.95,
     out_norm_weight: Optional[torch.Tensor] = None,
     out_norm_eps: float = 1e-6,
+    num_segments: int = 0,
 ) -> torch.Tensor:
-    """q [T,H,D]; k, v, g [T,Hkv,D]; cu_seqlens int32 [nseq+1]; state updated in place."""
+    """q [T,H,D]; k, v, g [T,Hkv,D]; cu_seqlens int32 [nseq+1]; state updated in place.
+    ``num_segments``: 0 lets the library decide whether to cut long sequences into parallel runs,
+    1 forces a single run per (sequence, head), >1 forces that many."""
     _dev(q, k, v, g, state, slot_idx, cu_seqlens, context_lens, meta_state, lower_bound, out_norm_weight)
     T, H, D = q.shape
     Hkv = k.shape[1]
@@ -186,7 +189,17 @@ def gla_prefill_varlen(
     a.gate_mode = gate_mode
     a.scale = float(scale) if scale is not None else 0.0
     a.gate_normalizer, a.gate_clamp, a.out_norm_eps = gate_normalizer, gate_clamp, out_norm_eps
-    _C.check(_C.load().hymeta_gla_prefill_varlen(C.byref(a), _stream(q)), "hymeta_gla_prefill_varlen")
+    lib = _C.load()
+    nseg = int(num_segments)
+    if nseg == 0:
+        nseg = int(lib.hymeta_gla_prefill_segments(nseq, H, int(max_seqlen)))
+    nseg = max(1, min(nseg, (int(max_seqlen) + 31) // 32))
+    a.num_segments = nseg
+    if nseg > 1:
+        nbytes = int(lib.hymeta_gla_prefill_workspace_bytes(nseq, H, nseg))
+        ws = _workspace(q.device, nbytes, "gla_prefill")
+        a.workspace, a.workspace_bytes = _p(ws), nbytes
+    _C.check(lib.hymeta_gla_prefill_varlen(C.byref(a), _stream(q)), "hymeta_gla_prefill_varlen")
     return out
 
 
@@ -232,12 +245,13 @@ def reshape_and_cache(
 _workspaces = {}
 
 
-def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Grow-only per-device scratch for split-KV partials (stream-ordered reuse)."""
-    ws = _workspaces.get(device)
+def _workspace(device: torch.device, nbytes: int, tag: str = "paged_decode") -> torch.Tensor:
+    """Grow-only per-device, per-op scratch (split-KV partials, prefill segment states); reuse is
+    ordered by the stream the ops run on."""
+    ws = _workspaces.get((device, tag))
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+        _workspaces[(device, tag)] = ws
     return ws
 
 
