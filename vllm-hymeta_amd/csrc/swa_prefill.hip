@@ -1,39 +1,69 @@
 // Varlen prefill attention: causal sliding window over the real keys plus an
 // always-visible block of meta keys, one softmax (flash-attention forward).
 //
-// MFMA-bound.  A 256-thread workgroup owns 128 consecutive queries of one
-// (sequence, q-head); each wave owns 32 of them as two 16-row MFMA tiles and
-// walks the visible keys in tiles of 32.  Operand plumbing is the same as in
-// the paged decode kernel, with query rows where the decode kernel has heads:
-//   S^T = K Q^T   (A = 16 key rows x 32 channels straight from memory,
-//                  B = the wave's resident Q fragments)
-//   O  += P V     (A = the S^T accumulators re-packed to bf16: the query is on
-//                  the lane and the keys are in registers, which is the
-//                  A-operand layout; B = V, 8 key rows x 16 bytes per lane,
-//                  transposed in registers with v_perm_b32)
+// MFMA-bound.  A 512-thread workgroup owns 256 consecutive queries of one
+// (sequence, q-head); each of its 8 waves owns 32 of them as two 16-row MFMA
+// tiles.  The workgroup walks the visible keys in tiles of 64: all threads
+// stage the tile's K and V rows once (global -> registers issued before the
+// tile's compute, registers -> LDS after it, one barrier per tile, two LDS
+// buffers), and every wave reads its operands from that shared image:
+//   S^T = K Q^T   A = 16 key rows x 32 channels, ds_read_b128 from the K image
+//                 (256-byte rows, 16-byte chunks XOR-ed with the row so the
+//                 sixteen rows of a read hit distinct banks);
+//                 B = the wave's resident Q fragments.
+//   O  += P V     A = the S^T accumulators re-packed to bf16: the query is on
+//                 the lane and the keys are in registers, which is the
+//                 A-operand layout up to a fixed permutation of the key slots;
+//                 B = V in the same permuted key order, two transposed 8-byte
+//                 LDS reads (ds_read_b64_tr_b16) per fragment from the V image
+//                 (288-byte rows: the four rows of a read sit 8 banks apart).
 // Keys are read through a block table (chunked / prefix prefill) or from the
-// packed [token, kv-head, dim] tensor of the step.
+// packed [token, kv-head, dim] tensor of the step.  Outputs are normalised,
+// staged through LDS and stored as whole 256-byte rows.
 #include "common.h"
 
 namespace hymeta {
 namespace {
 
-constexpr int kTile = 32;   // keys per step
+constexpr int kTile = 32;            // granularity required of the meta-key count
+constexpr int kTileK = 64;           // keys per step
 constexpr int kRowsPerWave = 32;
-constexpr int kRowsPerBlock = 128;
+constexpr int kRowsPerBlock = 256;
+constexpr int kThreads = 512;
+constexpr int kKPitch = 256;
+constexpr int kVPitch = 288;
+constexpr int kKBytes = kTileK * kKPitch;
+constexpr int kVBytes = kTileK * kVPitch;
+constexpr int kOPitch = 272;         // output staging rows (bf16 x 128 + pad)
 constexpr float kLog2e = 1.4426950408889634f;
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct Smem {
+  char k[2][kKBytes];
+  char v[2][kVBytes];
+};
+static_assert(sizeof(Smem) >= (kRowsPerBlock / kRowsPerWave) * kRowsPerWave * kOPitch, "output staging aliases the K/V images");
 
 __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ bf16x8 as_frag(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
+// 4 keys x 16 dims block read column-major: lane i of a 16-lane group gets dim i of the 4 keys.
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+}
+
 }  // namespace
 
-// grid = (ceil(max_seqlen_q / 128), num_seqs (+1: the meta-query rows), num_heads)
+// grid = (ceil(max_seqlen_q / 256), num_seqs (+1: the meta-query rows), num_heads)
 template <bool PAGED>
-__global__ __launch_bounds__(256) void swa_prefill_kernel(hymeta_swa_prefill_args a, float scale_log2) {
+__global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefill_args a, float scale_log2) {
   constexpr int D = kHeadDim;
+  __shared__ __attribute__((aligned(16))) Smem sm;
+
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -44,7 +74,8 @@ __global__ __launch_bounds__(256) void swa_prefill_kernel(hymeta_swa_prefill_arg
   const int h = blockIdx.z;
   const int kvh = h / (a.num_heads / a.num_kv_heads);
   const bool meta_rows = seq == a.num_seqs;  // this workgroup computes the meta-query rows
-  const int meta_tiles = a.meta_key != nullptr ? a.num_meta / kTile : 0;
+  const int M = a.meta_key != nullptr ? a.num_meta : 0;
+  const int meta_tiles = (M + kTileK - 1) / kTileK;
   const int out_row0 = a.meta_query != nullptr ? a.num_meta : 0;
 
   int Lq, Lk, q_first;        // query count, key count, first query row of the sequence
@@ -71,8 +102,10 @@ __global__ __launch_bounds__(256) void swa_prefill_kernel(hymeta_swa_prefill_arg
     q_stride_t = a.q_stride_t;
     out_first = out_row0 + q_first;
   }
-  const int row0 = blockIdx.x * kRowsPerBlock + wave * kRowsPerWave;  // first query of this wave
-  if (row0 >= Lq) return;
+  const int blk0 = blockIdx.x * kRowsPerBlock;
+  if (blk0 >= Lq) return;                      // workgroup-uniform
+  const int row0 = blk0 + wave * kRowsPerWave;  // first query of this wave
+  const bool active = row0 < Lq;               // idle waves still stage tiles and meet the barriers
   const int pos_shift = Lk - Lq;  // query r sits at key position r + pos_shift (bottom-right aligned)
 
   // Q fragments: qf[qt][ks] = Q[row0 + 16qt + n][32ks + 8c .. +7]
@@ -97,17 +130,26 @@ __global__ __launch_bounds__(256) void swa_prefill_kernel(hymeta_swa_prefill_arg
   float m_run[2] = {-INFINITY, -INFINITY};
   float l_run[2] = {0.f, 0.f};
 
-  // Real-key tile range visible to this wave's 32 queries.
+  // Real-key tile ranges: of this wave's 32 queries and of the workgroup's 256.
   const int last_row = min(row0 + kRowsPerWave, Lq) - 1;
   const int p_lo = row0 + pos_shift, p_hi = last_row + pos_shift;
-  int t_lo = 0, t_hi = -1;
-  if (!meta_rows && Lk > 0 && p_hi >= 0) {
-    const int k_lo = (a.window_left >= 0 && p_lo - a.window_left > 0) ? p_lo - a.window_left : 0;
-    const int k_hi = p_hi < Lk - 1 ? p_hi : Lk - 1;
-    t_lo = k_lo / kTile;
-    t_hi = k_hi / kTile;
+  int tw_lo = 0, tw_hi = -1, T_lo = 0, T_hi = -1;
+  if (!meta_rows && Lk > 0) {
+    if (active && p_hi >= 0) {
+      const int k_lo = (a.window_left >= 0 && p_lo - a.window_left > 0) ? p_lo - a.window_left : 0;
+      const int k_hi = p_hi < Lk - 1 ? p_hi : Lk - 1;
+      tw_lo = k_lo / kTileK;
+      tw_hi = k_hi / kTileK;
+    }
+    const int P_lo = blk0 + pos_shift, P_hi = min(blk0 + kRowsPerBlock, Lq) - 1 + pos_shift;
+    if (P_hi >= 0) {
+      const int k_lo = (a.window_left >= 0 && P_lo - a.window_left > 0) ? P_lo - a.window_left : 0;
+      const int k_hi = P_hi < Lk - 1 ? P_hi : Lk - 1;
+      T_lo = k_lo / kTileK;
+      T_hi = k_hi / kTileK;
+    }
   }
-  const int ntiles = meta_tiles + (t_hi - t_lo + 1);
+  const int ntiles = meta_tiles + (T_hi - T_lo + 1);
 
   const uint16_t* kglob = nullptr;
   const uint16_t* vglob = nullptr;
@@ -121,161 +163,167 @@ __global__ __launch_bounds__(256) void swa_prefill_kernel(hymeta_swa_prefill_arg
     vglob = reinterpret_cast<const uint16_t*>(a.value) + k_first * a.v_stride_t + static_cast<int64_t>(kvh) * a.v_stride_h;
   }
 
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const bool is_meta = tile < meta_tiles;
-    const uint16_t* krow[2];
-    const uint16_t* vrow[2];
-    int64_t kstride, vstride;
-    int pos0 = 0;
-    bool sub_ok[2] = {true, true};
-    if (is_meta) {
-      kstride = vstride = a.meta_stride_t;
-      const int64_t off = static_cast<int64_t>(tile) * kTile * a.meta_stride_t + static_cast<int64_t>(kvh) * a.meta_stride_h;
-      krow[0] = reinterpret_cast<const uint16_t*>(a.meta_key) + off;
-      vrow[0] = reinterpret_cast<const uint16_t*>(a.meta_value) + off;
-      krow[1] = krow[0] + 16 * kstride;
-      vrow[1] = vrow[0] + 16 * vstride;
-    } else {
-      pos0 = (t_lo + tile - meta_tiles) * kTile;
-      if constexpr (PAGED) {
-        kstride = vstride = a.cache_stride_pos;
+  // ---- staging role: thread = 16-byte chunk sc of key rows sr and sr + 32 of the tile
+  const int sr = tid >> 4, sc = tid & 15;
+  u32x4 kreg[2], vreg[2];
+  auto issue = [&](int tile) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int p = pos0 + 16 * s;
-          sub_ok[s] = p < Lk;
-          int64_t off = 0;
-          if (sub_ok[s]) {
-            const int blk = bt[p / a.block_size];
-            off = static_cast<int64_t>(blk) * a.cache_stride_block + static_cast<int64_t>(p % a.block_size) * a.cache_stride_pos;
-          }
-          krow[s] = kglob + off;
-          vrow[s] = vglob + off;
-        }
+    for (int i = 0; i < 2; ++i) {
+      const int r = sr + 32 * i;
+      const uint16_t* kp = nullptr;
+      const uint16_t* vp = nullptr;
+      bool ok;
+      if (tile < meta_tiles) {
+        const int idx = tile * kTileK + r;
+        ok = idx < M;
+        const int64_t off = static_cast<int64_t>(idx) * a.meta_stride_t + static_cast<int64_t>(kvh) * a.meta_stride_h + 8 * sc;
+        kp = reinterpret_cast<const uint16_t*>(a.meta_key) + off;
+        vp = reinterpret_cast<const uint16_t*>(a.meta_value) + off;
       } else {
-        kstride = a.k_stride_t;
-        vstride = a.v_stride_t;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          krow[s] = kglob + static_cast<int64_t>(pos0 + 16 * s) * kstride;
-          vrow[s] = vglob + static_cast<int64_t>(pos0 + 16 * s) * vstride;
+        const int p = (T_lo + tile - meta_tiles) * kTileK + r;
+        ok = p < Lk;   // rows past the sequence end: next sequence, outside the tensor, or stale cache
+        if constexpr (PAGED) {
+          int64_t off = 8 * sc;
+          if (ok) off += static_cast<int64_t>(bt[p / a.block_size]) * a.cache_stride_block +
+                         static_cast<int64_t>(p % a.block_size) * a.cache_stride_pos;
+          kp = kglob + off;
+          vp = vglob + off;
+        } else {
+          kp = kglob + static_cast<int64_t>(p) * a.k_stride_t + 8 * sc;
+          vp = vglob + static_cast<int64_t>(p) * a.v_stride_t + 8 * sc;
         }
       }
+      kreg[i] = ok ? ld16(kp) : u32x4{0u, 0u, 0u, 0u};
+      vreg[i] = ok ? ld16(vp) : u32x4{0u, 0u, 0u, 0u};
     }
-    // Every (query, key) pair of the tile visible?  (wave-uniform)
-    const bool full = is_meta || (pos0 + kTile - 1 <= p_lo && pos0 + kTile <= Lk &&
-                                  (a.window_left < 0 || p_hi - pos0 <= a.window_left) &&
-                                  row0 + kRowsPerWave <= Lq);
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = sr + 32 * i;
+      st16(&sm.k[buf][r * kKPitch + 16 * (sc ^ (r & 15))], kreg[i]);
+      st16(&sm.v[buf][r * kVPitch + 16 * sc], vreg[i]);
+    }
+  };
 
-    u32x4 kraw[2][4];
-    u32x4 vraw[8];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      // Un-paged rows past the sequence end belong to the next sequence or lie outside the tensor.
-      const bool row_ok = PAGED || is_meta ? sub_ok[s] : (pos0 + 16 * s + n < Lk);
-      const uint16_t* kp = krow[s] + static_cast<int64_t>(n) * kstride + 8 * c;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kraw[s][ks] = row_ok ? ld16(kp + 32 * ks) : u32x4{0u, 0u, 0u, 0u};
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int s = j >> 2;
-      const int kk = 4 * c + (j & 3);
-      const bool row_ok = PAGED || is_meta ? sub_ok[s] : (pos0 + 16 * s + kk < Lk);
-      const uint16_t* vp = vrow[s] + static_cast<int64_t>(kk) * vstride + 8 * n;
-      vraw[j] = row_ok ? ld16(vp) : u32x4{0u, 0u, 0u, 0u};
-    }
+  if (ntiles > 0) {
+    issue(0);
+    commit(0);
+  }
+  __syncthreads();
 
-    // S^T tiles: st[qt][s][r] = score(key 16s + 4c + r, query 16qt + n)
-    f32x4 st[2][2];
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int buf = tile & 1;
+    if (tile + 1 < ntiles) issue(tile + 1);
+
+    const bool is_meta = tile < meta_tiles;
+    const int rt = T_lo + tile - meta_tiles;   // real tile index
+    if (active && (is_meta || (rt >= tw_lo && rt <= tw_hi))) {
+      const int pos0 = is_meta ? tile * kTileK : rt * kTileK;
+      // Every (query, key) pair of the tile visible?  (wave-uniform)
+      const bool full = is_meta ? (pos0 + kTileK <= M)
+                                : (pos0 + kTileK - 1 <= p_lo && pos0 + kTileK <= Lk &&
+                                   (a.window_left < 0 || p_hi - pos0 <= a.window_left));
+      const char* kimg = sm.k[buf];
+      const char* vimg = sm.v[buf];
+
+      // S^T tiles: st[qt][s][r] = score(key 16s + 4c + r, query 16qt + n)
+      f32x4 st[2][4];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 kf[4];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        st[qt][s] = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = as_frag(ld16(kimg + (16 * s + n) * kKPitch + 16 * ((4 * ks + c) ^ n)));
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) st[qt][s] = mfma16(as_frag(kraw[s][ks]), qf[qt][ks], st[qt][s]);
+        for (int qt = 0; qt < 2; ++qt) {
+          st[qt][s] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) st[qt][s] = mfma16(kf[ks], qf[qt][ks], st[qt][s]);
+        }
       }
 
-    float sc[2][8];
+      if (!full) {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < 2; ++qt) {
+          const int qp = row0 + 16 * qt + n + pos_shift;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sc[qt][j] = st[qt][j >> 2][j & 3] * scale_log2;
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int kp = pos0 + 16 * s + 4 * c + r;
+              const bool ok = is_meta ? kp < M
+                                      : (kp <= qp && kp < Lk && (a.window_left < 0 || qp - kp <= a.window_left));
+              st[qt][s][r] = ok ? st[qt][s][r] : -INFINITY;
+            }
+        }
+      }
 
-    if (!full) {
+      // online softmax per query column; P re-packed as the A operand of P V:
+      // fragment kh, slot j <-> key 32kh + (j < 4 ? 4c + j : 16 + 4c + j - 4)
+      bf16x8 pf[2][2];
+      float alpha[2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        const int qr = row0 + 16 * qt + n;
-        const int qp = qr + pos_shift;
+        float tmax = fmaxf(fmaxf(st[qt][0][0], st[qt][0][1]), fmaxf(st[qt][0][2], st[qt][0][3]));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int kp = pos0 + 16 * (j >> 2) + 4 * c + (j & 3);
-          const bool ok = qr < Lq && kp <= qp && kp < Lk && (a.window_left < 0 || qp - kp <= a.window_left);
-          sc[qt][j] = ok ? sc[qt][j] : -INFINITY;
+        for (int s = 1; s < 4; ++s)
+          tmax = fmaxf(tmax, fmaxf(fmaxf(st[qt][s][0], st[qt][s][1]), fmaxf(st[qt][s][2], st[qt][s][3])));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run[qt], tmax);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        alpha[qt] = __builtin_amdgcn_exp2f((m_run[qt] - m_use) * scale_log2);
+        const float ms = m_use * scale_log2;
+        float psum = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          float p[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            p[j] = __builtin_amdgcn_exp2f(fmaf(st[qt][2 * kh + (j >> 2)][j & 3], scale_log2, -ms));
+            psum += p[j];
+          }
+          u32x4 pw;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pw[i] = pack_bf16x2(p[2 * i], p[2 * i + 1]);
+          pf[qt][kh] = as_frag(pw);
         }
+        l_run[qt] = l_run[qt] * alpha[qt] + psum;
+        m_run[qt] = m_new;
       }
-      if constexpr (PAGED) {
-        // Cache rows past the sequence end may hold anything; p = 0 does not neutralise NaN/Inf.
+      if (!__all(alpha[0] == 1.f && alpha[1] == 1.f)) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int kp = pos0 + 16 * (j >> 2) + 4 * c + (j & 3);
-          if (kp >= Lk) vraw[j] = u32x4{0u, 0u, 0u, 0u};
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(alpha[qt], 4 * c + r);  // o rows are queries 4c + r
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[qt][t][r] *= ar;
+          }
+      }
+
+      // O += P V : o[qt][t][r] = O[query 16qt + 4c + r][dim 16t + n]
+      const char* vlane = vimg + (4 * c + (n >> 2)) * kVPitch + 8 * (n & 3);
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const s16x4 lo = tr_read(vlane + (32 * kh) * kVPitch + 32 * t);
+          const s16x4 hi = tr_read(vlane + (32 * kh + 16) * kVPitch + 32 * t);
+          const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[0][t] = mfma16(pf[0][kh], vf, o[0][t]);
+          o[1][t] = mfma16(pf[1][kh], vf, o[1][t]);
         }
       }
     }
 
-    // online softmax per query column
-    bf16x8 pf[2];
-    float alpha[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      float tmax = sc[qt][0];
-#pragma unroll
-      for (int j = 1; j < 8; ++j) tmax = fmaxf(tmax, sc[qt][j]);
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-      const float m_new = fmaxf(m_run[qt], tmax);
-      const float m_use = m_new == -INFINITY ? 0.f : m_new;
-      alpha[qt] = __builtin_amdgcn_exp2f(m_run[qt] - m_use);
-      float p[8], psum = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        p[j] = __builtin_amdgcn_exp2f(sc[qt][j] - m_use);
-        psum += p[j];
-      }
-      l_run[qt] = l_run[qt] * alpha[qt] + psum;
-      m_run[qt] = m_new;
-      u32x4 pw;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pw[i] = pack_bf16x2(p[2 * i], p[2 * i + 1]);
-      pf[qt] = as_frag(pw);
-    }
-    if (!__all(alpha[0] == 1.f && alpha[1] == 1.f)) {
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float ar = __shfl(alpha[qt], 4 * c + r);  // o rows are queries 4c + r
-#pragma unroll
-          for (int t = 0; t < 8; ++t) o[qt][t][r] *= ar;
-        }
-    }
-
-    // O += P V
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      u32x4 vt;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const uint32_t x = vraw[2 * w][t >> 1], y = vraw[2 * w + 1][t >> 1];
-        vt[w] = (t & 1) ? __builtin_amdgcn_perm(y, x, 0x07060302u) : __builtin_amdgcn_perm(y, x, 0x05040100u);
-      }
-      o[0][t] = mfma16(pf[0], as_frag(vt), o[0][t]);
-      o[1][t] = mfma16(pf[1], as_frag(vt), o[1][t]);
-    }
+    if (tile + 1 < ntiles) commit(buf ^ 1);
+    __syncthreads();
   }
 
-  // epilogue: normalise and store.  o[qt][t][r] = O[query 16qt + 4c + r][dim 8n + t]
+  // epilogue: normalise, stage the wave's 32 x 128 outputs in LDS (the K/V images are free after
+  // the loop's last barrier), store whole rows.
+  char* ost = reinterpret_cast<char*>(&sm) + wave * (kRowsPerWave * kOPitch);
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     float l = l_run[qt];
@@ -285,15 +333,21 @@ __global__ __launch_bounds__(256) void swa_prefill_kernel(hymeta_swa_prefill_arg
     for (int r = 0; r < 4; ++r) {
       const float lr = __shfl(l, 4 * c + r);
       const float inv = lr > 0.f ? 1.f / lr : 0.f;
-      const int qr = row0 + 16 * qt + 4 * c + r;
-      if (qr < Lq) {
-        u32x4 w;
+      uint16_t* orow = reinterpret_cast<uint16_t*>(ost + (16 * qt + 4 * c + r) * kOPitch) + n;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[qt][2 * i][r] * inv, o[qt][2 * i + 1][r] * inv);
-        uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (out_first + qr) * a.out_stride_t +
-                       static_cast<int64_t>(h) * a.out_stride_h + 8 * n;
-        st16(op, w);
-      }
+      for (int t = 0; t < 8; ++t) orow[16 * t] = f2bf(o[qt][t][r] * inv);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int id = lane + 64 * i;
+    const int row = id >> 4, ch = id & 15;
+    const int qr = row0 + row;
+    if (qr < Lq) {
+      uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (out_first + qr) * a.out_stride_t +
+                     static_cast<int64_t>(h) * a.out_stride_h + 8 * ch;
+      st16(op, ld16(ost + row * kOPitch + 16 * ch));
     }
   }
 }
@@ -345,7 +399,7 @@ extern "C" int hymeta_meta_swa_prefill(const hymeta_swa_prefill_args* args, hyme
   if (!have_rows) a.num_seqs = 0;
   dim3 grid((max_rows + kRowsPerBlock - 1) / kRowsPerBlock, seqs + (a.meta_query != nullptr ? 1 : 0), a.num_heads);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (paged) hipLaunchKernelGGL((swa_prefill_kernel<true>), grid, dim3(256), 0, s, a, scale * kLog2e);
-  else hipLaunchKernelGGL((swa_prefill_kernel<false>), grid, dim3(256), 0, s, a, scale * kLog2e);
+  if (paged) hipLaunchKernelGGL((swa_prefill_kernel<true>), grid, dim3(kThreads), 0, s, a, scale * kLog2e);
+  else hipLaunchKernelGGL((swa_prefill_kernel<false>), grid, dim3(kThreads), 0, s, a, scale * kLog2e);
   return launch_status();
 }
