@@ -51,6 +51,13 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const 
 }
 __device__ __forceinline__ bf16x8 as_frag(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
+// max of three as ONE instruction (the plain fmaxf chain gets a canonicalising v_max per MFMA output).
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // 4 keys x 16 dims block read column-major: lane i of a 16-lane group gets dim i of the 4 keys.
 __device__ __forceinline__ s16x4 tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
@@ -128,7 +135,8 @@ __global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefil
 #pragma unroll
     for (int t = 0; t < 8; ++t) o[qt][t] = {0.f, 0.f, 0.f, 0.f};
   float m_run[2] = {-INFINITY, -INFINITY};
-  float l_run[2] = {0.f, 0.f};
+  f32x4 l_acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // l_acc[qt][r]: softmax denominator of query 16qt + 4c + r
+  const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
 
   // Real-key tile ranges: of this wave's 32 queries and of the workgroup's 256.
   const int last_row = min(row0 + kRowsPerWave, Lq) - 1;
@@ -245,14 +253,21 @@ __global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefil
       if (!full) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
+          // visible key positions of this lane's query: [lo, hi], as one unsigned range test
           const int qp = row0 + 16 * qt + n + pos_shift;
+          int lo = 0, hi = M - 1;
+          if (!is_meta) {
+            lo = a.window_left >= 0 ? max(qp - a.window_left, 0) : 0;
+            hi = min(qp, Lk - 1);
+          }
+          const bool any = hi >= lo;
+          const unsigned span = static_cast<unsigned>(hi - lo);
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int kp = pos0 + 16 * s + 4 * c + r;
-              const bool ok = is_meta ? kp < M
-                                      : (kp <= qp && kp < Lk && (a.window_left < 0 || qp - kp <= a.window_left));
+              const bool ok = any & (static_cast<unsigned>(kp - lo) <= span);
               st[qt][s][r] = ok ? st[qt][s][r] : -INFINITY;
             }
         }
@@ -264,31 +279,30 @@ __global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefil
       float alpha[2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        float tmax = fmaxf(fmaxf(st[qt][0][0], st[qt][0][1]), fmaxf(st[qt][0][2], st[qt][0][3]));
-#pragma unroll
-        for (int s = 1; s < 4; ++s)
-          tmax = fmaxf(tmax, fmaxf(fmaxf(st[qt][s][0], st[qt][s][1]), fmaxf(st[qt][s][2], st[qt][s][3])));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run[qt], tmax);
+        float tmax = max3(st[qt][0][0], st[qt][0][1], st[qt][0][2]);
+        tmax = max3(tmax, st[qt][0][3], st[qt][1][0]);
+        tmax = max3(tmax, st[qt][1][1], st[qt][1][2]);
+        tmax = max3(tmax, st[qt][1][3], st[qt][2][0]);
+        tmax = max3(tmax, st[qt][2][1], st[qt][2][2]);
+        tmax = max3(tmax, st[qt][2][3], st[qt][3][0]);
+        tmax = max3(tmax, st[qt][3][1], st[qt][3][2]);
+        tmax = max3(tmax, st[qt][3][3], st[qt][3][3]);
+        tmax = max3(tmax, __shfl_xor(tmax, 16), tmax);
+        const float m_new = max3(m_run[qt], tmax, __shfl_xor(tmax, 32));
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
         alpha[qt] = __builtin_amdgcn_exp2f((m_run[qt] - m_use) * scale_log2);
         const float ms = m_use * scale_log2;
-        float psum = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
           float p[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 0; j < 8; ++j)
             p[j] = __builtin_amdgcn_exp2f(fmaf(st[qt][2 * kh + (j >> 2)][j & 3], scale_log2, -ms));
-            psum += p[j];
-          }
           u32x4 pw;
 #pragma unroll
           for (int i = 0; i < 4; ++i) pw[i] = pack_bf16x2(p[2 * i], p[2 * i + 1]);
           pf[qt][kh] = as_frag(pw);
         }
-        l_run[qt] = l_run[qt] * alpha[qt] + psum;
         m_run[qt] = m_new;
       }
       if (!__all(alpha[0] == 1.f && alpha[1] == 1.f)) {
@@ -299,6 +313,7 @@ __global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefil
             const float ar = __shfl(alpha[qt], 4 * c + r);  // o rows are queries 4c + r
 #pragma unroll
             for (int t = 0; t < 8; ++t) o[qt][t][r] *= ar;
+            l_acc[qt][r] *= ar;
           }
       }
 
@@ -306,6 +321,9 @@ __global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefil
       const char* vlane = vimg + (4 * c + (n >> 2)) * kVPitch + 8 * (n & 3);
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
+        // row sums of the bf16 P that enters P V, on the matrix cores (B = ones)
+        l_acc[0] = mfma16(pf[0][kh], ones, l_acc[0]);
+        l_acc[1] = mfma16(pf[1][kh], ones, l_acc[1]);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           const s16x4 lo = tr_read(vlane + (32 * kh) * kVPitch + 32 * t);
@@ -326,12 +344,9 @@ __global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefil
   char* ost = reinterpret_cast<char*>(&sm) + wave * (kRowsPerWave * kOPitch);
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l = l_run[qt];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float lr = __shfl(l, 4 * c + r);
+      const float lr = l_acc[qt][r];
       const float inv = lr > 0.f ? 1.f / lr : 0.f;
       uint16_t* orow = reinterpret_cast<uint16_t*>(ost + (16 * qt + 4 * c + r) * kOPitch) + n;
 #pragma unroll
