@@ -173,27 +173,29 @@ __global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefil
 
   // ---- staging role: thread = 16-byte chunk sc of key rows sr and sr + 32 of the tile
   const int sr = tid >> 4, sc = tid & 15;
+  // Loads are unconditional (rows past the end are clamped to the last valid row and zeroed when
+  // they are committed), so nothing has to wait for them before the tile's compute.
   u32x4 kreg[2], vreg[2];
+  bool rok[2] = {false, false};
   auto issue = [&](int tile) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = sr + 32 * i;
-      const uint16_t* kp = nullptr;
-      const uint16_t* vp = nullptr;
-      bool ok;
+      const uint16_t* kp;
+      const uint16_t* vp;
       if (tile < meta_tiles) {
         const int idx = tile * kTileK + r;
-        ok = idx < M;
-        const int64_t off = static_cast<int64_t>(idx) * a.meta_stride_t + static_cast<int64_t>(kvh) * a.meta_stride_h + 8 * sc;
+        rok[i] = idx < M;
+        const int64_t off = static_cast<int64_t>(min(idx, M - 1)) * a.meta_stride_t + static_cast<int64_t>(kvh) * a.meta_stride_h + 8 * sc;
         kp = reinterpret_cast<const uint16_t*>(a.meta_key) + off;
         vp = reinterpret_cast<const uint16_t*>(a.meta_value) + off;
       } else {
-        const int p = (T_lo + tile - meta_tiles) * kTileK + r;
-        ok = p < Lk;   // rows past the sequence end: next sequence, outside the tensor, or stale cache
+        const int p_raw = (T_lo + tile - meta_tiles) * kTileK + r;
+        rok[i] = p_raw < Lk;   // rows past the sequence end: next sequence, outside the tensor, or stale cache
+        const int p = min(p_raw, Lk - 1);
         if constexpr (PAGED) {
-          int64_t off = 8 * sc;
-          if (ok) off += static_cast<int64_t>(bt[p / a.block_size]) * a.cache_stride_block +
-                         static_cast<int64_t>(p % a.block_size) * a.cache_stride_pos;
+          const int64_t off = static_cast<int64_t>(bt[p / a.block_size]) * a.cache_stride_block +
+                              static_cast<int64_t>(p % a.block_size) * a.cache_stride_pos + 8 * sc;
           kp = kglob + off;
           vp = vglob + off;
         } else {
@@ -201,16 +203,17 @@ __global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefil
           vp = vglob + static_cast<int64_t>(p) * a.v_stride_t + 8 * sc;
         }
       }
-      kreg[i] = ok ? ld16(kp) : u32x4{0u, 0u, 0u, 0u};
-      vreg[i] = ok ? ld16(vp) : u32x4{0u, 0u, 0u, 0u};
+      kreg[i] = ld16(kp);
+      vreg[i] = ld16(vp);
     }
   };
   auto commit = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = sr + 32 * i;
-      st16(&sm.k[buf][r * kKPitch + 16 * (sc ^ (r & 15))], kreg[i]);
-      st16(&sm.v[buf][r * kVPitch + 16 * sc], vreg[i]);
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      st16(&sm.k[buf][r * kKPitch + 16 * (sc ^ (r & 15))], rok[i] ? kreg[i] : z);
+      st16(&sm.v[buf][r * kVPitch + 16 * sc], rok[i] ? vreg[i] : z);
     }
   };
 
@@ -218,6 +221,12 @@ __global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefil
     issue(0);
     commit(0);
   }
+  // Pin the Q fragments as landed here: otherwise the first MFMA of EVERY tile waits for all
+  // outstanding global loads (the just-issued next tile included) on behalf of the Q loads above.
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qt][ks]));
   __syncthreads();
 
   for (int tile = 0; tile < ntiles; ++tile) {
