@@ -414,7 +414,9 @@ int hymeta_hybrid_combine(const hymeta_combine_args* args, hymeta_stream_t strea
  *   scales  [K / group, N]  fp16 or bf16;
  *   w[k, n] = scales[k/group, n] * (q[k, n] - (qzeros[k/group, n] + zero_offset)).
  * Rows are in natural order (g_idx[k] = k / group; act-order checkpoints are not supported).
- * Split-K: when split_k > 1 the partial sums meet in `workspace` (fp32 [M, N]).
+ * Split-K: when split_k > 1 the partial tiles meet in `workspace`
+ * (hymeta_gptq_gemm_workspace_bytes: fp32 slabs [split_k, M, N] + ticket counters);
+ * the last workgroup to reach an output tile sums its slabs and writes it.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_gptq_gemm_args {
   const void* x;          /* bf16 [M, K] */
@@ -423,7 +425,7 @@ typedef struct hymeta_gptq_gemm_args {
   const void* scales;
   const void* bias;       /* bf16 [N] or NULL */
   void* out;              /* bf16 [M, N] */
-  float* workspace;       /* fp32 [M, N] or NULL (needed when the library splits K) */
+  float* workspace;       /* hymeta_gptq_gemm_workspace_bytes() bytes, or NULL when split_k == 1 */
   size_t workspace_bytes;
   int32_t M, K, N;
   int32_t bits;           /* 4 or 8 */
@@ -435,6 +437,7 @@ typedef struct hymeta_gptq_gemm_args {
 } hymeta_gptq_gemm_args;
 
 int hymeta_gptq_gemm_split_k(int32_t M, int32_t K, int32_t N, int32_t group_size);
+size_t hymeta_gptq_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream_t stream);
 
 /* ------------------------------------------------------------------------

@@ -12,9 +12,13 @@
 //          pair (128 + q_w, 128 + q_{w+4}) in ONE VALU op; the k-order this
 //          induces (0,4,1,5,2,6,3,7) is applied to the activation fragment too.
 //   8-bit: v_cvt_f32_ubyteN + a byte-permute keep the exact integer in bf16.
+// Split-K partial tiles meet in fp32 slabs; the last workgroup to arrive at a tile sums and writes it
+// (no atomics on data, no second launch).
 // Scales and zeros are applied once per group, outside the MFMA chain:
 //   sum_k x w = s * ( sum_k x (c + q)  -  (c + z) * sum_k x ),   c = 128 (4-bit) or 0,
 // where sum_k x comes from one extra MFMA against an all-ones B fragment.
+#include <type_traits>
+
 #include "common.h"
 
 namespace hymeta {
@@ -35,11 +39,36 @@ __device__ __forceinline__ float load_scale(const void* p, int64_t idx, int dtyp
 
 constexpr int kColsPerBlock = 64;  // output columns per workgroup: lane n owns columns 4n .. 4n+3
 
+// Split-K meeting point shared by both GEMMs: every K-slice workgroup of an output tile stores its
+// fp32 partial tile ("slab") with plain stores, publishes it with one agent-scope release and
+// draws a ticket; the workgroup that draws the last ticket acquires and returns true: it sums the
+// slabs and writes the tile.  `flag` is one int of the caller's (already idle) LDS array.
+__device__ __forceinline__ bool last_arriver(int* counter, int splits, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = ticket == splits - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *flag = last ? 1 : 0;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
 }  // namespace
 
-// grid = (N / 64, ceil(M / (16 MT)), splits); 256 threads: the 4 waves take alternate groups.
-template <int BITS, int MT>
-__global__ __launch_bounds__(256) void gptq_gemm_kernel(hymeta_gptq_gemm_args a, int splits, int groups_per_split) {
+// grid = (N / 64, ceil(M / (16 MT)), splits); 256 threads: the 4 waves take alternate groups of
+// the workgroup's K slice; each wave's (group, k-step) sequence is software-pipelined one step
+// deep (next step's packed weights and activation fragments are in flight during the MFMAs).
+template <int BITS, int MT, int KSTEPS>
+__global__ __launch_bounds__(256) void gptq_gemm_kernel(hymeta_gptq_gemm_args a, int splits, int groups_per_split,
+                                                        float* slabs, int* counters) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* s_red = reinterpret_cast<float*>(smem_raw);  // [4 waves][16 MT rows][64 cols]
 
@@ -53,9 +82,9 @@ __global__ __launch_bounds__(256) void gptq_gemm_kernel(hymeta_gptq_gemm_args a,
   const int G = a.K / a.group_size;
   const int g_lo = split * groups_per_split;
   const int g_hi = min(G, g_lo + groups_per_split);
-  const int ksteps = a.group_size / 32;
   const int col0 = nb * kColsPerBlock + 4 * n;   // this lane's first output column
   constexpr int PACK = 32 / BITS;
+  constexpr int QL = BITS == 4 ? 1 : 2;          // 16-byte weight loads per k-step
 
   f32x4 acc_tot[MT][4];
 #pragma unroll
@@ -66,8 +95,52 @@ __global__ __launch_bounds__(256) void gptq_gemm_kernel(hymeta_gptq_gemm_args a,
   const u32x4 ones_raw = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
   const bf16x8 ones = as_frag(ones_raw);
   const uint16_t* xbase = reinterpret_cast<const uint16_t*>(a.x);
+  // rows past M read row M - 1 (their results are never stored)
+  const uint16_t* xrow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) xrow[mt] = xbase + static_cast<int64_t>(min(m0 + 16 * mt + n, a.M - 1)) * a.x_stride_m + 8 * c;
 
-  for (int g = g_lo + wave; g < g_hi; g += 4) {
+  const int first_g = g_lo + wave;
+  const int ng = first_g < g_hi ? (g_hi - first_g + 3) / 4 : 0;
+
+  // Register rings, refilled slot by slot as soon as a step has consumed its slot: packed weights
+  // (HBM latency, 16 bytes per lane and step) two groups ahead, activation fragments (L2 hits,
+  // 16 MT bytes) kXDepth steps ahead, a group's scales and zeros one group ahead.  Control flow is
+  // uniform and every load unconditional (steps past the end re-read the last step; an odd group
+  // count is padded with a group of zero scale): with conditional issue the compiler cannot count
+  // the loads in flight and drains them all at the next use.
+  constexpr int kWDepth = 2 * KSTEPS;
+  constexpr int kXCap = MT == 1 ? 8 : (MT == 2 ? 4 : 2);
+  constexpr int kXDepth = kWDepth < kXCap ? kWDepth : kXCap;
+  const int ngp = (ng + 1) & ~1;
+  const int last_step = ng * KSTEPS - 1;
+  u32x4 qring[kWDepth][QL], xring[kXDepth][MT];
+  u32x2 sraw[2];     // 4 scales (16-bit) of the lane's columns
+  uint32_t zraw[2];  // packed zeros word holding the lane's columns
+  auto step_k0 = [&](int t) {
+    const int g = first_g + 4 * (t / KSTEPS);
+    return g * a.group_size + 32 * (t % KSTEPS);   // + 8c inside the pointers
+  };
+  auto load_w = [&](int t, u32x4 (&q)[QL]) {
+    const int32_t* qp = a.qweight + static_cast<int64_t>((step_k0(min(t, last_step)) + 8 * c) / PACK) * a.N + col0;
+#pragma unroll
+    for (int i = 0; i < QL; ++i) q[i] = ld16(qp + static_cast<int64_t>(i) * a.N);
+  };
+  auto load_x = [&](int t, u32x4 (&x)[MT]) {
+    const int k0 = step_k0(min(t, last_step));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) x[mt] = ld16(xrow[mt] + k0);
+  };
+  auto load_params = [&](int gi, u32x2& sr, uint32_t& zr) {
+    const int g = first_g + 4 * min(gi, ng - 1);
+    sr = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.scales) + static_cast<int64_t>(g) * a.N + col0);
+    zr = static_cast<uint32_t>(a.qzeros[static_cast<int64_t>(g) * (a.N / PACK) + col0 / PACK]);
+  };
+
+  auto do_group = [&](int gi, auto parity) {
+    constexpr int PAR = decltype(parity)::value;
+    load_params(gi + 1, sraw[PAR ^ 1], zraw[PAR ^ 1]);
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc_g[MT][4], acc_x[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -75,22 +148,24 @@ __global__ __launch_bounds__(256) void gptq_gemm_kernel(hymeta_gptq_gemm_args a,
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc_g[mt][i] = {0.f, 0.f, 0.f, 0.f};
     }
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const int k0 = g * a.group_size + 32 * ks + 8 * c;   // this lane group's 8 k-values
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      constexpr int kDummy = 0;
+      (void)kDummy;
+      const int t = gi * KSTEPS + ks;
+      const int wslot = PAR * KSTEPS + ks;
+      const int xslot = wslot % kXDepth;
       // ---- weights: 8 k-values x 4 columns per lane
       u32x4 bq[4];
       if constexpr (BITS == 4) {
-        const u32x4 qw = ld16(a.qweight + static_cast<int64_t>(k0 / 8) * a.N + col0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int w = 0; w < 4; ++w) bq[i][w] = ((qw[i] >> (4 * w)) & 0x000F000Fu) | 0x43004300u;
+          for (int w = 0; w < 4; ++w) bq[i][w] = ((qring[wslot][0][i] >> (4 * w)) & 0x000F000Fu) | 0x43004300u;
       } else {
-        const u32x4 qa = ld16(a.qweight + static_cast<int64_t>(k0 / 4) * a.N + col0);
-        const u32x4 qb = ld16(a.qweight + static_cast<int64_t>(k0 / 4 + 1) * a.N + col0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const uint32_t lohi[2] = {qa[i], qb[i]};
+          const uint32_t lohi[2] = {qring[wslot][0][i], qring[wslot][QL - 1][i]};
 #pragma unroll
           for (int hw = 0; hw < 2; ++hw) {
             const float f0 = static_cast<float>(lohi[hw] & 0xffu);
@@ -103,12 +178,13 @@ __global__ __launch_bounds__(256) void gptq_gemm_kernel(hymeta_gptq_gemm_args a,
           }
         }
       }
+      load_w(t + kWDepth, qring[wslot]);
+      __builtin_amdgcn_sched_barrier(0);   // keep the refill here: the scheduler would sink it to its use
       // ---- activations: 16 rows x 8 k per m-tile
+      bf16x8 af[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int row = m0 + 16 * mt + n;
-        u32x4 xr = {0u, 0u, 0u, 0u};
-        if (row < a.M) xr = ld16(xbase + static_cast<int64_t>(row) * a.x_stride_m + k0);
+        u32x4 xr = xring[xslot][mt];
         if constexpr (BITS == 4) {
           // k-slot order (0,4,1,5,2,6,3,7), the order the nibble trick emits
           u32x4 xp;
@@ -118,24 +194,29 @@ __global__ __launch_bounds__(256) void gptq_gemm_kernel(hymeta_gptq_gemm_args a,
           xp[3] = __builtin_amdgcn_perm(xr[3], xr[1], 0x07060302u);
           xr = xp;
         }
-        const bf16x8 af = as_frag(xr);
+        af[mt] = as_frag(xr);
+      }
+      load_x(t + kXDepth, xring[xslot]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc_g[mt][i] = mfma16(af, as_frag(bq[i]), acc_g[mt][i]);
-        acc_x[mt] = mfma16(af, ones, acc_x[mt]);
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc_g[mt][i] = mfma16(af[mt], as_frag(bq[i]), acc_g[mt][i]);
+        acc_x[mt] = mfma16(af[mt], ones, acc_x[mt]);
       }
     }
-    // ---- group epilogue: scales and zeros of this lane's 4 columns
+    // ---- group epilogue: s * (sum x (c + q) - (c + z) * sum x), zero scale for a padding group
+    const bool real = gi < ng;
+    const uint32_t zw = zraw[PAR];
+    const int first = col0 % PACK;
     float sc[4], zf[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sc[i] = load_scale(a.scales, static_cast<int64_t>(g) * a.N + col0 + i, a.scales_dtype);
-    {
-      const uint32_t zw = static_cast<uint32_t>(a.qzeros[static_cast<int64_t>(g) * (a.N / PACK) + col0 / PACK]);
-      const int first = col0 % PACK;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t z = (zw >> (BITS * (first + i))) & ((1u << BITS) - 1u);
-        zf[i] = static_cast<float>(z + a.zero_offset) + (BITS == 4 ? 128.f : 0.f);
-      }
+    for (int i = 0; i < 4; ++i) {
+      const uint16_t raw = static_cast<uint16_t>(sraw[PAR][i >> 1] >> (16 * (i & 1)));
+      const float sv = a.scales_dtype == HYMETA_F16 ? static_cast<float>(__builtin_bit_cast(_Float16, raw)) : bf2f(raw);
+      sc[i] = real ? sv : 0.f;
+      const uint32_t z = (zw >> (BITS * (first + i))) & ((1u << BITS) - 1u);
+      zf[i] = static_cast<float>(z + a.zero_offset) + (BITS == 4 ? 128.f : 0.f);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -144,6 +225,18 @@ __global__ __launch_bounds__(256) void gptq_gemm_kernel(hymeta_gptq_gemm_args a,
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           acc_tot[mt][i][r] += sc[i] * (acc_g[mt][i][r] - zf[i] * acc_x[mt][r]);
+  };
+
+  if (ng > 0) {
+#pragma unroll
+    for (int p = 0; p < kWDepth; ++p) load_w(p, qring[p]);
+#pragma unroll
+    for (int p = 0; p < kXDepth; ++p) load_x(p, xring[p]);
+    load_params(0, sraw[0], zraw[0]);
+    for (int gi = 0; gi < ngp; gi += 2) {
+      do_group(gi, std::integral_constant<int, 0>{});
+      do_group(gi + 1, std::integral_constant<int, 1>{});
+    }
   }
 
   // ---- reduce the 4 waves: s_red[wave][row][col], row = 16 mt + 4c + r, col = 4n + i
@@ -156,43 +249,44 @@ __global__ __launch_bounds__(256) void gptq_gemm_kernel(hymeta_gptq_gemm_args a,
     }
   __syncthreads();
   const int cg = tid & 15;          // 4 columns per thread
-  for (int row = tid >> 4; row < 16 * MT; row += 16) {
-    const int grow = m0 + row;
-    if (grow >= a.M) break;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const int col = nb * kColsPerBlock + 4 * cg;
+  f32x4 sum[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int row = (tid >> 4) + 16 * j;
+    sum[j] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < 4; ++w)
-      s += *reinterpret_cast<const f32x4*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kColsPerBlock + 4 * cg);
-    const int col = nb * kColsPerBlock + 4 * cg;
-    if (splits == 1) {
-      if (a.bias != nullptr) {
-        const u32x2 bw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.bias) + col);
-        s[0] += lo_bf(bw[0]); s[1] += hi_bf(bw[0]); s[2] += lo_bf(bw[1]); s[3] += hi_bf(bw[1]);
-      }
-      u32x2 o = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
-      *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(grow) * a.out_stride_m + col) = o;
-    } else {
-      float* w = a.workspace + static_cast<int64_t>(grow) * a.N + col;
+      sum[j] += *reinterpret_cast<const f32x4*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kColsPerBlock + 4 * cg);
+  }
+  if (splits > 1) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) atomicAdd(w + i, s[i]);
+    for (int j = 0; j < MT; ++j) {
+      const int grow = m0 + (tid >> 4) + 16 * j;
+      if (grow < a.M) *reinterpret_cast<f32x4*>(slabs + (static_cast<int64_t>(split) * a.M + grow) * a.N + col) = sum[j];
+    }
+    if (!last_arriver(counters + blockIdx.y * gridDim.x + blockIdx.x, splits, reinterpret_cast<int*>(s_red))) return;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int grow = m0 + (tid >> 4) + 16 * j;
+      sum[j] = {0.f, 0.f, 0.f, 0.f};
+      if (grow < a.M)
+        for (int sp = 0; sp < splits; ++sp)
+          sum[j] += *reinterpret_cast<const f32x4*>(slabs + (static_cast<int64_t>(sp) * a.M + grow) * a.N + col);
     }
   }
-}
-
-// out = bf16(workspace + bias), 4 columns per thread.
-__global__ __launch_bounds__(256) void gptq_finalize_kernel(hymeta_gptq_gemm_args a) {
-  const int64_t total = static_cast<int64_t>(a.M) * (a.N / 4);
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const int64_t row = i / (a.N / 4);
-    const int col = static_cast<int>(i % (a.N / 4)) * 4;
-    f32x4 s = *reinterpret_cast<const f32x4*>(a.workspace + row * a.N + col);
-    if (a.bias != nullptr) {
-      const u32x2 bw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.bias) + col);
-      s[0] += lo_bf(bw[0]); s[1] += hi_bf(bw[0]); s[2] += lo_bf(bw[1]); s[3] += hi_bf(bw[1]);
-    }
-    u32x2 o = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
-    *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + row * a.out_stride_m + col) = o;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias != nullptr) {
+    const u32x2 bw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.bias) + col);
+    bias = f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+  }
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int grow = m0 + (tid >> 4) + 16 * j;
+    if (grow >= a.M) continue;
+    const f32x4 y = sum[j] + bias;
+    const u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+    *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(grow) * a.out_stride_m + col) = o;
   }
 }
 
@@ -312,17 +406,30 @@ using namespace hymeta;
 
 static int mt_for(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : 4); }
 
+static int64_t gptq_tiles(int M, int N) {
+  const int mt = mt_for(M);
+  return static_cast<int64_t>(N / kColsPerBlock) * ((M + 16 * mt - 1) / (16 * mt));
+}
+
 extern "C" int hymeta_gptq_gemm_split_k(int32_t M, int32_t K, int32_t N, int32_t group_size) {
   if (M <= 0 || K <= 0 || N <= 0 || group_size <= 0) return 1;
-  const int mt = mt_for(M);
-  int64_t blocks = static_cast<int64_t>(N / kColsPerBlock) * ((M + 16 * mt - 1) / (16 * mt));
-  if (blocks < 1) blocks = 1;
+  int64_t tiles = gptq_tiles(M, N);
+  if (tiles < 1) tiles = 1;
   const int G = K / group_size;
-  int64_t want = (512 + blocks - 1) / blocks;      // enough workgroups to cover the chip twice
+  // About one workgroup per compute unit (measured: a workgroup's latency barely depends on its
+  // K slice; more slices only add slab traffic, for skinny M too).
+  int64_t want = 256 / tiles;
   const int64_t cap = G / 4 > 1 ? G / 4 : 1;       // every wave of a workgroup gets at least one group
   if (want > cap) want = cap;
   if (want < 1) want = 1;
   return static_cast<int>(want);
+}
+
+extern "C" size_t hymeta_gptq_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
+  if (M <= 0 || N <= 0 || split_k <= 1) return 0;
+  const size_t slabs = static_cast<size_t>(split_k) * M * N * sizeof(float);
+  const size_t counters = (static_cast<size_t>(gptq_tiles(M, N)) * sizeof(int) + 255) / 256 * 256;
+  return slabs + counters;
 }
 
 extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream_t stream) {
@@ -344,31 +451,35 @@ extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream
   int splits = a.split_k > 0 ? a.split_k : hymeta_gptq_gemm_split_k(a.M, a.K, a.N, a.group_size);
   if (splits > G) splits = G;
   if (splits > 1) {
-    const size_t need = static_cast<size_t>(a.M) * a.N * sizeof(float);
-    if (a.workspace == nullptr || a.workspace_bytes < need) return HYMETA_ERR_WORKSPACE;
+    if (a.workspace == nullptr || a.workspace_bytes < hymeta_gptq_gemm_workspace_bytes(a.M, a.N, splits)) return HYMETA_ERR_WORKSPACE;
   }
+  const int requested = splits;
   const int gps = (G + splits - 1) / splits;
   splits = (G + gps - 1) / gps;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (splits > 1 && hipMemsetAsync(a.workspace, 0, static_cast<size_t>(a.M) * a.N * sizeof(float), s) != hipSuccess)
+  // workspace = [slabs fp32 [requested splits][M][N]][ticket counters, zeroed per call]
+  float* slabs = a.workspace;
+  int* counters = reinterpret_cast<int*>(reinterpret_cast<char*>(a.workspace) + static_cast<size_t>(requested) * a.M * a.N * sizeof(float));
+  if (splits > 1 && hipMemsetAsync(counters, 0, static_cast<size_t>(gptq_tiles(a.M, a.N)) * sizeof(int), s) != hipSuccess)
     return HYMETA_ERR_LAUNCH;
   const int mt = mt_for(a.M);
   dim3 grid(a.N / kColsPerBlock, (a.M + 16 * mt - 1) / (16 * mt), splits), block(256);
   const size_t lds = static_cast<size_t>(4) * 16 * mt * kColsPerBlock * sizeof(float);
-#define HYMETA_LAUNCH_GPTQ(B, T) hipLaunchKernelGGL((gptq_gemm_kernel<B, T>), grid, block, lds, s, a, splits, gps)
+#define HYMETA_LAUNCH_GPTQ(B, T, KS) \
+  hipLaunchKernelGGL((gptq_gemm_kernel<B, T, KS>), grid, block, lds, s, a, splits, gps, slabs, counters)
+#define HYMETA_LAUNCH_GPTQ_KS(B, T)                   \
+  do {                                                \
+    if (a.group_size == 128) HYMETA_LAUNCH_GPTQ(B, T, 4); \
+    else if (a.group_size == 64) HYMETA_LAUNCH_GPTQ(B, T, 2); \
+    else HYMETA_LAUNCH_GPTQ(B, T, 1);                 \
+  } while (0)
   if (a.bits == 4) {
-    if (mt == 1) HYMETA_LAUNCH_GPTQ(4, 1); else if (mt == 2) HYMETA_LAUNCH_GPTQ(4, 2); else HYMETA_LAUNCH_GPTQ(4, 4);
+    if (mt == 1) HYMETA_LAUNCH_GPTQ_KS(4, 1); else if (mt == 2) HYMETA_LAUNCH_GPTQ_KS(4, 2); else HYMETA_LAUNCH_GPTQ_KS(4, 4);
   } else {
-    if (mt == 1) HYMETA_LAUNCH_GPTQ(8, 1); else if (mt == 2) HYMETA_LAUNCH_GPTQ(8, 2); else HYMETA_LAUNCH_GPTQ(8, 4);
+    if (mt == 1) HYMETA_LAUNCH_GPTQ_KS(8, 1); else if (mt == 2) HYMETA_LAUNCH_GPTQ_KS(8, 2); else HYMETA_LAUNCH_GPTQ_KS(8, 4);
   }
+#undef HYMETA_LAUNCH_GPTQ_KS
 #undef HYMETA_LAUNCH_GPTQ
-  if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
-  if (splits > 1) {
-    const int64_t total = static_cast<int64_t>(a.M) * (a.N / 4);
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gptq_finalize_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
-  }
   return launch_status();
 }
 

@@ -170,6 +170,7 @@ _SIGNATURES = {
     "hymeta_rms_sumsq2": (C.c_int, [C.POINTER(CombineArgs), _ptr]),
     "hymeta_hybrid_combine": (C.c_int, [C.POINTER(CombineArgs), _ptr]),
     "hymeta_gptq_gemm_split_k": (C.c_int, [_i32, _i32, _i32, _i32]),
+    "hymeta_gptq_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "hymeta_gptq_gemm": (C.c_int, [C.POINTER(GptqGemmArgs), _ptr]),
     "hymeta_w8a8_gemm": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),
 }

@@ -528,7 +528,7 @@ def gptq_gemm(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scal
     a = _C.GptqGemmArgs()
     ws = None
     if split_k > 1:
-        ws = _workspace(x.device, M * N * 4)
+        ws = _workspace(x.device, int(lib.hymeta_gptq_gemm_workspace_bytes(M, N, split_k)), "gptq_gemm")
         a.workspace, a.workspace_bytes = _p(ws), ws.numel()
     a.x, a.qweight, a.qzeros, a.scales, a.bias, a.out = _p(x), _p(qweight), _p(qzeros), _p(scales), _p(bias), _p(out)
     a.M, a.K, a.N, a.bits, a.group_size = M, K, N, bits, group_size
