@@ -448,6 +448,8 @@ int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream_t stream);
  *   s_x[m] = max|x[m,:]| / 127 ; xq = clamp(rint(x / s_x), -128, 127)
  *   out[m, n] = bf16( (sum_k xq[m,k] wq[n,k]) * s_x[m] * w_scale[n] + bias[n] )
  * xq / x_scale are caller-owned scratch ([M, K] int8, [M] fp32).
+ * Split-K as in hymeta_gptq_gemm (exact int32 slabs): split_k <= 0 lets the
+ * library choose when a workspace is given, and means 1 without one.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_w8a8_gemm_args {
   const void* x;           /* bf16 [M, K] */
@@ -459,7 +461,13 @@ typedef struct hymeta_w8a8_gemm_args {
   float* x_scale;          /* scratch fp32 [M] */
   int32_t M, K, N;
   int64_t x_stride_m, out_stride_m;
+  void* workspace;         /* hymeta_w8a8_gemm_workspace_bytes() bytes, or NULL */
+  size_t workspace_bytes;
+  int32_t split_k;
 } hymeta_w8a8_gemm_args;
+
+int hymeta_w8a8_gemm_split_k(int32_t M, int32_t K, int32_t N);
+size_t hymeta_w8a8_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 
 int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream);
 

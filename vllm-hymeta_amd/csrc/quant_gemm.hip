@@ -331,9 +331,11 @@ __global__ __launch_bounds__(256) void w8a8_quant_kernel(hymeta_w8a8_gemm_args a
   }
 }
 
-// grid = (N / 64, ceil(M / (16 MT))); the 4 waves take alternate 64-deep k-steps.
+// grid = (N / 64, ceil(M / (16 MT)), splits); the 4 waves take alternate 64-deep k-steps of the
+// workgroup's K slice; slices meet in int32 slabs (exact), the last arriver scales and writes.
 template <int MT>
-__global__ __launch_bounds__(256) void w8a8_gemm_kernel(hymeta_w8a8_gemm_args a) {
+__global__ __launch_bounds__(256) void w8a8_gemm_kernel(hymeta_w8a8_gemm_args a, int splits, int steps_per_split,
+                                                        int* slabs, int* counters) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int* s_red = reinterpret_cast<int*>(smem_raw);  // [4 waves][16 MT rows][64 cols]
   const int tid = threadIdx.x;
@@ -349,8 +351,10 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(hymeta_w8a8_gemm_args a)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[mt][i] = {0, 0, 0, 0};
 
-  const int ksteps = a.K / 64;
-  for (int ks = wave; ks < ksteps; ks += 4) {
+  const int split = blockIdx.z;
+  const int ks_lo = split * steps_per_split;
+  const int ks_hi = min(a.K / 64, ks_lo + steps_per_split);
+  for (int ks = ks_lo + wave; ks < ks_hi; ks += 4) {
     const int k0 = 64 * ks + 16 * c;
     i32x4 bfrag[4];
 #pragma unroll
@@ -378,24 +382,47 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(hymeta_w8a8_gemm_args a)
         s_red[(static_cast<size_t>(wave) * 16 * MT + 16 * mt + 4 * c + r) * kColsPerBlock + 16 * i + n] = acc[mt][i][r];
   __syncthreads();
   const int cg = tid & 15;
-  for (int row = tid >> 4; row < 16 * MT; row += 16) {
-    const int grow = m0 + row;
-    if (grow >= a.M) break;
-    i32x4 s = {0, 0, 0, 0};
+  const int col = nb * kColsPerBlock + 4 * cg;
+  i32x4 sum[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int row = (tid >> 4) + 16 * j;
+    sum[j] = {0, 0, 0, 0};
 #pragma unroll
     for (int w = 0; w < 4; ++w)
-      s += *reinterpret_cast<const i32x4*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kColsPerBlock + 4 * cg);
-    const int col = nb * kColsPerBlock + 4 * cg;
+      sum[j] += *reinterpret_cast<const i32x4*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kColsPerBlock + 4 * cg);
+  }
+  if (splits > 1) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int grow = m0 + (tid >> 4) + 16 * j;
+      if (grow < a.M) *reinterpret_cast<i32x4*>(slabs + (static_cast<int64_t>(split) * a.M + grow) * a.N + col) = sum[j];
+    }
+    if (!last_arriver(counters + blockIdx.y * gridDim.x + blockIdx.x, splits, s_red)) return;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int grow = m0 + (tid >> 4) + 16 * j;
+      sum[j] = {0, 0, 0, 0};
+      if (grow < a.M)
+        for (int sp = 0; sp < splits; ++sp)
+          sum[j] += *reinterpret_cast<const i32x4*>(slabs + (static_cast<int64_t>(sp) * a.M + grow) * a.N + col);
+    }
+  }
+  const f32x4 ws = *reinterpret_cast<const f32x4*>(a.w_scale + col);
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias != nullptr) {
+    const u32x2 bw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.bias) + col);
+    bias = f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+  }
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int grow = m0 + (tid >> 4) + 16 * j;
+    if (grow >= a.M) continue;
     const float xs = a.x_scale[grow];
-    const f32x4 ws = *reinterpret_cast<const f32x4*>(a.w_scale + col);
     float y[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = static_cast<float>(s[i]) * xs * ws[i];
-    if (a.bias != nullptr) {
-      const u32x2 bw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.bias) + col);
-      y[0] += lo_bf(bw[0]); y[1] += hi_bf(bw[0]); y[2] += lo_bf(bw[1]); y[3] += hi_bf(bw[1]);
-    }
-    u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+    for (int i = 0; i < 4; ++i) y[i] = static_cast<float>(sum[j][i]) * xs * ws[i] + bias[i];
+    const u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
     *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(grow) * a.out_stride_m + col) = o;
   }
 }
@@ -483,6 +510,21 @@ extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream
   return launch_status();
 }
 
+extern "C" int hymeta_w8a8_gemm_split_k(int32_t M, int32_t K, int32_t N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 1;
+  int64_t tiles = gptq_tiles(M, N);
+  if (tiles < 1) tiles = 1;
+  int64_t want = 256 / tiles;                       // about one workgroup per compute unit
+  const int64_t cap = K / 64 / 8 > 1 ? K / 64 / 8 : 1;   // at least two k-steps per wave
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  return static_cast<int>(want);
+}
+
+extern "C" size_t hymeta_w8a8_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
+  return hymeta_gptq_gemm_workspace_bytes(M, N, split_k);   // same layout: 4-byte slabs + ticket counters
+}
+
 extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream) {
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
   const hymeta_w8a8_gemm_args& a = *args;
@@ -492,16 +534,29 @@ extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream
   if (a.K % 64 != 0 || a.N % kColsPerBlock != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((a.x_stride_m | a.out_stride_m) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.qweight) | reinterpret_cast<uintptr_t>(a.out) |
-       reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.xq) | reinterpret_cast<uintptr_t>(a.w_scale)) % 16 != 0)
+       reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.xq) | reinterpret_cast<uintptr_t>(a.w_scale) |
+       reinterpret_cast<uintptr_t>(a.workspace)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
+  const int ksteps = a.K / 64;
+  int splits = a.split_k > 0 ? a.split_k : (a.workspace != nullptr ? hymeta_w8a8_gemm_split_k(a.M, a.K, a.N) : 1);
+  if (splits > ksteps) splits = ksteps;
+  if (splits > 1 && (a.workspace == nullptr || a.workspace_bytes < hymeta_w8a8_gemm_workspace_bytes(a.M, a.N, splits)))
+    return HYMETA_ERR_WORKSPACE;
+  const int requested = splits;
+  const int sps = (ksteps + splits - 1) / splits;
+  splits = (ksteps + sps - 1) / sps;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  int* slabs = static_cast<int*>(a.workspace);
+  int* counters = reinterpret_cast<int*>(static_cast<char*>(a.workspace) + static_cast<size_t>(requested) * a.M * a.N * sizeof(int));
+  if (splits > 1 && hipMemsetAsync(counters, 0, static_cast<size_t>(gptq_tiles(a.M, a.N)) * sizeof(int), s) != hipSuccess)
+    return HYMETA_ERR_LAUNCH;
   hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
   if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
   const int mt = mt_for(a.M);
-  dim3 grid(a.N / kColsPerBlock, (a.M + 16 * mt - 1) / (16 * mt)), block(256);
+  dim3 grid(a.N / kColsPerBlock, (a.M + 16 * mt - 1) / (16 * mt), splits), block(256);
   const size_t lds = static_cast<size_t>(4) * 16 * mt * kColsPerBlock * sizeof(int);
-  if (mt == 1) hipLaunchKernelGGL((w8a8_gemm_kernel<1>), grid, block, lds, s, a);
-  else if (mt == 2) hipLaunchKernelGGL((w8a8_gemm_kernel<2>), grid, block, lds, s, a);
-  else hipLaunchKernelGGL((w8a8_gemm_kernel<4>), grid, block, lds, s, a);
+  if (mt == 1) hipLaunchKernelGGL((w8a8_gemm_kernel<1>), grid, block, lds, s, a, splits, sps, slabs, counters);
+  else if (mt == 2) hipLaunchKernelGGL((w8a8_gemm_kernel<2>), grid, block, lds, s, a, splits, sps, slabs, counters);
+  else hipLaunchKernelGGL((w8a8_gemm_kernel<4>), grid, block, lds, s, a, splits, sps, slabs, counters);
   return launch_status();
 }

@@ -150,6 +150,7 @@ class W8A8GemmArgs(C.Structure):
         ("xq", _ptr), ("x_scale", _ptr),
         ("M", _i32), ("K", _i32), ("N", _i32),
         ("x_stride_m", _i64), ("out_stride_m", _i64),
+        ("workspace", _ptr), ("workspace_bytes", _sz), ("split_k", _i32),
     ]
 
 
@@ -173,6 +174,8 @@ _SIGNATURES = {
     "hymeta_gptq_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "hymeta_gptq_gemm": (C.c_int, [C.POINTER(GptqGemmArgs), _ptr]),
     "hymeta_w8a8_gemm": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),
+    "hymeta_w8a8_gemm_split_k": (C.c_int, [_i32, _i32, _i32]),
+    "hymeta_w8a8_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),
 }
 
 STRUCTS = {

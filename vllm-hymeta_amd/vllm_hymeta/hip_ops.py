@@ -561,5 +561,11 @@ def w8a8_gemm(x: torch.Tensor, qweight: torch.Tensor, w_scale: torch.Tensor,
         _p(x), _p(qweight), _p(w_scale), _p(bias), _p(out), _p(xq), _p(xs))
     a.M, a.K, a.N = M, K, N
     a.x_stride_m, a.out_stride_m = x.stride(0), out.stride(0)
-    _C.check(_C.load().hymeta_w8a8_gemm(C.byref(a), _stream(x)), "hymeta_w8a8_gemm")
+    lib = _C.load()
+    split_k = int(lib.hymeta_w8a8_gemm_split_k(M, K, N))
+    a.split_k = split_k
+    if split_k > 1:
+        ws = _workspace(x.device, int(lib.hymeta_w8a8_gemm_workspace_bytes(M, N, split_k)), "w8a8_gemm")
+        a.workspace, a.workspace_bytes = _p(ws), ws.numel()
+    _C.check(lib.hymeta_w8a8_gemm(C.byref(a), _stream(x)), "hymeta_w8a8_gemm")
     return out
