@@ -440,6 +440,14 @@ int hymeta_gptq_gemm_split_k(int32_t M, int32_t K, int32_t N, int32_t group_size
 size_t hymeta_gptq_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream_t stream);
 
+/* Whole-matrix form of the same dequantisation: out bf16 [K, N] = w[k, n] above, rounded to
+ * bf16.  For prefill-sized M the host side expands the weights once per call and runs a plain
+ * library bf16 GEMM on them (the choice vLLM's GPTQ linear method makes above its own row
+ * threshold for the layers cited above). */
+int hymeta_gptq_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, void* out,
+                        int32_t K, int32_t N, int32_t bits, int32_t group_size, int32_t scales_dtype,
+                        int32_t zero_offset, hymeta_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * W8A8 int8 linear: per-output-channel int8 weights, dynamic per-token int8
  * activations (compressed-tensors "W8A8" as written by hf_model/quant_w8a8.py:121-132

@@ -83,3 +83,37 @@ def test_quant_gemm_rejects_unsupported():
     sc = torch.ones(1, 48, dtype=torch.float16, device="cuda")
     with pytest.raises(RuntimeError):
         hip_ops.gptq_gemm(x, qw, qz, sc, 4, 128)
+
+
+@pytest.mark.parametrize("bits,group,scales_dtype", [(4, 128, torch.float16), (8, 64, torch.float16), (4, 32, torch.bfloat16)])
+def test_gptq_dequant_is_the_rounded_oracle_matrix(bits, group, scales_dtype):
+    """Whole-matrix dequantisation: bit-exact bf16 rounding of s * (q - z) evaluated in fp32."""
+    from oracle.quant import gptq_dequant_ref
+    from vllm_hymeta import hip_ops
+
+    K, N = 512, 192
+    qw, qz, scales = _gptq_problem(5, K, N, bits, group, scales_dtype)
+    w = hip_ops.gptq_dequant(qw.cuda(), qz.cuda(), scales.cuda(), bits, group)
+    torch.cuda.synchronize()
+    ref = gptq_dequant_ref(qw, qz, scales, bits, group).float().to(torch.bfloat16)   # s and (q - z) are exact in fp32
+    assert torch.equal(w.cpu(), ref)
+
+
+def test_gptq_linear_large_m_uses_expanded_weights():
+    """Above the row threshold the linear expands its weights and runs the library GEMM: same
+    result as the oracle within the bf16 tolerance, and equal code path selection on both sides
+    of the threshold."""
+    from oracle.quant import gptq_gemm_ref
+    from vllm_hymeta import linear as L
+
+    K, N, bits, group = 512, 256, 4, 128
+    qw, qz, scales = _gptq_problem(6, K, N, bits, group, torch.float16)
+    g_ = gen(7)
+    bias = randn_bf16(g_, N)
+    lin = L.HymetaLinear.from_gptq(qw.cuda(), qz.cuda(), scales.cuda(), bits, group, bias=bias.cuda())
+    for M in (L.GPTQ_EXPAND_ROWS, L.GPTQ_EXPAND_ROWS + 44):
+        x = randn_bf16(g_, M, K)
+        ref = gptq_gemm_ref(x, qw, qz, scales, bits, group, bias)
+        out = lin(x.cuda())
+        torch.cuda.synchronize()
+        assert_bf16_close(out.cpu(), ref, f"gptq linear M={M}", rel=8e-3)

@@ -290,6 +290,38 @@ __global__ __launch_bounds__(256) void gptq_gemm_kernel(hymeta_gptq_gemm_args a,
   }
 }
 
+// Whole-matrix dequantisation W[k][n] = bf16(s * (q - z)) for the prefill regime, where a library
+// bf16 GEMM on the expanded weights beats re-dequantising them per 64-row block.
+// Thread = one packed word row x 4 columns: 16-byte read, PACK rows of 8-byte writes.
+template <int BITS>
+__global__ __launch_bounds__(256) void gptq_dequant_kernel(const int32_t* __restrict__ qweight, const int32_t* __restrict__ qzeros,
+                                                           const void* __restrict__ scales, uint16_t* __restrict__ out, int K, int N,
+                                                           int group_size, int scales_dtype, int zero_offset) {
+  constexpr int PACK = 32 / BITS;
+  const int ncg = N / 4;
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= static_cast<int64_t>(K / PACK) * ncg) return;
+  const int kr = static_cast<int>(idx / ncg);
+  const int col = static_cast<int>(idx % ncg) * 4;
+  const int g = kr * PACK / group_size;
+  const u32x4 qw = ld16(qweight + static_cast<int64_t>(kr) * N + col);
+  const uint32_t zw = static_cast<uint32_t>(qzeros[static_cast<int64_t>(g) * (N / PACK) + col / PACK]);
+  float sc[4], zf[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sc[i] = load_scale(scales, static_cast<int64_t>(g) * N + col + i, scales_dtype);
+    zf[i] = static_cast<float>(((zw >> (BITS * (col % PACK + i))) & ((1u << BITS) - 1u)) + zero_offset);
+  }
+#pragma unroll
+  for (int j = 0; j < PACK; ++j) {
+    float w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = sc[i] * (static_cast<float>((qw[i] >> (BITS * j)) & ((1u << BITS) - 1u)) - zf[i]);
+    const u32x2 o = {pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3])};
+    *reinterpret_cast<u32x2*>(out + (static_cast<int64_t>(kr) * PACK + j) * N + col) = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // W8A8
 // ---------------------------------------------------------------------------------------------
@@ -507,6 +539,24 @@ extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream
   }
 #undef HYMETA_LAUNCH_GPTQ_KS
 #undef HYMETA_LAUNCH_GPTQ
+  return launch_status();
+}
+
+extern "C" int hymeta_gptq_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, void* out,
+                                   int32_t K, int32_t N, int32_t bits, int32_t group_size, int32_t scales_dtype,
+                                   int32_t zero_offset, hymeta_stream_t stream) {
+  if (!qweight || !qzeros || !scales || !out || K <= 0 || N <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (bits != 4 && bits != 8) return HYMETA_ERR_UNSUPPORTED;
+  if (group_size <= 0 || group_size % (32 / bits) != 0 || K % group_size != 0 || N % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if (scales_dtype != HYMETA_F16 && scales_dtype != HYMETA_BF16) return HYMETA_ERR_UNSUPPORTED;
+  if (zero_offset != 0 && zero_offset != 1) return HYMETA_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(qweight) | reinterpret_cast<uintptr_t>(out)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  const int64_t threads = static_cast<int64_t>(K / (32 / bits)) * (N / 4);
+  dim3 grid(static_cast<unsigned>((threads + 255) / 256)), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uint16_t* o = static_cast<uint16_t*>(out);
+  if (bits == 4) hipLaunchKernelGGL(gptq_dequant_kernel<4>, grid, block, 0, s, qweight, qzeros, scales, o, K, N, group_size, scales_dtype, zero_offset);
+  else hipLaunchKernelGGL(gptq_dequant_kernel<8>, grid, block, 0, s, qweight, qzeros, scales, o, K, N, group_size, scales_dtype, zero_offset);
   return launch_status();
 }
 

@@ -173,6 +173,7 @@ _SIGNATURES = {
     "hymeta_gptq_gemm_split_k": (C.c_int, [_i32, _i32, _i32, _i32]),
     "hymeta_gptq_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "hymeta_gptq_gemm": (C.c_int, [C.POINTER(GptqGemmArgs), _ptr]),
+    "hymeta_gptq_dequant": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "hymeta_w8a8_gemm": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),
     "hymeta_w8a8_gemm_split_k": (C.c_int, [_i32, _i32, _i32]),
     "hymeta_w8a8_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -539,6 +539,26 @@ def gptq_gemm(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scal
     return out
 
 
+def gptq_dequant(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor, bits: int, group_size: int,
+                 zero_offset: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GPTQ tensors -> bf16 weights [K, N] (so that y = x @ W)."""
+    _dev(qweight, qzeros, scales, out)
+    pack = 32 // bits
+    K, N = qweight.shape[0] * pack, qweight.shape[1]
+    _require(qweight.dtype == torch.int32 and qweight.is_contiguous(), "qweight must be contiguous int32 [K/pack, N]")
+    _require(qzeros.dtype == torch.int32 and qzeros.is_contiguous() and qzeros.shape == (K // group_size, N // pack),
+             "qzeros must be contiguous int32 [K/group, N/pack]")
+    _require(scales.dtype in (torch.float16, torch.bfloat16) and scales.is_contiguous()
+             and scales.shape == (K // group_size, N), "scales must be contiguous fp16/bf16 [K/group, N]")
+    if out is None:
+        out = torch.empty(K, N, dtype=torch.bfloat16, device=qweight.device)
+    _require(out.shape == (K, N) and out.dtype == torch.bfloat16 and out.is_contiguous(), "out must be contiguous bf16 [K, N]")
+    sd = _C.HYMETA_F16 if scales.dtype == torch.float16 else _C.HYMETA_BF16
+    _C.check(_C.load().hymeta_gptq_dequant(_p(qweight), _p(qzeros), _p(scales), _p(out), K, N, bits, group_size, sd,
+                                           zero_offset, _stream(qweight)), "hymeta_gptq_dequant")
+    return out
+
+
 def w8a8_gemm(x: torch.Tensor, qweight: torch.Tensor, w_scale: torch.Tensor,
               bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x bf16 [M,K] -> dynamic per-token int8; qweight int8 [N,K]; w_scale fp32 [N] -> bf16 [M,N]."""
