@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="decode sequences per GPU")
     ap.add_argument("--ctx", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the 32k prefill (TTFT) side measurement")
+    ap.add_argument("--prefill-ctx", type=int, default=32768)
     return ap.parse_args()
 
 
@@ -117,6 +119,62 @@ def run_step(w, s, B, events=None):
         if events is not None:
             e1.record()
             events.append((e0, e1))
+
+
+def prefill_side_measurement(dev, L):
+    """Attention share of the time to first token of ONE L-token prompt (Hymeta-7B, TP=1): the
+    28 layers' prefill kernels (14 GLA chunked prefill with fused gate + norm and state write-back,
+    14 sliding-window varlen attention + paged KV write of the prompt).  Outside the timed decode
+    region; reported next to the headline value."""
+    from vllm_hymeta import _C, hip_ops
+
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1)
+    qkv = torch.randn(L, (H + 2 * HKV) * D, generator=g).to(torch.bfloat16).to(dev)
+    q = qkv[:, : H * D].view(L, H, D)
+    k = qkv[:, H * D:(H + HKV) * D].view(L, HKV, D)
+    v = qkv[:, (H + HKV) * D:].view(L, HKV, D)
+    gk = torch.randn(L, HKV, D, generator=g).to(torch.bfloat16).to(dev)
+    state = torch.zeros(1, H, D, D, dtype=torch.bfloat16, device=dev)
+    slot = torch.zeros(1, dtype=torch.int32, device=dev)
+    cu = torch.tensor([0, L], dtype=torch.int32, device=dev)
+    ctx0 = torch.zeros(1, dtype=torch.int32, device=dev)
+    g_norm = torch.ones(D, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(L, H, D, dtype=torch.bfloat16, device=dev)
+    nblk = (L + BLOCK - 1) // BLOCK
+    kv = torch.zeros(2, nblk, BLOCK, HKV, D, dtype=torch.bfloat16, device=dev)
+    slots = torch.arange(L, dtype=torch.int64, device=dev)
+
+    def gla():
+        hip_ops.gla_prefill_varlen(q, k, v, gk, state, slot, cu, L, context_lens=ctx0, out=out,
+                                   gate_mode=_C.GATE_7B, out_norm_weight=g_norm, out_norm_eps=1e-6)
+
+    def swa():
+        hip_ops.reshape_and_cache(k, v, kv[0], kv[1], slots)
+        hip_ops.meta_swa_prefill(q, cu, L, key=k, value=v, cu_seqlens_k=cu, window_left=WINDOW, out=out)
+
+    def timed(fn, iters=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    t_gla, t_swa = timed(gla), timed(swa)
+    pos = torch.arange(L, dtype=torch.float64)
+    vis = torch.minimum(pos + 1, torch.tensor(float(WINDOW + 1), dtype=torch.float64)).sum().item()
+    return {
+        "prompt_tokens": L,
+        "gla_prefill_ms_per_layer": round(t_gla, 4),
+        "swa_prefill_ms_per_layer": round(t_swa, 4),
+        "attention_ttft_ms": round(N_GLA * t_gla + N_SWA * t_swa, 3),
+        "swa_prefill_tflops": round(4.0 * D * H * vis / (t_swa * 1e-3) / 1e12, 1),
+        "prefill_tokens_per_s": round(L / ((N_GLA * t_gla + N_SWA * t_swa) * 1e-3), 1),
+    }
 
 
 def cpu_baseline(args):
@@ -254,6 +312,8 @@ def main():
             "avg_launch_ms": round(kern_ms, 5),
         },
     }
+    if world == 1 and not args.no_prefill:
+        line["prefill"] = prefill_side_measurement(dev, args.prefill_ctx)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(line), flush=True)
