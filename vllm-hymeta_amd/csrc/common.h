@@ -44,6 +44,13 @@ __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 
 __device__ __forceinline__ u32x4 ld16(const void* p) {
   return *reinterpret_cast<const u32x4*>(p);
 }
+// 16-byte load through an explicitly GLOBAL pointer.  A pointer chosen at run time between two
+// kernel-argument buffers degrades to a flat pointer; flat loads count on both the vector-memory
+// and the LDS counters, so the compiler waits for all of them at the first use and a register
+// pipeline of loads drains.
+__device__ __forceinline__ u32x4 ld16g(const void* p) {
+  return *(const __attribute__((address_space(1))) u32x4*)(p);
+}
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
 __device__ __forceinline__ float logsigmoidf(float x) {

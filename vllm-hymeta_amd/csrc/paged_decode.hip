@@ -113,15 +113,24 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
   const uint16_t* vc = reinterpret_cast<const uint16_t*>(a.value_cache) + static_cast<int64_t>(kvh) * a.cache_stride_h;
   const int32_t* bt = a.block_tables + static_cast<int64_t>(b) * a.block_table_stride;
 
-  for (int tile = geo.lo + wave; tile < geo.hi; tile += NW) {
-    const bool is_meta = tile < meta_tiles;
-    // Row pointers of the two 16-key sub-tiles (wave-uniform).
+  // K as A-operand rows (16 keys x 64 B per instruction), V as 8 key rows x 16 bytes per lane.
+  struct TileRegs {
+    u32x4 k[2][4];
+    u32x4 v[8];
+  };
+  // Loads are unconditional: a sub-tile outside the visible range (or a tile past this wave's
+  // last) reads the nearest visible sub-tile instead, and the scores / V rows are masked when the
+  // tile is consumed.  With conditional issue the compiler could not count the loads in flight
+  // and the two-tile register pipeline below would drain at every use.
+  const int sub_first = (geo.kstart / 16) * 16;
+  const int sub_last = geo.L > 0 ? ((geo.L - 1) / 16) * 16 : 0;
+  const int tile_last = geo.hi - 1;
+  auto issue = [&](int tile_raw, TileRegs& r) {
+    const int tile = min(tile_raw, tile_last);
     const uint16_t* krow[2];
     const uint16_t* vrow[2];
     int64_t row_stride;
-    int pos0 = 0;          // position of the tile's first key (real tiles)
-    bool sub_ok[2] = {true, true};
-    if (is_meta) {
+    if (tile < meta_tiles) {
       row_stride = a.meta_stride_t;
       const int64_t off = static_cast<int64_t>(tile) * kTile * a.meta_stride_t + static_cast<int64_t>(kvh) * a.meta_stride_h;
       krow[0] = reinterpret_cast<const uint16_t*>(a.meta_key) + off;
@@ -130,39 +139,34 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
       vrow[1] = vrow[0] + 16 * row_stride;
     } else {
       row_stride = a.cache_stride_pos;
-      pos0 = (geo.t0 + tile - meta_tiles) * kTile;
+      const int pos0 = (geo.t0 + tile - meta_tiles) * kTile;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int p = pos0 + 16 * s;
-        sub_ok[s] = p < geo.L && p + 15 >= geo.kstart;  // any visible key in the sub-tile
-        int64_t off = 0;
-        if (sub_ok[s]) {
-          const int blk = bt[p / a.block_size];
-          off = static_cast<int64_t>(blk) * a.cache_stride_block + static_cast<int64_t>(p % a.block_size) * a.cache_stride_pos;
-        }
+        const int p = max(min(pos0 + 16 * s, sub_last), sub_first);
+        const int blk = bt[p / a.block_size];
+        const int64_t off = static_cast<int64_t>(blk) * a.cache_stride_block + static_cast<int64_t>(p % a.block_size) * a.cache_stride_pos;
         krow[s] = kc + off;
         vrow[s] = vc + off;
       }
     }
-    const bool full = is_meta || (pos0 >= geo.kstart && pos0 + kTile <= geo.L);
-
-    // ---- loads: K as A-operand rows, V as 8 key rows x 16 bytes per lane ----
-    u32x4 kraw[2][4];
-    u32x4 vraw[8];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const uint16_t* kp = krow[s] + static_cast<int64_t>(n) * row_stride + 8 * c;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        kraw[s][ks] = sub_ok[s] ? ld16(kp + 32 * ks) : u32x4{0u, 0u, 0u, 0u};
-      }
+      for (int ks = 0; ks < 4; ++ks) r.k[s][ks] = ld16g(kp + 32 * ks);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int s = j >> 2;
-      const uint16_t* vp = vrow[s] + static_cast<int64_t>(4 * c + (j & 3)) * row_stride + 8 * n;
-      vraw[j] = sub_ok[s] ? ld16(vp) : u32x4{0u, 0u, 0u, 0u};
+      const uint16_t* vp = vrow[j >> 2] + static_cast<int64_t>(4 * c + (j & 3)) * row_stride + 8 * n;
+      r.v[j] = ld16g(vp);
     }
+  };
+
+  auto consume = [&](int tile, TileRegs& r) {
+    if (tile >= geo.hi) return;   // wave-uniform; the registers hold a redundant copy of the last tile
+    const bool is_meta = tile < meta_tiles;
+    const int pos0 = is_meta ? 0 : (geo.t0 + tile - meta_tiles) * kTile;
+    const bool full = is_meta || (pos0 >= geo.kstart && pos0 + kTile <= geo.L);
 
     // ---- S^T = K Q^T : st[s][r] = score(key 16s + 4c + r, head n) ----
     f32x4 st[2];
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
     for (int s = 0; s < 2; ++s) {
       st[s] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) st[s] = mfma16(as_frag(kraw[s][ks]), qf[ks], st[s]);
+      for (int ks = 0; ks < 4; ++ks) st[s] = mfma16(as_frag(r.k[s][ks]), qf[ks], st[s]);
     }
 
     float sc[8];
@@ -182,9 +186,9 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
         const int p = pos0 + 16 * (j >> 2) + 4 * c + (j & 3);
         const bool ok = p >= geo.kstart && p < geo.L;
         sc[j] = ok ? sc[j] : -INFINITY;
-        // Rows outside the sequence may hold anything (NaN included): a zero
+        // Rows outside the visible range may hold anything (NaN included): a zero
         // probability does not neutralise them inside the MFMA, so clear them.
-        if (!ok) vraw[j] = u32x4{0u, 0u, 0u, 0u};
+        if (!ok) r.v[j] = u32x4{0u, 0u, 0u, 0u};
       }
     }
 
@@ -210,10 +214,10 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
     if (!__all(alpha == 1.f)) {
       // o[t][r] belongs to head 4c + r; its factor lives on the lanes with n == 4c + r.
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ar = __shfl(alpha, 4 * c + r);
+      for (int rr = 0; rr < 4; ++rr) {
+        const float ar = __shfl(alpha, 4 * c + rr);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) o[t][r] *= ar;
+        for (int t = 0; t < 8; ++t) o[t][rr] *= ar;
       }
     }
 
@@ -228,11 +232,25 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
       u32x4 vt;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        const uint32_t x = vraw[2 * w][t >> 1];
-        const uint32_t y = vraw[2 * w + 1][t >> 1];
+        const uint32_t x = r.v[2 * w][t >> 1];
+        const uint32_t y = r.v[2 * w + 1][t >> 1];
         vt[w] = (t & 1) ? __builtin_amdgcn_perm(y, x, 0x07060302u) : __builtin_amdgcn_perm(y, x, 0x05040100u);
       }
       o[t] = mfma16(pf, as_frag(vt), o[t]);
+    }
+  };
+
+  // Two register sets: the next tile of this wave is in flight while the current one is consumed.
+  if (geo.lo + wave < geo.hi) {
+    TileRegs ra, rb;
+    issue(geo.lo + wave, ra);
+    for (int tile = geo.lo + wave; tile < geo.hi; tile += 2 * NW) {
+      issue(tile + NW, rb);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(tile, ra);
+      issue(tile + 2 * NW, ra);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(tile + NW, rb);
     }
   }
 
