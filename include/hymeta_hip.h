@@ -234,6 +234,13 @@ int hymeta_reshape_and_cache(const hymeta_reshape_and_cache_args* args, hymeta_s
  * the size needed for (batch, num_heads, head_dim, num_splits).
  * num_splits <= 0 lets the library choose from batch, num_kv_heads and
  * max_seqlen_k; pass the same value to the size query.
+ *
+ * Fused KV write (decode-only steps): with new_key != NULL the call also does
+ * the work of the hymeta_reshape_and_cache that would precede it
+ * (meta_attention.py:790-799): row b of new_key / new_value is stored at cache
+ * slot slot_mapping[b] (negative: skipped), which must be the slot of position
+ * cache_seqlens[b] - 1, before sequence b is attended.  One launch instead of
+ * two per layer and step.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_paged_decode_args {
   const void* q;            /* bf16 [batch, num_heads, head_dim] */
@@ -262,6 +269,11 @@ typedef struct hymeta_paged_decode_args {
   int64_t block_table_stride;
   int64_t meta_stride_t, meta_stride_h;
   float scale;              /* <= 0 selects head_dim^-0.5 */
+  const void* new_key;      /* bf16 [batch, num_kv_heads, head_dim] or NULL */
+  const void* new_value;
+  const int64_t* slot_mapping;   /* [batch], required with new_key */
+  int64_t new_key_stride_b, new_key_stride_h;
+  int64_t new_value_stride_b, new_value_stride_h;
 } hymeta_paged_decode_args;
 
 size_t hymeta_meta_swa_paged_decode_workspace_bytes(int32_t batch, int32_t num_heads,

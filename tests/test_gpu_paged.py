@@ -157,3 +157,41 @@ def test_paged_decode_workspace_error():
     assert lib.hymeta_meta_swa_paged_decode_workspace_bytes(4, 28, 128, 3) == 4 * 28 * 3 * 130 * 4
     a = _C.PagedDecodeArgs()
     assert lib.hymeta_meta_swa_paged_decode(C.byref(a), None) == -1  # null pointers
+
+
+@pytest.mark.parametrize("M,window_left,splits", [(0, 100, 1), (32, 63, 3), (0, -1, 0)])
+def test_paged_decode_fused_kv_write_equals_write_then_decode(M, window_left, splits):
+    """The decode call that also stores the decoded token's K/V row: same cache bytes and same
+    output bits as hymeta_reshape_and_cache followed by the plain decode (skipped slot included)."""
+    from vllm_hymeta import hip_ops
+
+    H, Hkv, bs = 8, 2, 16
+    seq_lens = [1, 16, 17, 130, 257, 64]
+    kc, vc, bt = _paged_problem(21, seq_lens, Hkv, bs)
+    g_ = gen(22)
+    B = len(seq_lens)
+    q = randn_bf16(g_, B, H, D)
+    qkv = randn_bf16(g_, B, 2 * Hkv * D)                 # new K/V as views of one fused buffer
+    nk, nv = qkv[:, : Hkv * D].view(B, Hkv, D), qkv[:, Hkv * D:].view(B, Hkv, D)
+    k2 = randn_bf16(g_, M, Hkv, D) if M else None
+    v2 = randn_bf16(g_, M, Hkv, D) if M else None
+    slots = torch.tensor([bt[i, (L - 1) // bs].item() * bs + (L - 1) % bs for i, L in enumerate(seq_lens)],
+                         dtype=torch.int64)
+    slots[3] = -1                                        # padded entry: nothing written
+    lens = torch.tensor(seq_lens, dtype=torch.int32).cuda()
+    dev = lambda t: None if t is None else t.cuda()
+
+    k_a, v_a = kc.cuda(), vc.cuda()
+    hip_ops.reshape_and_cache(nk.cuda(), nv.cuda(), k_a, v_a, slots.cuda())
+    out_a = hip_ops.meta_swa_paged_decode(q.cuda(), k_a, v_a, lens, bt.cuda(), meta_key=dev(k2), meta_value=dev(v2),
+                                          window_left=window_left, num_splits=splits)
+    k_b, v_b = kc.cuda(), vc.cuda()
+    qkv_d = qkv.cuda()
+    out_b = hip_ops.meta_swa_paged_decode(q.cuda(), k_b, v_b, lens, bt.cuda(), meta_key=dev(k2), meta_value=dev(v2),
+                                          window_left=window_left, num_splits=splits,
+                                          new_key=qkv_d[:, : Hkv * D].view(B, Hkv, D),
+                                          new_value=qkv_d[:, Hkv * D:].view(B, Hkv, D), slot_mapping=slots.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(k_a.cpu().view(torch.int16), k_b.cpu().view(torch.int16))
+    assert torch.equal(v_a.cpu().view(torch.int16), v_b.cpu().view(torch.int16))
+    assert torch.equal(out_a.cpu().view(torch.int16), out_b.cpu().view(torch.int16))

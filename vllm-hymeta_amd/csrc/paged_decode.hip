@@ -19,6 +19,7 @@
 // alternate 32-key tiles and merge their online-softmax states through LDS.
 // With more than one split the un-normalised partial results go to a
 // workspace and a second kernel merges them.
+#include <cstdint>
 #include <cstdlib>
 
 #include "common.h"
@@ -113,6 +114,24 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
   const uint16_t* vc = reinterpret_cast<const uint16_t*>(a.value_cache) + static_cast<int64_t>(kvh) * a.cache_stride_h;
   const int32_t* bt = a.block_tables + static_cast<int64_t>(b) * a.block_table_stride;
 
+  // Fused KV write: the workgroup that owns the sequence's last tile (the only reader of the
+  // new row; the host uses this form only when one workgroup covers all q-heads of the kv-head)
+  // stores the decoded token's K/V row and, instead of waiting for that store to become visible,
+  // patches the row into the last tile's registers from the source tensors.
+  // The row loads are unconditional (a workgroup without a row to patch re-reads its q) and the
+  // store is issued after the tile loop: conditional memory operations ahead of the loop would
+  // keep the compiler from counting the loads in flight inside it.
+  const bool owner = a.new_key != nullptr && geo.hi == geo.ntiles && geo.hi > geo.lo;
+  const int64_t new_slot = owner ? a.slot_mapping[b] : -1;
+  const bool patch = new_slot >= 0;
+  const uint16_t* qrow = reinterpret_cast<const uint16_t*>(a.q) + b * a.q_stride_b + static_cast<int64_t>(head0) * a.q_stride_h;
+  const uint16_t* nk = patch ? reinterpret_cast<const uint16_t*>(a.new_key) + b * a.new_key_stride_b + static_cast<int64_t>(kvh) * a.new_key_stride_h : qrow;
+  const uint16_t* nv = patch ? reinterpret_cast<const uint16_t*>(a.new_value) + b * a.new_value_stride_b + static_cast<int64_t>(kvh) * a.new_value_stride_h : qrow;
+  u32x4 nkf[4], nvf;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) nkf[ks] = ld16g(nk + 32 * ks + 8 * c);
+  nvf = ld16g(nv + 8 * n);
+
   // K as A-operand rows (16 keys x 64 B per instruction), V as 8 key rows x 16 bytes per lane.
   struct TileRegs {
     u32x4 k[2][4];
@@ -167,6 +186,17 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
     const bool is_meta = tile < meta_tiles;
     const int pos0 = is_meta ? 0 : (geo.t0 + tile - meta_tiles) * kTile;
     const bool full = is_meta || (pos0 >= geo.kstart && pos0 + kTile <= geo.L);
+    if (patch && tile == geo.ntiles - 1) {   // wave-uniform: the tile that holds position L - 1
+      const int rn = geo.L - 1 - pos0;       // row of the new token inside the tile
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bool mine = rn == 16 * s + n;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) r.k[s][ks] = mine ? nkf[ks] : r.k[s][ks];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[j] = (rn == 16 * (j >> 2) + 4 * c + (j & 3)) ? nvf : r.v[j];
+    }
 
     // ---- S^T = K Q^T : st[s][r] = score(key 16s + 4c + r, head n) ----
     f32x4 st[2];
@@ -252,6 +282,14 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
       __builtin_amdgcn_sched_barrier(0);
       consume(tile + NW, rb);
     }
+  }
+
+  if (patch && tid < 32) {   // the new row into the cache (nothing in this launch reads it back)
+    const int chunk = tid & 15;
+    const bool is_v = tid >= 16;
+    uint16_t* dst = const_cast<uint16_t*>(is_v ? vc : kc) + (new_slot / a.block_size) * a.cache_stride_block +
+                    (new_slot % a.block_size) * a.cache_stride_pos;
+    st16(dst + 8 * chunk, ld16g((is_v ? nv : nk) + 8 * chunk));
   }
 
   // ---- merge the four waves ----
@@ -395,6 +433,28 @@ extern "C" int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args
   const int head_groups = (group + kMaxGroup - 1) / kMaxGroup;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a.new_key != nullptr) {
+    if (!a.new_value || !a.slot_mapping) return HYMETA_ERR_INVALID_ARG;
+    if ((a.new_key_stride_b | a.new_key_stride_h | a.new_value_stride_b | a.new_value_stride_h) % 8 != 0 ||
+        (reinterpret_cast<uintptr_t>(a.new_key) | reinterpret_cast<uintptr_t>(a.new_value)) % 16 != 0)
+      return HYMETA_ERR_UNSUPPORTED;
+    if (head_groups > 1) {
+      // several workgroups read the new row: write it with the stand-alone kernel first
+      hymeta_reshape_and_cache_args w = {};
+      w.key = a.new_key; w.value = a.new_value;
+      w.key_cache = const_cast<void*>(a.key_cache); w.value_cache = const_cast<void*>(a.value_cache);
+      w.slot_mapping = a.slot_mapping;
+      w.num_tokens = a.batch; w.num_kv_heads = a.num_kv_heads; w.head_dim = a.head_dim; w.block_size = a.block_size;
+      w.elem_bytes = 2;
+      w.num_blocks = INT64_MAX / (a.cache_stride_block > 0 ? a.cache_stride_block : 1) / 4;   // bound unknown here: the caller vouches for its slots
+      w.key_stride_t = a.new_key_stride_b; w.key_stride_h = a.new_key_stride_h;
+      w.value_stride_t = a.new_value_stride_b; w.value_stride_h = a.new_value_stride_h;
+      w.cache_stride_block = a.cache_stride_block; w.cache_stride_pos = a.cache_stride_pos; w.cache_stride_h = a.cache_stride_h;
+      const int rc = hymeta_reshape_and_cache(&w, stream);
+      if (rc != HYMETA_OK) return rc;
+      a.new_key = nullptr;
+    }
+  }
   dim3 grid(static_cast<unsigned>(a.batch) * a.num_kv_heads * head_groups, static_cast<unsigned>(splits));
   const char* nw_env = getenv("HYMETA_PAGED_NW");
   const int nw = nw_env ? atoi(nw_env) : 4;

@@ -91,6 +91,9 @@ class PagedDecodeArgs(C.Structure):
         ("block_table_stride", _i64),
         ("meta_stride_t", _i64), ("meta_stride_h", _i64),
         ("scale", _f32),
+        ("new_key", _ptr), ("new_value", _ptr), ("slot_mapping", _ptr),
+        ("new_key_stride_b", _i64), ("new_key_stride_h", _i64),
+        ("new_value_stride_b", _i64), ("new_value_stride_h", _i64),
     ]
 
 

@@ -425,7 +425,12 @@ class MetaAttentionImpl(AttentionImpl):
             assert ks == 1.0 and vs == 1.0, "key/value scales other than 1.0 need an fp8 cache (unsupported)"
 
         have_cache = kv_cache.numel() > 0
-        if have_cache and key is not None and value is not None:
+        # decode-only step with one token per sequence: the KV write rides inside the decode launch
+        fuse_write = (have_cache and key is not None and value is not None
+                      and attn_metadata.num_prefill_tokens == 0 and attn_metadata.num_decode_tokens > 0
+                      and not (attn_metadata.max_decode_query_len or 0) > 1
+                      and attn_metadata.slot_mapping.numel() == attn_metadata.num_decode_tokens)
+        if have_cache and key is not None and value is not None and not fuse_write:
             hip_ops.reshape_and_cache(key, value, kv_cache[0], kv_cache[1], attn_metadata.slot_mapping.flatten())
 
         num_prefill_tokens = attn_metadata.num_prefill_tokens
@@ -476,5 +481,7 @@ class MetaAttentionImpl(AttentionImpl):
                     decode_query, kv_cache[0], kv_cache[1], decode_meta.seq_lens_tensor,
                     decode_meta.block_tables, meta_key=key2, meta_value=value2, window_left=window[0],
                     scale=self.scale, max_seqlen_k=decode_meta.max_decode_seq_len or 0,
-                    out=output[num_meta_prefill_tokens:])
+                    out=output[num_meta_prefill_tokens:],
+                    new_key=key if fuse_write else None, new_value=value if fuse_write else None,
+                    slot_mapping=attn_metadata.slot_mapping.flatten() if fuse_write else None)
         return output

@@ -275,10 +275,16 @@ def meta_swa_paged_decode(
     num_splits: int = 0,
     out: Optional[torch.Tensor] = None,
     workspace: Optional[torch.Tensor] = None,
+    new_key: Optional[torch.Tensor] = None,
+    new_value: Optional[torch.Tensor] = None,
+    slot_mapping: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """q [B,H,D]; caches [nblk,bs,Hkv,D]; cache_seqlens int32 [B]; block_tables int32 [B,maxblk];
-    meta_key/meta_value [M,Hkv,D] or None.  Returns out [B,H,D] bf16."""
-    _dev(q, key_cache, value_cache, cache_seqlens, block_tables, meta_key, meta_value, out, workspace)
+    meta_key/meta_value [M,Hkv,D] or None.  Returns out [B,H,D] bf16.
+    With ``new_key`` / ``new_value`` [B,Hkv,D] and ``slot_mapping`` int64 [B] the call first writes the
+    decoded tokens' K/V rows into the cache (the fused form of ``reshape_and_cache`` + decode)."""
+    _dev(q, key_cache, value_cache, cache_seqlens, block_tables, meta_key, meta_value, out, workspace,
+         new_key, new_value, slot_mapping)
     B, H, D = q.shape
     nblk, bs, Hkv, Dc = key_cache.shape
     _require(q.dtype == torch.bfloat16 and key_cache.dtype == torch.bfloat16
@@ -323,6 +329,18 @@ def meta_swa_paged_decode(
     a.window_left, a.max_seqlen_k, a.num_splits = int(window_left), int(max_seqlen_k), int(num_splits)
     a.q_stride_b, a.q_stride_h = q.stride(0), q.stride(1)
     a.out_stride_b, a.out_stride_h = out.stride(0), out.stride(1)
+    if new_key is not None:
+        _require(new_value is not None and slot_mapping is not None, "new_key needs new_value and slot_mapping")
+        _require(new_key.shape == (B, Hkv, D) and new_value.shape == (B, Hkv, D)
+                 and new_key.dtype == torch.bfloat16 and new_value.dtype == torch.bfloat16,
+                 "new_key / new_value must be bf16 [B, Hkv, D]")
+        _require(slot_mapping.dtype == torch.int64 and slot_mapping.is_contiguous() and slot_mapping.numel() == B,
+                 "slot_mapping must be contiguous int64 [B]")
+        _inner_contig(new_key, "new_key")
+        _inner_contig(new_value, "new_value")
+        a.new_key, a.new_value, a.slot_mapping = _p(new_key), _p(new_value), _p(slot_mapping)
+        a.new_key_stride_b, a.new_key_stride_h = new_key.stride(0), new_key.stride(1)
+        a.new_value_stride_b, a.new_value_stride_h = new_value.stride(0), new_value.stride(1)
     a.cache_stride_block, a.cache_stride_pos, a.cache_stride_h = (
         key_cache.stride(0), key_cache.stride(1), key_cache.stride(2))
     a.block_table_stride = block_tables.stride(0)
