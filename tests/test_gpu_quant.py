@@ -26,6 +26,12 @@ def _gptq_problem(seed, K, N, bits, group, scales_dtype):
     (8, 64, 40, 768, 64, torch.float16, 2),
     (4, 128, 100, 512, 128, torch.float16, 1),   # several 64-row passes
     (4, 32, 5, 256, 64, torch.float16, 0),
+    # wider outputs, odd group counts per K slice, ragged rows, two row blocks
+    (4, 128, 64, 1024, 512, torch.float16, 0),
+    (4, 128, 33, 640, 256, torch.bfloat16, 3),   # odd group count per slice, ragged rows
+    (4, 64, 17, 512, 256, torch.float16, 2),
+    (8, 64, 50, 512, 512, torch.float16, 1),
+    (4, 32, 100, 256, 256, torch.float16, 4),    # two row blocks
 ])
 def test_gptq_gemm(bits, group, M, K, N, scales_dtype, split_k):
     from oracle.quant import gptq_gemm_ref
