@@ -35,7 +35,7 @@ struct StateIO<uint16_t> {  // bf16 state: 8 elements = one 16-byte access
 };
 
 template <int NSPLIT, bool STATE_F32>
-__global__ __launch_bounds__(256) void gla_decode_kernel(hymeta_gla_decode_args a, GateParams gp) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void gla_decode_kernel(hymeta_gla_decode_args a, GateParams gp) {
   constexpr int D = kHeadDim;
   constexpr int COLS = D / NSPLIT;      // state columns this workgroup owns
   constexpr int CG = COLS / 8;          // 8-column groups per row
@@ -95,16 +95,17 @@ __global__ __launch_bounds__(256) void gla_decode_kernel(hymeta_gla_decode_args 
   for (int c = 0; c < 8; ++c) acc[c] = 0.f;
 
   if constexpr (!STATE_F32) {
-    // Rows go through in batches of at most 4 passes: 16 VGPRs of loads in flight per lane keep
-    // the kernel at <= 64 VGPRs, so 8 workgroups fit on a CU and 2048 (sequence, head) units
-    // are resident at once.
-    constexpr int PB = NPASS < 4 ? NPASS : 4;
+    // Rows go through in batches of 2 passes with the next batch's loads issued as soon as a
+    // register is consumed; the batch loop is kept rolled so that the kernel stays within 72
+    // VGPRs: 7 workgroups per CU, i.e. the 1792 (sequence, head) units of a 64-sequence 7B step
+    // are resident in ONE round instead of 1.75.
+    constexpr int PB = NPASS < 2 ? NPASS : 2;
     uint16_t* sp = reinterpret_cast<uint16_t*>(a.state) + sbase + col0;
     u32x4 raw[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) raw[i] = ld16(sp + (r0 + RPP * i) * D);
     __syncthreads();
-#pragma unroll
+#pragma unroll 1
     for (int hb = 0; hb < NPASS; hb += PB) {
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(256) void gla_decode_kernel(hymeta_gla_decode_args 
         const float kr = s_k[row], dr = s_dec[row], qr = s_q[row];
         float s[8];
         StateIO<uint16_t>::unpack(raw[i], s);
-        if (hb + PB < NPASS) raw[i] = ld16(sp + (row + RPP * PB) * D);  // next batch, same register
+        // next batch, same register (the last batch re-reads its own rows: unconditional issue)
+        raw[i] = ld16(sp + min(row + RPP * PB, r0 + RPP * (NPASS - 1)) * D);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const float kv = bf16_round(kr * vf[c]);  // outer product is formed in bf16
