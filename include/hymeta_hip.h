@@ -491,6 +491,80 @@ size_t hymeta_w8a8_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 
 int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Sparse mixture-of-experts block (70B, 16 experts, top-1, shared expert on the
+ * side): replaces HymetaMoE.forward -> vLLM FusedMoE(renormalize=False,
+ * reduce_results=True) (vllm_hymeta/models/modeling_hymeta.py:273-364) and the
+ * shared-expert sum of HybridBlock.forward (:1044-1068).  Eager oracle:
+ * hf_model/moe.py:34-101 (which renormalises the top-k weights: `renormalize`).
+ * The expert arithmetic lives in vLLM 0.10.0 (third-party): parity unpinned.
+ *
+ * Call order per layer (all stream-ordered, no host read of the expert counts):
+ *   hymeta_moe_route     logits [T, E] -> topk_ids / topk_weights [T, k], the (token, choice)
+ *                        pairs counting-sorted by expert: expert_offsets [E + 1], sorted_pair
+ *                        [T k] (pair index per sorted slot), pair_pos [T k] (slot of a pair, -1
+ *                        when its expert is outside [local_expert_begin, local_expert_end):
+ *                        expert parallelism)
+ *   hymeta_moe_gemm      h13[slot] = x[sorted_pair[slot] / k] W13[e]^T      (a_rows = sorted_pair)
+ *   hymeta_silu_and_mul  h[slot] = silu(h13[slot, :I]) * h13[slot, I:]      (also SiluAndMul of the dense MLP, :263-270)
+ *   hymeta_moe_gemm      y[slot] = bf16(w[pair] * (h[slot] W2[e]^T))        (row_scale = topk_weights)
+ *   hymeta_moe_combine   out[t] = sum_k y[pair_pos[t, k]] (+ shared[t])
+ * followed, under tensor / expert parallelism, by the caller's all-reduce.
+ * Weight stacks are K-contiguous: W13 [E, 2 I, H], W2 [E, H, I] (vLLM's w13 / w2).
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_moe_route_args {
+  const void* router_logits;   /* logits_dtype [num_tokens, num_experts] */
+  int32_t* topk_ids;           /* out [num_tokens, top_k] */
+  float* topk_weights;         /* out [num_tokens, top_k] */
+  int32_t* counts;             /* scratch [num_experts] */
+  int32_t* cursors;            /* scratch [num_experts] */
+  int32_t* expert_offsets;     /* out [num_experts + 1] */
+  int32_t* sorted_pair;        /* out [num_tokens * top_k] */
+  int32_t* pair_pos;           /* out [num_tokens * top_k] */
+  int32_t num_tokens;
+  int32_t num_experts;         /* <= 64 */
+  int32_t top_k;               /* 1 or 2 */
+  int32_t renormalize;         /* 0: softmax probabilities as they are (the vLLM path) */
+  int32_t logits_dtype;        /* HYMETA_BF16 or HYMETA_F32 */
+  int32_t local_expert_begin, local_expert_end;
+  int64_t logits_stride_t;
+} hymeta_moe_route_args;
+
+int hymeta_moe_route(const hymeta_moe_route_args* args, hymeta_stream_t stream);
+
+typedef struct hymeta_moe_gemm_args {
+  const void* x;               /* bf16 rows of K */
+  const void* weights;         /* bf16 [experts, N, K] */
+  void* out;                   /* bf16 [slots, N] */
+  const int32_t* expert_offsets;   /* [experts + 1], device */
+  const int32_t* a_rows;       /* source row of slot s = a_rows[s] / a_rows_div, or NULL: s */
+  const int32_t* scale_rows;   /* index into row_scale per slot, or NULL: s */
+  const float* row_scale;      /* or NULL */
+  int32_t a_rows_div;
+  int32_t max_rows;            /* upper bound on the slots in use (num_tokens * top_k) */
+  int32_t K, N;
+  int32_t local_expert_begin, local_expert_end;
+  int64_t x_stride_m, out_stride_m, w_stride_e;
+} hymeta_moe_gemm_args;
+
+int hymeta_moe_gemm(const hymeta_moe_gemm_args* args, hymeta_stream_t stream);
+
+/* num_rows_dev: optional device count of the rows in use (e.g. expert_offsets + E); NULL: num_rows. */
+int hymeta_silu_and_mul(const void* in, void* out, const int32_t* num_rows_dev, int32_t num_rows,
+                        int32_t inter, int64_t in_stride, int64_t out_stride, hymeta_stream_t stream);
+
+typedef struct hymeta_moe_combine_args {
+  const void* y;               /* bf16 [slots, hidden] */
+  const void* shared;          /* bf16 [num_tokens, hidden] or NULL */
+  void* out;                   /* bf16 [num_tokens, hidden] */
+  const int32_t* pair_pos;     /* [num_tokens * top_k] */
+  const float* topk_weights;   /* unused (kept for callers that weight at combine time) */
+  int32_t num_tokens, hidden, top_k;
+  int64_t y_stride_m, shared_stride_m, out_stride_m;
+} hymeta_moe_combine_args;
+
+int hymeta_moe_combine(const hymeta_moe_combine_args* args, hymeta_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,111 @@
+"""Sparse MoE block (routing, counting sort, grouped expert GEMMs, activation, combine) and the
+dense MLP vs the CPU restatement."""
+import pytest
+import torch
+
+from _util import assert_bf16_close, gen, randn_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(seed, T, H, inter, E):
+    g_ = gen(seed)
+    x = randn_bf16(g_, T, H)
+    gate_w = randn_bf16(g_, E, H, scale=H ** -0.5)
+    w13 = randn_bf16(g_, E, 2 * inter, H, scale=H ** -0.5)
+    w2 = randn_bf16(g_, E, H, inter, scale=inter ** -0.5)
+    logits = (x.float() @ gate_w.float().t()).to(torch.bfloat16)
+    return x, gate_w, w13, w2, logits
+
+
+def test_silu_and_mul_bit_exact():
+    from oracle.moe import silu_and_mul_ref
+    from vllm_hymeta import hip_ops
+
+    x = randn_bf16(gen(0), 37, 2 * 320, scale=3.0)
+    out = hip_ops.silu_and_mul(x.cuda())
+    torch.cuda.synchronize()
+    ref = silu_and_mul_ref(x)
+    # exp / reciprocal differ from torch's by at most an fp32 ulp: at most one bf16 ulp, rarely
+    diff = (out.cpu().view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 0.01
+
+
+@pytest.mark.parametrize("T,E,top_k,renorm,with_shared", [
+    (1, 16, 1, False, False),       # single decode token
+    (64, 16, 1, False, True),       # decode batch, the 70B routing (top-1, softmax weight), shared expert
+    (300, 16, 1, False, True),      # prefill chunk: 64-row tiles, ragged expert sizes
+    (50, 8, 2, True, False),        # the eager module's top-2 with renormalised weights
+    (40, 4, 2, False, True),
+])
+def test_moe_forward(T, E, top_k, renorm, with_shared):
+    from oracle.moe import moe_ref
+    from vllm_hymeta import hip_ops
+
+    H, inter = 256, 192
+    x, gate_w, w13, w2, logits = _problem(1, T, H, inter, E)   # bf16 logits: ties between experts do occur
+    shared = randn_bf16(gen(2), T, H) if with_shared else None
+    ref = moe_ref(x, logits, w13, w2, top_k, renorm, shared)
+    out = hip_ops.moe_forward(x.cuda(), logits.cuda(), w13.cuda(), w2.cuda(), top_k=top_k, renormalize=renorm,
+                              shared=None if shared is None else shared.cuda())
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), ref, f"moe T={T} E={E} k={top_k}", rel=8e-3)
+
+
+def test_moe_expert_parallel_shares_sum_to_the_whole():
+    """Two expert-parallel ranks (emulated in one process): each computes only its experts' pairs;
+    the sum of the two outputs (the layer's all-reduce) equals the single-rank result, and each
+    share equals the oracle's share."""
+    from oracle.moe import moe_ref
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta.models.moe import expert_range
+
+    T, H, inter, E = 90, 256, 128, 16
+    x, gate_w, w13, w2, logits = _problem(3, T, H, inter, E)
+    full = hip_ops.moe_forward(x.cuda(), logits.cuda(), w13.cuda(), w2.cuda())
+    parts = []
+    for r in range(2):
+        lo_hi = expert_range(E, 2, r)
+        part = hip_ops.moe_forward(x.cuda(), logits.cuda(), w13.cuda(), w2.cuda(), local_experts=lo_hi)
+        torch.cuda.synchronize()
+        assert_bf16_close(part.cpu(), moe_ref(x, logits, w13, w2, local_experts=lo_hi), f"EP share {r}", rel=8e-3)
+        parts.append(part.float())
+    # top-1: every token belongs to exactly one rank, so the sum is bit-identical to the whole
+    assert torch.equal((parts[0] + parts[1]).to(torch.bfloat16), full)
+    with pytest.raises(ValueError):
+        expert_range(16, 3, 0)
+
+
+def test_hymeta_moe_module_and_dense_mlp():
+    from oracle.moe import mlp_ref, moe_ref
+    from vllm_hymeta.linear import HymetaLinear
+    from vllm_hymeta.models.moe import HymetaMLP, HymetaMoE
+
+    T, H, inter, E = 33, 256, 192, 16
+    x, gate_w, w13, w2, logits = _problem(4, T, H, inter, E)
+    g_ = gen(5)
+    s13 = randn_bf16(g_, 2 * inter, H, scale=H ** -0.5)
+    s2 = randn_bf16(g_, H, inter, scale=inter ** -0.5)
+    mlp = HymetaMLP(HymetaLinear.from_weight(s13.cuda()), HymetaLinear.from_weight(s2.cuda()))
+    y = mlp(x.cuda())
+    torch.cuda.synchronize()
+    shared_ref = mlp_ref(x, s13, s2)
+    assert_bf16_close(y.cpu(), shared_ref, "dense MLP", rel=8e-3)
+    moe = HymetaMoE(gate_w.cuda(), w13.cuda(), w2.cuda(), shared_mlp=mlp)
+    out = moe(x.cuda().view(3, 11, H))
+    torch.cuda.synchronize()
+    # route the oracle with the router output of the device's own bf16 linear (a library GEMM whose
+    # rounding may differ from the host's in the last bit, which can flip a near-tie)
+    logits = torch.nn.functional.linear(x.cuda(), gate_w.cuda()).cpu()
+    ref = moe_ref(x, logits, w13, w2, 1, False, shared_ref)
+    assert out.shape == (3, 11, H)
+    assert_bf16_close(out.cpu().view(T, H), ref, "HymetaMoE + shared expert", rel=8e-3)
+
+
+def test_moe_rejects_unsupported():
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta._C import HymetaError
+
+    x, gate_w, w13, w2, logits = _problem(6, 4, 256, 128, 16)
+    with pytest.raises(HymetaError):
+        hip_ops.moe_forward(x.cuda(), logits.cuda(), w13.cuda(), w2.cuda(), top_k=3)

@@ -1,0 +1,332 @@
+// Sparse mixture-of-experts block of the 70B model: top-k routing (softmax probability as the
+// weight, optionally renormalised), counting sort of the (token, choice) pairs by expert, grouped
+// expert GEMMs straight from the per-expert weight stacks, SiLU-and-multiply, and the combine
+// with the shared expert.  Everything stays on the device: no host read of the expert counts.
+//
+//   route    one lane-group per token: softmax over E <= 64 logits, k <= 2 picks, histogram
+//   offsets  exclusive prefix over the experts (one workgroup)
+//   scatter  pair -> slot offsets[e] + ticket; the order inside an expert is arbitrary, which
+//            cannot change a result: rows of a GEMM are independent
+//   gemm     out[row] = x[a_rows[row]] W[e]^T for the rows of expert e; 64 columns per workgroup,
+//            the 4 waves take alternate 32-deep k-steps (bf16 MFMA 16x16x32, operands straight
+//            from global memory: both x rows and W rows are K-contiguous), LDS reduce
+//   combine  out[t] = sum_k y[pos[t,k]] (+ shared[t]), y weighted in the down GEMM; pairs of non-local experts
+//            (expert parallelism) carry pos = -1 and add nothing
+#include "common.h"
+
+namespace hymeta {
+namespace {
+
+constexpr int kMaxExperts = 64;
+constexpr int kCols = 64;
+
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 as_frag(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+}  // namespace
+
+// One thread per token (E is small).  counts[e] += 1 per pair.
+__global__ __launch_bounds__(256) void moe_route_kernel(hymeta_moe_route_args a) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.num_tokens) return;
+  float logit[kMaxExperts];
+  float mx = -INFINITY;
+  for (int e = 0; e < a.num_experts; ++e) {
+    const int64_t i = static_cast<int64_t>(t) * a.logits_stride_t + e;
+    logit[e] = a.logits_dtype == HYMETA_F32 ? reinterpret_cast<const float*>(a.router_logits)[i]
+                                            : bf2f(reinterpret_cast<const uint16_t*>(a.router_logits)[i]);
+    mx = fmaxf(mx, logit[e]);
+  }
+  float denom = 0.f;
+  for (int e = 0; e < a.num_experts; ++e) {
+    logit[e] = expf(logit[e] - mx);
+    denom += logit[e];
+  }
+  int pick[2] = {0, 0};
+  float pw[2] = {0.f, 0.f};
+  for (int j = 0; j < a.top_k; ++j) {
+    int best = -1;
+    float bv = -1.f;
+    for (int e = 0; e < a.num_experts; ++e) {
+      const bool taken = j == 1 && e == pick[0];
+      if (!taken && logit[e] > bv) {   // first maximum wins, as torch.topk on ties of distinct indices
+        bv = logit[e];
+        best = e;
+      }
+    }
+    pick[j] = best;
+    pw[j] = bv / denom;
+  }
+  if (a.renormalize) {
+    float s = 0.f;
+    for (int j = 0; j < a.top_k; ++j) s += pw[j];
+    for (int j = 0; j < a.top_k; ++j) pw[j] /= s;
+  }
+  for (int j = 0; j < a.top_k; ++j) {
+    a.topk_ids[t * a.top_k + j] = pick[j];
+    a.topk_weights[t * a.top_k + j] = pw[j];
+    atomicAdd(a.counts + pick[j], 1);
+  }
+}
+
+// offsets[0..E] = exclusive prefix of counts; cursors zeroed.
+__global__ __launch_bounds__(64) void moe_offsets_kernel(hymeta_moe_route_args a) {
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int e = 0; e < a.num_experts; ++e) {
+      a.expert_offsets[e] = run;
+      run += a.counts[e];
+      a.cursors[e] = 0;
+    }
+    a.expert_offsets[a.num_experts] = run;
+  }
+}
+
+__global__ __launch_bounds__(256) void moe_scatter_kernel(hymeta_moe_route_args a) {
+  const int p = blockIdx.x * 256 + threadIdx.x;   // pair index = token * top_k + choice
+  if (p >= a.num_tokens * a.top_k) return;
+  const int e = a.topk_ids[p];
+  const bool local = e >= a.local_expert_begin && e < a.local_expert_end;
+  int pos = -1;
+  if (local) {
+    pos = a.expert_offsets[e] + atomicAdd(a.cursors + e, 1);
+    a.sorted_pair[pos] = p;
+  }
+  a.pair_pos[p] = pos;
+}
+
+// grid = (N / 64, local experts); rows of expert e = sorted slots [offsets[e], offsets[e + 1]).
+// Row tiles of 16 MT rows are walked inside the workgroup (weights of the 64 columns are re-read
+// per tile, from L2 after the first).
+template <int MT>
+__global__ __launch_bounds__(256) void moe_gemm_kernel(hymeta_moe_gemm_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s_red = reinterpret_cast<float*>(smem_raw);  // [4 waves][16 MT rows][64 cols]
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int c = lane >> 4, n = lane & 15;
+  const int nb = blockIdx.x;
+  const int e = a.local_expert_begin + blockIdx.y;
+  const int row_lo = a.expert_offsets[e], row_hi = a.expert_offsets[e + 1];
+  if (row_lo >= row_hi) return;
+
+  const uint16_t* wbase = reinterpret_cast<const uint16_t*>(a.weights) + static_cast<int64_t>(e) * a.w_stride_e;
+  const uint16_t* wrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wrow[i] = wbase + static_cast<int64_t>(nb * kCols + 16 * i + n) * a.K + 8 * c;
+  const int ksteps = a.K / 32;
+  const int nsteps = wave < ksteps ? (ksteps - wave + 3) / 4 : 0;   // this wave's k-steps: wave, wave + 4, ...
+  const int last = nsteps - 1;
+
+  for (int r0 = row_lo; r0 < row_hi; r0 += 16 * MT) {
+    const uint16_t* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int slot = min(r0 + 16 * mt + n, row_hi - 1);   // rows past the expert's end re-read its last row
+      const int src = a.a_rows != nullptr ? a.a_rows[slot] / a.a_rows_div : slot;
+      xrow[mt] = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(src) * a.x_stride_m + 8 * c;
+    }
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[mt][i] = {0.f, 0.f, 0.f, 0.f};
+
+    // two register sets, unconditional loads (steps past the end re-read the last step)
+    u32x4 wa[4], xa[MT], wb[4], xb[MT];
+    auto load = [&](int s, u32x4 (&w)[4], u32x4 (&x)[MT]) {
+      const int k0 = 32 * (wave + 4 * min(s, last));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = ld16g(wrow[i] + k0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) x[mt] = ld16g(xrow[mt] + k0);
+    };
+    auto fma_step = [&](const u32x4 (&w)[4], const u32x4 (&x)[MT]) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[mt][i] = mfma16(as_frag(x[mt]), as_frag(w[i]), acc[mt][i]);
+    };
+    if (nsteps > 0) {
+      load(0, wa, xa);
+      for (int s = 0; s < nsteps; s += 2) {
+        load(s + 1, wb, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        fma_step(wa, xa);
+        load(s + 2, wa, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nsteps) fma_step(wb, xb);
+      }
+    }
+
+    // acc[mt][i][r] = C[row 16 mt + 4c + r][col 16 i + n]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          s_red[(static_cast<size_t>(wave) * 16 * MT + 16 * mt + 4 * c + r) * kCols + 16 * i + n] = acc[mt][i][r];
+    __syncthreads();
+    const int cg = tid & 15;
+    const int col = nb * kCols + 4 * cg;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int row = (tid >> 4) + 16 * j;
+      const int slot = r0 + row;
+      if (slot < row_hi) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          s += *reinterpret_cast<const f32x4*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kCols + 4 * cg);
+        // routing weight applied to the fp32 sums, one rounding (as the fused expert kernel the
+        // reference delegates to)
+        if (a.row_scale != nullptr) s *= a.row_scale[a.scale_rows != nullptr ? a.scale_rows[slot] : slot];
+        const u32x2 o = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(slot) * a.out_stride_m + col) = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// out[r, j] = silu(in[r, j]) * in[r, inter + j]; the product is formed in fp32 and rounded once.
+__global__ __launch_bounds__(256) void silu_and_mul_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                           const int32_t* __restrict__ num_rows_dev, int num_rows,
+                                                           int inter, int64_t in_stride, int64_t out_stride) {
+  const int rows = num_rows_dev != nullptr ? min(*num_rows_dev, num_rows) : num_rows;
+  const int chunks = inter / 8;
+  const int64_t total = static_cast<int64_t>(rows) * chunks;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t r = i / chunks;
+    const int ch = static_cast<int>(i % chunks);
+    const u32x4 g = ld16(in + r * in_stride + 8 * ch);
+    const u32x4 u = ld16(in + r * in_stride + inter + 8 * ch);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g0 = lo_bf(g[j]), g1 = hi_bf(g[j]);
+      o[j] = pack_bf16x2(g0 * sigmoidf(g0) * lo_bf(u[j]), g1 * sigmoidf(g1) * hi_bf(u[j]));
+    }
+    st16(out + r * out_stride + 8 * ch, o);
+  }
+}
+
+// out[t] = sum_k y[pos[t,k]] (+ shared[t]); thread = 8 columns of one token.
+__global__ __launch_bounds__(256) void moe_combine_kernel(hymeta_moe_combine_args a) {
+  const int chunks = a.hidden / 8;
+  const int64_t total = static_cast<int64_t>(a.num_tokens) * chunks;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * 256) {
+    const int t = static_cast<int>(i / chunks);
+    const int ch = static_cast<int>(i % chunks);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int k = 0; k < a.top_k; ++k) {
+      const int pos = a.pair_pos[t * a.top_k + k];
+      if (pos < 0) continue;
+      const u32x4 y = ld16(reinterpret_cast<const uint16_t*>(a.y) + static_cast<int64_t>(pos) * a.y_stride_m + 8 * ch);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {   // y already carries its routing weight
+        acc[2 * j] += lo_bf(y[j]);
+        acc[2 * j + 1] += hi_bf(y[j]);
+      }
+    }
+    if (a.shared != nullptr) {
+      const u32x4 s = ld16(reinterpret_cast<const uint16_t*>(a.shared) + static_cast<int64_t>(t) * a.shared_stride_m + 8 * ch);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] = bf16_round(acc[2 * j]) + lo_bf(s[j]);
+        acc[2 * j + 1] = bf16_round(acc[2 * j + 1]) + hi_bf(s[j]);
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(acc[2 * j], acc[2 * j + 1]);
+    st16(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(t) * a.out_stride_m + 8 * ch, o);
+  }
+}
+
+}  // namespace hymeta
+
+using namespace hymeta;
+
+extern "C" int hymeta_moe_route(const hymeta_moe_route_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_moe_route_args& a = *args;
+  if (a.num_tokens < 0 || a.num_experts <= 0 || a.top_k <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.num_experts > kMaxExperts || a.top_k > 2 || a.top_k > a.num_experts) return HYMETA_ERR_UNSUPPORTED;
+  if (a.logits_dtype != HYMETA_BF16 && a.logits_dtype != HYMETA_F32) return HYMETA_ERR_UNSUPPORTED;
+  if (a.local_expert_begin < 0 || a.local_expert_end > a.num_experts || a.local_expert_begin > a.local_expert_end)
+    return HYMETA_ERR_INVALID_ARG;
+  if (!a.counts || !a.expert_offsets || !a.cursors) return HYMETA_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(a.counts, 0, sizeof(int32_t) * a.num_experts, s) != hipSuccess) return HYMETA_ERR_LAUNCH;
+  if (a.num_tokens > 0) {
+    if (!a.router_logits || !a.topk_ids || !a.topk_weights || !a.sorted_pair || !a.pair_pos) return HYMETA_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(moe_route_kernel, dim3((a.num_tokens + 255) / 256), dim3(256), 0, s, a);
+  }
+  hipLaunchKernelGGL(moe_offsets_kernel, dim3(1), dim3(64), 0, s, a);
+  if (a.num_tokens > 0)
+    hipLaunchKernelGGL(moe_scatter_kernel, dim3((a.num_tokens * a.top_k + 255) / 256), dim3(256), 0, s, a);
+  return launch_status();
+}
+
+extern "C" int hymeta_moe_gemm(const hymeta_moe_gemm_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_moe_gemm_args& a = *args;
+  if (a.max_rows < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.local_expert_begin < 0 || a.local_expert_end < a.local_expert_begin) return HYMETA_ERR_INVALID_ARG;
+  if (a.max_rows == 0 || a.local_expert_end == a.local_expert_begin) return HYMETA_OK;
+  if (!a.x || !a.weights || !a.out || !a.expert_offsets) return HYMETA_ERR_INVALID_ARG;
+  if (a.a_rows != nullptr && a.a_rows_div <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.K % 32 != 0 || a.N % kCols != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((a.x_stride_m | a.out_stride_m | a.w_stride_e) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.weights) | reinterpret_cast<uintptr_t>(a.out)) % 16 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int experts = a.local_expert_end - a.local_expert_begin;
+  dim3 grid(a.N / kCols, experts), block(256);
+  // few rows per expert on average (decode): 16-row tiles; otherwise 64-row tiles
+  const bool small = static_cast<int64_t>(a.max_rows) <= 8LL * experts;
+  if (small) hipLaunchKernelGGL((moe_gemm_kernel<1>), grid, block, 4 * 16 * kCols * sizeof(float), s, a);
+  else hipLaunchKernelGGL((moe_gemm_kernel<4>), grid, block, 4 * 64 * kCols * sizeof(float), s, a);
+  return launch_status();
+}
+
+extern "C" int hymeta_silu_and_mul(const void* in, void* out, const int32_t* num_rows_dev, int32_t num_rows,
+                                   int32_t inter, int64_t in_stride, int64_t out_stride, hymeta_stream_t stream) {
+  if (num_rows < 0 || inter <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (num_rows == 0) return HYMETA_OK;
+  if (!in || !out) return HYMETA_ERR_INVALID_ARG;
+  if (inter % 8 != 0 || (in_stride | out_stride) % 8 != 0 ||
+      (reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  const int64_t total = static_cast<int64_t>(num_rows) * (inter / 8);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(silu_and_mul_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint16_t*>(in), static_cast<uint16_t*>(out), num_rows_dev, num_rows, inter, in_stride,
+                     out_stride);
+  return launch_status();
+}
+
+extern "C" int hymeta_moe_combine(const hymeta_moe_combine_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_moe_combine_args& a = *args;
+  if (a.num_tokens < 0 || a.hidden <= 0 || a.top_k <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.num_tokens == 0) return HYMETA_OK;
+  if (!a.y || !a.out || !a.pair_pos) return HYMETA_ERR_INVALID_ARG;
+  if (a.hidden % 8 != 0 || (a.y_stride_m | a.out_stride_m | a.shared_stride_m) % 8 != 0 ||
+      (reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.shared)) % 16 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  const int64_t total = static_cast<int64_t>(a.num_tokens) * (a.hidden / 8);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(moe_combine_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return launch_status();
+}

@@ -157,6 +157,34 @@ class W8A8GemmArgs(C.Structure):
     ]
 
 
+class MoeRouteArgs(C.Structure):
+    _fields_ = [
+        ("router_logits", _ptr), ("topk_ids", _ptr), ("topk_weights", _ptr), ("counts", _ptr), ("cursors", _ptr),
+        ("expert_offsets", _ptr), ("sorted_pair", _ptr), ("pair_pos", _ptr),
+        ("num_tokens", _i32), ("num_experts", _i32), ("top_k", _i32), ("renormalize", _i32), ("logits_dtype", _i32),
+        ("local_expert_begin", _i32), ("local_expert_end", _i32),
+        ("logits_stride_t", _i64),
+    ]
+
+
+class MoeGemmArgs(C.Structure):
+    _fields_ = [
+        ("x", _ptr), ("weights", _ptr), ("out", _ptr), ("expert_offsets", _ptr), ("a_rows", _ptr), ("scale_rows", _ptr),
+        ("row_scale", _ptr),
+        ("a_rows_div", _i32), ("max_rows", _i32), ("K", _i32), ("N", _i32),
+        ("local_expert_begin", _i32), ("local_expert_end", _i32),
+        ("x_stride_m", _i64), ("out_stride_m", _i64), ("w_stride_e", _i64),
+    ]
+
+
+class MoeCombineArgs(C.Structure):
+    _fields_ = [
+        ("y", _ptr), ("shared", _ptr), ("out", _ptr), ("pair_pos", _ptr), ("topk_weights", _ptr),
+        ("num_tokens", _i32), ("hidden", _i32), ("top_k", _i32),
+        ("y_stride_m", _i64), ("shared_stride_m", _i64), ("out_stride_m", _i64),
+    ]
+
+
 # symbol -> (restype, argtypes); every function include/hymeta_hip.h declares.
 _SIGNATURES = {
     "hymeta_strerror": (C.c_char_p, [C.c_int]),
@@ -178,6 +206,10 @@ _SIGNATURES = {
     "hymeta_gptq_gemm": (C.c_int, [C.POINTER(GptqGemmArgs), _ptr]),
     "hymeta_gptq_dequant": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "hymeta_w8a8_gemm": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),
+    "hymeta_moe_route": (C.c_int, [C.POINTER(MoeRouteArgs), _ptr]),
+    "hymeta_moe_gemm": (C.c_int, [C.POINTER(MoeGemmArgs), _ptr]),
+    "hymeta_silu_and_mul": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),
+    "hymeta_moe_combine": (C.c_int, [C.POINTER(MoeCombineArgs), _ptr]),
     "hymeta_w8a8_gemm_split_k": (C.c_int, [_i32, _i32, _i32]),
     "hymeta_w8a8_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),
 }
@@ -192,6 +224,9 @@ STRUCTS = {
     "hymeta_combine_args": CombineArgs,
     "hymeta_gptq_gemm_args": GptqGemmArgs,
     "hymeta_w8a8_gemm_args": W8A8GemmArgs,
+    "hymeta_moe_route_args": MoeRouteArgs,
+    "hymeta_moe_gemm_args": MoeGemmArgs,
+    "hymeta_moe_combine_args": MoeCombineArgs,
 }
 
 

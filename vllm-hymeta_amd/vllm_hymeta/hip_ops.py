@@ -607,3 +607,95 @@ def w8a8_gemm(x: torch.Tensor, qweight: torch.Tensor, w_scale: torch.Tensor,
         a.workspace, a.workspace_bytes = _p(ws), ws.numel()
     _C.check(lib.hymeta_w8a8_gemm(C.byref(a), _stream(x)), "hymeta_w8a8_gemm")
     return out
+
+
+# ---------------------------------------------------------------------------
+# Sparse mixture of experts
+# ---------------------------------------------------------------------------
+def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None, num_rows_dev: Optional[torch.Tensor] = None
+                 ) -> torch.Tensor:
+    """x bf16 [R, 2I] -> silu(x[:, :I]) * x[:, I:] bf16 [R, I]; ``num_rows_dev`` (int32 device scalar)
+    limits the rows actually computed."""
+    _dev(x, out, num_rows_dev)
+    R, two_i = x.shape
+    inter = two_i // 2
+    _require(x.dtype == torch.bfloat16 and x.stride(1) == 1 and two_i % 2 == 0, "x must be row-contiguous bf16 [R, 2I]")
+    if out is None:
+        out = torch.empty(R, inter, dtype=torch.bfloat16, device=x.device)
+    _require(out.shape == (R, inter) and out.dtype == torch.bfloat16 and out.stride(1) == 1, "out must be bf16 [R, I]")
+    _C.check(_C.load().hymeta_silu_and_mul(_p(x), _p(out), _p(num_rows_dev), R, inter, x.stride(0), out.stride(0),
+                                           _stream(x)), "hymeta_silu_and_mul")
+    return out
+
+
+def moe_forward(x: torch.Tensor, router_logits: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, top_k: int = 1,
+                renormalize: bool = False, shared: Optional[torch.Tensor] = None,
+                local_experts: Optional[tuple] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Sparse MoE block: x bf16 [T,H], router_logits [T,E] (bf16 | fp32), w13 bf16 [E,2I,H], w2 bf16
+    [E,H,I]; ``shared`` bf16 [T,H] is added to the result; ``local_experts = (lo, hi)`` computes only
+    this rank's experts (the caller all-reduces).  Returns bf16 [T,H]."""
+    _dev(x, router_logits, w13, w2, shared, out)
+    T, H = x.shape
+    E, two_i, Hw = w13.shape
+    inter = two_i // 2
+    _require(x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [T, H]")
+    _require(w13.dtype == torch.bfloat16 and w13.is_contiguous() and Hw == H, "w13 must be contiguous bf16 [E, 2I, H]")
+    _require(w2.dtype == torch.bfloat16 and w2.is_contiguous() and w2.shape == (E, H, inter),
+             "w2 must be contiguous bf16 [E, H, I]")
+    _require(router_logits.shape == (T, E) and router_logits.dtype in _DT and router_logits.stride(1) == 1,
+             "router_logits must be [T, E] bf16 | fp32")
+    lo, hi = local_experts if local_experts is not None else (0, E)
+    dev = x.device
+    P = T * top_k
+    ids = torch.empty(T, top_k, dtype=torch.int32, device=dev)
+    wts = torch.empty(T, top_k, dtype=torch.float32, device=dev)
+    meta = torch.empty(3 * (E + 1), dtype=torch.int32, device=dev)
+    counts, cursors, offsets = meta[: E + 1], meta[E + 1: 2 * (E + 1)], meta[2 * (E + 1):]
+    sorted_pair = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+    pair_pos = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+    if out is None:
+        out = torch.empty(T, H, dtype=torch.bfloat16, device=dev)
+    if T == 0:
+        return out
+    lib, st = _C.load(), _stream(x)
+    r = _C.MoeRouteArgs()
+    r.router_logits, r.topk_ids, r.topk_weights = _p(router_logits), _p(ids), _p(wts)
+    r.counts, r.cursors, r.expert_offsets = _p(counts), _p(cursors), _p(offsets)
+    r.sorted_pair, r.pair_pos = _p(sorted_pair), _p(pair_pos)
+    r.num_tokens, r.num_experts, r.top_k, r.renormalize = T, E, top_k, int(bool(renormalize))
+    r.logits_dtype = _DT[router_logits.dtype]
+    r.local_expert_begin, r.local_expert_end = lo, hi
+    r.logits_stride_t = router_logits.stride(0)
+    _C.check(lib.hymeta_moe_route(C.byref(r), st), "hymeta_moe_route")
+
+    h13 = torch.empty(P, two_i, dtype=torch.bfloat16, device=dev)
+    g = _C.MoeGemmArgs()
+    g.x, g.weights, g.out, g.expert_offsets = _p(x), _p(w13), _p(h13), _p(offsets)
+    g.a_rows, g.a_rows_div, g.max_rows, g.K, g.N = _p(sorted_pair), top_k, P, H, two_i
+    g.local_expert_begin, g.local_expert_end = lo, hi
+    g.x_stride_m, g.out_stride_m, g.w_stride_e = x.stride(0), h13.stride(0), w13.stride(0)
+    _C.check(lib.hymeta_moe_gemm(C.byref(g), st), "hymeta_moe_gemm (w13)")
+
+    # slots in use are a prefix only when lo == 0; otherwise act on all P rows (unused rows are never read)
+    hact = torch.empty(P, inter, dtype=torch.bfloat16, device=dev)
+    silu_and_mul(h13, out=hact)
+
+    y = torch.empty(P, H, dtype=torch.bfloat16, device=dev)
+    d = _C.MoeGemmArgs()
+    d.x, d.weights, d.out, d.expert_offsets = _p(hact), _p(w2), _p(y), _p(offsets)
+    d.scale_rows, d.row_scale = _p(sorted_pair), _p(wts)
+    d.a_rows_div, d.max_rows, d.K, d.N = 1, P, inter, H
+    d.local_expert_begin, d.local_expert_end = lo, hi
+    d.x_stride_m, d.out_stride_m, d.w_stride_e = hact.stride(0), y.stride(0), w2.stride(0)
+    _C.check(lib.hymeta_moe_gemm(C.byref(d), st), "hymeta_moe_gemm (w2)")
+
+    c = _C.MoeCombineArgs()
+    c.y, c.shared, c.out, c.pair_pos, c.topk_weights = _p(y), _p(shared), _p(out), _p(pair_pos), _p(wts)
+    c.num_tokens, c.hidden, c.top_k = T, H, top_k
+    c.y_stride_m, c.out_stride_m = y.stride(0), out.stride(0)
+    if shared is not None:
+        _require(shared.shape == (T, H) and shared.dtype == torch.bfloat16 and shared.stride(1) == 1,
+                 "shared must be bf16 [T, H]")
+        c.shared_stride_m = shared.stride(0)
+    _C.check(lib.hymeta_moe_combine(C.byref(c), st), "hymeta_moe_combine")
+    return out

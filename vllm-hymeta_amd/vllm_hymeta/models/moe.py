@@ -1,0 +1,75 @@
+"""Feed-forward blocks of the 70B model on the HIP kernels: the dense gated MLP and the sparse
+mixture of experts with its shared expert.
+
+Reference: ``HymetaMLP`` (``vllm_hymeta/models/modeling_hymeta.py:236-271``), ``HymetaMoE``
+(``:273-364``, vLLM ``FusedMoE(top_k, renormalize=False, reduce_results=True)``) and the
+shared-expert sum in ``HybridBlock.forward`` (``:1044-1058``); eager: ``hf_model/moe.py:34-101``.
+
+What changed in mechanism: routing, the counting sort by expert, both expert GEMMs, the
+activation and the combine (with the shared expert's output folded in) run as six stream-ordered
+launches with no host read of the expert counts; the ``copy.deepcopy`` of the activations
+(``:1048``) is gone; under expert parallelism a rank computes only its experts' pairs and the one
+all-reduce of the layer sums the ranks (what vLLM's EP does at DP = 1).
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .. import hip_ops
+from ..linear import HymetaLinear
+from ..parallel import all_reduce_sum
+
+
+class HymetaMLP(torch.nn.Module):
+    """``down(silu(gate(x)) * up(x))`` with the gate and up projections fused (``gate_up_proj`` rows =
+    gate then up)."""
+
+    def __init__(self, gate_up_proj: HymetaLinear, down_proj: HymetaLinear, tp_group=None, reduce_results: bool = True):
+        super().__init__()
+        self.gate_up_proj, self.down_proj = gate_up_proj, down_proj
+        self.tp_group, self.reduce_results = tp_group, reduce_results
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = self.down_proj(hip_ops.silu_and_mul(self.gate_up_proj(x)))
+        return all_reduce_sum(y, self.tp_group) if self.reduce_results else y
+
+
+def expert_range(num_experts: int, ep_size: int, ep_rank: int) -> Tuple[int, int]:
+    """Experts owned by one expert-parallel rank: contiguous, equal shares (``num_experts % ep_size == 0``)."""
+    if num_experts % ep_size != 0:
+        raise ValueError(f"num_experts {num_experts} must be divisible by the expert-parallel size {ep_size}")
+    per = num_experts // ep_size
+    return ep_rank * per, (ep_rank + 1) * per
+
+
+class HymetaMoE(torch.nn.Module):
+    """Top-k routed experts (+ optional shared expert).  ``w13 [E, 2I, H]`` / ``w2 [E, H, I]`` hold ALL
+    expert slots (a rank that owns experts ``[lo, hi)`` may leave the other slots unallocated-sized
+    views of anything: they are never read)."""
+
+    def __init__(self, gate_weight: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, top_k: int = 1,
+                 renormalize: bool = False, shared_mlp: Optional[HymetaMLP] = None,
+                 local_experts: Optional[Tuple[int, int]] = None, group=None):
+        super().__init__()
+        self.register_buffer("gate_weight", gate_weight)   # [E, H], replicated
+        self.register_buffer("w13", w13)
+        self.register_buffer("w2", w2)
+        self.top_k, self.renormalize = top_k, renormalize
+        self.shared_mlp = shared_mlp
+        self.local_experts = local_experts
+        self.group = group
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        x = hidden_states.reshape(-1, hidden_states.shape[-1])
+        router_logits = torch.nn.functional.linear(x, self.gate_weight)
+        shared = None
+        if self.shared_mlp is not None:
+            # the shared expert is tensor-parallel like a dense MLP; its partial sums ride in the
+            # same all-reduce as the experts' when it is built with reduce_results=False
+            shared = self.shared_mlp(x)
+        out = hip_ops.moe_forward(x, router_logits, self.w13, self.w2, top_k=self.top_k, renormalize=self.renormalize,
+                                  shared=shared, local_experts=self.local_experts)
+        return all_reduce_sum(out, self.group).view_as(hidden_states)
