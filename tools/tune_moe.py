@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Time the sparse MoE block at Hymeta-70B TP=4 shapes (needs a GPU): 16 experts, top-1,
+hidden 3584, expert intermediate 18944 / 4."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vllm-hymeta_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa: E402
+from tune_quant import bench  # noqa: E402
+from vllm_hymeta import hip_ops  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda")
+    E, H, inter = 16, 3584, 18944 // 4
+    w13 = (torch.randn(E, 2 * inter, H, device=dev) * H ** -0.5).to(torch.bfloat16)
+    w2 = (torch.randn(E, H, inter, device=dev) * inter ** -0.5).to(torch.bfloat16)
+    wbytes = (w13.numel() + w2.numel()) * 2
+    for T in (1, 16, 64, 256, 2048, 8192):
+        x = torch.randn(T, H, device=dev).to(torch.bfloat16)
+        logits = torch.randn(T, E, device=dev).to(torch.bfloat16)
+        out = torch.empty(T, H, device=dev, dtype=torch.bfloat16)
+        us = bench(lambda: hip_ops.moe_forward(x, logits, w13, w2, out=out), iters=5)
+        touched = min(T, E) / E * wbytes if T < 64 else wbytes
+        flops = 2.0 * T * 3 * inter * H
+        print(f"moe T={T:5d}: {us:9.1f} us   ~{touched / us / 1e3:7.1f} GB/s weights   {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
