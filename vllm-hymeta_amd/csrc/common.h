@@ -59,6 +59,14 @@ __device__ __forceinline__ float logsigmoidf(float x) {
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// Entry points report launch failures through hipGetLastError(), which is sticky per host thread:
+// a benign error left behind by an earlier runtime call of the host program (a not-ready event
+// or stream query, for instance) must not be mistaken for ours, so the state is cleared first.
+inline hipStream_t begin_launches(hymeta_stream_t stream) {
+  (void)hipGetLastError();
+  return static_cast<hipStream_t>(stream);
+}
+
 inline int launch_status() {
   return hipGetLastError() == hipSuccess ? HYMETA_OK : HYMETA_ERR_LAUNCH;
 }

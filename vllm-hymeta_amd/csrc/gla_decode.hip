@@ -219,7 +219,7 @@ extern "C" int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stre
   gp.normalizer = a.gate_normalizer > 0.f ? a.gate_normalizer : 16.f;
   gp.clamp = a.gate_clamp > 0.f ? a.gate_clamp : 0.95f;
 
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t s = begin_launches(stream);
   const int64_t units = static_cast<int64_t>(a.batch) * a.num_heads;
   const bool f32 = a.state_dtype == HYMETA_F32;
   // Few (sequence, head) units: split the state columns over two workgroups so

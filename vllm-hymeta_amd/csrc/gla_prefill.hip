@@ -740,7 +740,7 @@ extern "C" int hymeta_gla_prefill_varlen(const hymeta_gla_prefill_args* args, hy
   gp.normalizer = a.gate_normalizer > 0.f ? a.gate_normalizer : 16.f;
   gp.clamp = a.gate_clamp > 0.f ? a.gate_clamp : 0.95f;
 
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t s = begin_launches(stream);
   float* ws = static_cast<float*>(a.workspace);
   if (nseg > 1) {
     launch_main<kStateOnly>(a, gp, ws, nseg, seg_chunks, s);

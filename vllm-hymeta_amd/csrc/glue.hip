@@ -126,7 +126,7 @@ extern "C" int hymeta_rope_neox(const hymeta_rope_args* args, hymeta_stream_t st
   if ((a.q_stride_t | a.q_stride_h | a.k_stride_t | a.k_stride_h) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k) |
        reinterpret_cast<uintptr_t>(a.cos_sin_cache)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(rope_neox_kernel, dim3(a.num_tokens), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(rope_neox_kernel, dim3(a.num_tokens), dim3(256), 0, begin_launches(stream), a);
   return launch_status();
 }
 
@@ -145,7 +145,7 @@ extern "C" int hymeta_rms_sumsq2(const hymeta_combine_args* args, hymeta_stream_
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
   const int rc = check_combine(*args, false);
   if (rc != HYMETA_OK || args->num_tokens == 0) return rc;
-  hipLaunchKernelGGL((hybrid_combine_kernel<0>), dim3(args->num_tokens), dim3(256), 0, static_cast<hipStream_t>(stream), *args);
+  hipLaunchKernelGGL((hybrid_combine_kernel<0>), dim3(args->num_tokens), dim3(256), 0, begin_launches(stream), *args);
   return launch_status();
 }
 
@@ -153,6 +153,6 @@ extern "C" int hymeta_hybrid_combine(const hymeta_combine_args* args, hymeta_str
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
   const int rc = check_combine(*args, true);
   if (rc != HYMETA_OK || args->num_tokens == 0) return rc;
-  hipLaunchKernelGGL((hybrid_combine_kernel<1>), dim3(args->num_tokens), dim3(256), 0, static_cast<hipStream_t>(stream), *args);
+  hipLaunchKernelGGL((hybrid_combine_kernel<1>), dim3(args->num_tokens), dim3(256), 0, begin_launches(stream), *args);
   return launch_status();
 }

@@ -264,7 +264,7 @@ extern "C" int hymeta_moe_route(const hymeta_moe_route_args* args, hymeta_stream
   if (a.local_expert_begin < 0 || a.local_expert_end > a.num_experts || a.local_expert_begin > a.local_expert_end)
     return HYMETA_ERR_INVALID_ARG;
   if (!a.counts || !a.expert_offsets || !a.cursors) return HYMETA_ERR_INVALID_ARG;
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t s = begin_launches(stream);
   if (hipMemsetAsync(a.counts, 0, sizeof(int32_t) * a.num_experts, s) != hipSuccess) return HYMETA_ERR_LAUNCH;
   if (a.num_tokens > 0) {
     if (!a.router_logits || !a.topk_ids || !a.topk_weights || !a.sorted_pair || !a.pair_pos) return HYMETA_ERR_INVALID_ARG;
@@ -288,7 +288,7 @@ extern "C" int hymeta_moe_gemm(const hymeta_moe_gemm_args* args, hymeta_stream_t
   if ((a.x_stride_m | a.out_stride_m | a.w_stride_e) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.weights) | reinterpret_cast<uintptr_t>(a.out)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t s = begin_launches(stream);
   const int experts = a.local_expert_end - a.local_expert_begin;
   dim3 grid(a.N / kCols, experts), block(256);
   // few rows per expert on average (decode): 16-row tiles; otherwise 64-row tiles
@@ -309,7 +309,7 @@ extern "C" int hymeta_silu_and_mul(const void* in, void* out, const int32_t* num
   const int64_t total = static_cast<int64_t>(num_rows) * (inter / 8);
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(silu_and_mul_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(silu_and_mul_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, begin_launches(stream),
                      static_cast<const uint16_t*>(in), static_cast<uint16_t*>(out), num_rows_dev, num_rows, inter, in_stride,
                      out_stride);
   return launch_status();
@@ -327,6 +327,6 @@ extern "C" int hymeta_moe_combine(const hymeta_moe_combine_args* args, hymeta_st
   const int64_t total = static_cast<int64_t>(a.num_tokens) * (a.hidden / 8);
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(moe_combine_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(moe_combine_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, begin_launches(stream), a);
   return launch_status();
 }

@@ -432,7 +432,7 @@ extern "C" int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args
   const int group = a.num_heads / a.num_kv_heads;
   const int head_groups = (group + kMaxGroup - 1) / kMaxGroup;
 
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t s = begin_launches(stream);
   if (a.new_key != nullptr) {
     if (!a.new_value || !a.slot_mapping) return HYMETA_ERR_INVALID_ARG;
     if ((a.new_key_stride_b | a.new_key_stride_h | a.new_value_stride_b | a.new_value_stride_h) % 8 != 0 ||

@@ -515,7 +515,7 @@ extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream
   const int requested = splits;
   const int gps = (G + splits - 1) / splits;
   splits = (G + gps - 1) / gps;
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t s = begin_launches(stream);
   // workspace = [slabs fp32 [requested splits][M][N]][ticket counters, zeroed per call]
   float* slabs = a.workspace;
   int* counters = reinterpret_cast<int*>(reinterpret_cast<char*>(a.workspace) + static_cast<size_t>(requested) * a.M * a.N * sizeof(float));
@@ -553,7 +553,7 @@ extern "C" int hymeta_gptq_dequant(const int32_t* qweight, const int32_t* qzeros
   if ((reinterpret_cast<uintptr_t>(qweight) | reinterpret_cast<uintptr_t>(out)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
   const int64_t threads = static_cast<int64_t>(K / (32 / bits)) * (N / 4);
   dim3 grid(static_cast<unsigned>((threads + 255) / 256)), block(256);
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t s = begin_launches(stream);
   uint16_t* o = static_cast<uint16_t*>(out);
   if (bits == 4) hipLaunchKernelGGL(gptq_dequant_kernel<4>, grid, block, 0, s, qweight, qzeros, scales, o, K, N, group_size, scales_dtype, zero_offset);
   else hipLaunchKernelGGL(gptq_dequant_kernel<8>, grid, block, 0, s, qweight, qzeros, scales, o, K, N, group_size, scales_dtype, zero_offset);
@@ -595,7 +595,7 @@ extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream
   const int requested = splits;
   const int sps = (ksteps + splits - 1) / splits;
   splits = (ksteps + sps - 1) / sps;
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t s = begin_launches(stream);
   int* slabs = static_cast<int*>(a.workspace);
   int* counters = reinterpret_cast<int*>(static_cast<char*>(a.workspace) + static_cast<size_t>(requested) * a.M * a.N * sizeof(int));
   if (splits > 1 && hipMemsetAsync(counters, 0, static_cast<size_t>(gptq_tiles(a.M, a.N)) * sizeof(int), s) != hipSuccess)

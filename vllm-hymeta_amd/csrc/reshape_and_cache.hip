@@ -61,6 +61,6 @@ extern "C" int hymeta_reshape_and_cache(const hymeta_reshape_and_cache_args* arg
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(reshape_and_cache_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a, chunks_per_row, elems_per_chunk);
+                     begin_launches(stream), a, chunks_per_row, elems_per_chunk);
   return launch_status();
 }

@@ -422,7 +422,7 @@ extern "C" int hymeta_meta_swa_prefill(const hymeta_swa_prefill_args* args, hyme
   const int seqs = have_rows ? a.num_seqs : 0;
   if (!have_rows) a.num_seqs = 0;
   dim3 grid((max_rows + kRowsPerBlock - 1) / kRowsPerBlock, seqs + (a.meta_query != nullptr ? 1 : 0), a.num_heads);
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t s = begin_launches(stream);
   if (paged) hipLaunchKernelGGL((swa_prefill_kernel<true>), grid, dim3(kThreads), 0, s, a, scale * kLog2e);
   else hipLaunchKernelGGL((swa_prefill_kernel<false>), grid, dim3(kThreads), 0, s, a, scale * kLog2e);
   return launch_status();

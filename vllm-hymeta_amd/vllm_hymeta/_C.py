@@ -249,6 +249,11 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{_LIB_NAME} not found at {path}: build it with `make -C vllm-hymeta_amd` "
             "(or __graft_entry__.build()); the Hymeta ops have no non-HIP fallback")
+    # torch carries its own copy of the HIP runtime (same soname).  The process must hold one
+    # runtime only, and it has to be the one that owns torch's device memory and streams: loaded
+    # the other way round, launches from this library fail with hipErrorNoDevice.
+    import torch  # noqa: F401
+
     lib = C.CDLL(path)
     for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError names the missing symbol
