@@ -406,6 +406,33 @@ typedef struct hymeta_combine_args {
 int hymeta_rms_sumsq2(const hymeta_combine_args* args, hymeta_stream_t stream);
 int hymeta_hybrid_combine(const hymeta_combine_args* args, hymeta_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Block-level RMS norm with the residual add folded in.
+ * Replaces vLLM's RMSNorm as the decoder blocks call it:
+ *   attn_norm(x)                 vllm_hymeta/models/modeling_hymeta.py:1024,
+ *                                model_for_7B/modeling_gla_swa.py:294
+ *   mlp_norm(x, residual)        modeling_hymeta.py:1039, modeling_gla_swa.py:302
+ *   final norm                   modeling_hymeta.py:1191, modeling_gla_swa.py:497
+ * Arithmetic of the device op those calls dispatch to (vllm==0.10.0
+ * rms_norm / fused_add_rms_norm, third party):
+ *   residual != NULL: z = bf16(x + residual); residual <- z   (in place)
+ *   residual == NULL: z = x
+ *   out = bf16( bf16(z * rsqrt(mean(z^2) + eps)) * weight ),  mean and rsqrt in fp32.
+ * out may alias x.  hidden is a multiple of 8.
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_add_rmsnorm_args {
+  const void* x;         /* bf16 [num_tokens, hidden] */
+  void* residual;        /* bf16 [num_tokens, hidden], updated in place, or NULL */
+  const void* weight;    /* bf16 [hidden] */
+  void* out;             /* bf16 [num_tokens, hidden] */
+  int32_t num_tokens;
+  int32_t hidden;
+  int64_t x_stride_t, residual_stride_t, out_stride_t;
+  float eps;
+} hymeta_add_rmsnorm_args;
+
+int hymeta_add_rmsnorm(const hymeta_add_rmsnorm_args* args, hymeta_stream_t stream);
+
 
 /* ------------------------------------------------------------------------
  * Fused dequant-GEMM for GPTQ checkpoints: out = x W (+ bias), W dequantised on

@@ -62,6 +62,20 @@ def rms_norm_ref(x: torch.Tensor, weight: Optional[torch.Tensor], eps: float = 1
     return y if weight is None else y * weight.to(dt)
 
 
+def add_rms_norm_ref(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor,
+                     eps: float = 1e-6) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """The blocks' ``attn_norm(x)`` / ``mlp_norm(x, residual)``
+    (``vllm_hymeta/models/modeling_hymeta.py:1024,1039``,
+    ``model_for_7B/modeling_gla_swa.py:294,302``): vLLM's ``RMSNorm`` with an optional
+    residual.  As the device op computes it (vllm==0.10.0 ``fused_add_rms_norm``, third
+    party): the sum is rounded to the activation dtype, stored as the new residual, and
+    normed.  Returns ``(normed, new_residual)``."""
+    if residual is not None:
+        x = (x.float() + residual.float()).to(x.dtype)
+        residual = x
+    return rms_norm_ref(x, weight, eps), residual
+
+
 def rms_norm_tp_ref(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6,
                     variance: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``HymetaRMSNormTP._forward`` (``vllm_hymeta/models/modeling_hymeta.py:151-173``):
@@ -231,3 +245,16 @@ def hybrid_layer_70b_ref(x: torch.Tensor, meta_x: torch.Tensor, positions: torch
     o_lin = o_lin.to(x.dtype).reshape(T, num_heads * D)
     y = hybrid_combine_ref(o_attn, o_lin, p["norm1.weight"], p["norm2.weight"], norm_eps)
     return _linear(y, p["out_proj.weight"])
+
+
+# --------------------------------------------------------------------------- decoder block
+def decoder_block_ref(x: torch.Tensor, attn, mlp, attn_norm_w: torch.Tensor, mlp_norm_w: torch.Tensor,
+                      eps: float = 1e-6) -> torch.Tensor:
+    """``HybridBlock.forward`` / ``GLAswaBlock.forward``
+    (``vllm_hymeta/models/modeling_hymeta.py:1021-1075``, ``model_for_7B/modeling_gla_swa.py:292-306``):
+    ``r = x; h = attn(attn_norm(x)); n, r = mlp_norm(h, r); return r + mlp(n)``; ``attn`` and ``mlp``
+    are callables on bf16 ``[T, hidden]``."""
+    h, _ = add_rms_norm_ref(x, None, attn_norm_w, eps)
+    h = attn(h)
+    n, r = add_rms_norm_ref(h, x, mlp_norm_w, eps)
+    return (r.float() + mlp(n).float()).to(x.dtype)

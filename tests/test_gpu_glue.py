@@ -1,4 +1,4 @@
-"""RoPE and the 70B two-branch norm combine vs the CPU restatement."""
+"""RoPE, the 70B two-branch norm combine and the blocks' RMS norm vs the CPU restatement."""
 import pytest
 import torch
 
@@ -70,3 +70,39 @@ def test_hybrid_combine(tp):
         out = hip_ops.hybrid_combine(a, b, wa, wb, 1e-6, stats=stats)
         torch.cuda.synchronize()
         assert_bf16_close(out.cpu(), ref, f"hybrid combine shard {r}", rel=3e-3)
+
+
+@pytest.mark.parametrize("T,hidden", [(1, 3584), (19, 3584), (64, 8192), (5, 136)])
+@pytest.mark.parametrize("with_residual", [False, True])
+def test_add_rmsnorm(T, hidden, with_residual):
+    from oracle.layers import add_rms_norm_ref
+    from vllm_hymeta import hip_ops
+
+    g_ = gen(2)
+    x = randn_bf16(g_, T, hidden, scale=2.0)
+    res = randn_bf16(g_, T, hidden) if with_residual else None
+    w = (1 + 0.1 * torch.randn(hidden, generator=g_)).to(torch.bfloat16)
+    ref, res_ref = add_rms_norm_ref(x, res, w, 1e-6)
+    res_dev = res.cuda() if with_residual else None
+    out = hip_ops.add_rmsnorm(x.cuda(), w.cuda(), 1e-6, residual=res_dev)
+    torch.cuda.synchronize()
+    if with_residual:
+        assert torch.equal(res_dev.cpu(), res_ref), "new residual = bf16(x + residual), bit-exact"
+    assert_bf16_close(out.cpu(), ref, "add_rmsnorm", rel=3e-3)
+    # in place over x, from a strided view of a wider buffer
+    wide = torch.zeros(T, hidden + 64, dtype=torch.bfloat16, device="cuda")
+    wide[:, :hidden] = x.cuda()
+    res_dev2 = res.cuda() if with_residual else None
+    hip_ops.add_rmsnorm(wide[:, :hidden], w.cuda(), 1e-6, residual=res_dev2, out=wide[:, :hidden])
+    torch.cuda.synchronize()
+    assert torch.equal(wide[:, :hidden].cpu(), out.cpu())
+    assert not wide[:, hidden:].any()
+
+
+def test_add_rmsnorm_rejects_bad_layout():
+    from vllm_hymeta import hip_ops
+
+    x = torch.zeros(4, 130, dtype=torch.bfloat16, device="cuda")
+    w = torch.ones(130, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(Exception):
+        hip_ops.add_rmsnorm(x, w)

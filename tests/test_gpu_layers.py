@@ -277,3 +277,41 @@ def test_70b_block_two_head_shards_equal_unsharded():
     assert torch.equal(torch.cat([p_[1] for p_ in parts], dim=1), o_a)
     assert torch.equal(torch.cat([p_[2] for p_ in parts], dim=1), o_l)
     assert_bf16_close(y_tp.cpu(), y_full.cpu(), "two shards vs unsharded", rel=1e-2)
+
+
+def test_7b_decoder_block_gla_with_dense_mlp():
+    """Pre-norm, GLA attention, norm with the residual add, gated MLP, residual: one block of the 7B
+    model on a 512-token prompt."""
+    from oracle.layers import decoder_block_ref, gla_layer_7b_ref
+    from oracle.moe import mlp_ref
+    from vllm_hymeta.linear import HymetaLinear
+    from vllm_hymeta.model_for_7B.gla_attention import GatedLinearAttention
+    from vllm_hymeta.models.block import GLAswaBlock, HymetaRMSNorm
+    from vllm_hymeta.models.moe import HymetaMLP
+
+    dev = torch.device("cuda")
+    g_ = gen(7)
+    hidden, H, Hkv, inter, T = 512, 4, 2, 1024, 512
+    p = _gla_params(g_, hidden, H, Hkv)
+    w_gu, w_dn = _lin(g_, 2 * inter, hidden, False)["weight"], _lin(g_, hidden, inter, False)["weight"]
+    n1 = (1 + 0.1 * torch.randn(hidden, generator=g_)).to(torch.bfloat16)
+    n2 = (1 + 0.1 * torch.randn(hidden, generator=g_)).to(torch.bfloat16)
+    x = randn_bf16(g_, T, hidden)
+    ref = decoder_block_ref(x, lambda h: gla_layer_7b_ref(h, p, H, Hkv)[0], lambda h: mlp_ref(h, w_gu, w_dn), n1, n2)
+
+    qkv_w = torch.cat([p["q_proj.weight"], p["k_proj.weight"], p["v_proj.weight"]]).to(dev)
+    qkv_b = torch.cat([p["q_proj.bias"], p["k_proj.bias"], p["v_proj.bias"]]).to(dev)
+    attn = GatedLinearAttention(
+        hidden, H, Hkv, HymetaLinear.from_weight(qkv_w, qkv_b), HymetaLinear.from_weight(p["gk_proj.0.weight"].to(dev)),
+        HymetaLinear.from_weight(p["gk_proj.1.weight"].to(dev), p["gk_proj.1.bias"].to(dev)),
+        HymetaLinear.from_weight(p["o_proj.weight"].to(dev)), p["g_norm.weight"].to(dev))
+    mlp = HymetaMLP(HymetaLinear.from_weight(w_gu.to(dev)), HymetaLinear.from_weight(w_dn.to(dev)))
+    block = GLAswaBlock(HymetaRMSNorm(hidden, 1e-6, n1.to(dev)), attn, HymetaRMSNorm(hidden, 1e-6, n2.to(dev)), mlp)
+    cache = torch.zeros(2, H, D, D, dtype=torch.bfloat16, device=dev)
+    xd = x.to(dev)
+    out, second = block(xd, gla_cache=cache, state_indices_tensor=torch.tensor([1], dtype=torch.int32, device=dev),
+                        attn_metadata=_md(dev, prefill_lens=[T], context_lens=[0]))
+    torch.cuda.synchronize()
+    assert second is None
+    assert torch.equal(xd.cpu(), x), "the block must not modify its input"
+    assert_bf16_close(out.cpu(), ref, "7B decoder block", rel=1e-2)

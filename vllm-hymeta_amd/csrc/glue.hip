@@ -1,5 +1,5 @@
-// Element-wise glue of the attention layers: NeoX rotary embedding and the
-// 70B two-branch RMS-norm combine.  HBM-bound; 16-byte accesses throughout.
+// Element-wise glue of the attention layers: NeoX rotary embedding, the 70B
+// two-branch RMS-norm combine and the blocks' RMS norm with the residual add.  HBM-bound; 16-byte accesses throughout.
 #include "common.h"
 
 namespace hymeta {
@@ -112,6 +112,44 @@ __global__ __launch_bounds__(256) void hybrid_combine_kernel(hymeta_combine_args
   }
 }
 
+// One workgroup per token.  With a residual: z = bf16(x + residual) is written over the residual
+// and read back by the same thread for the second pass.
+template <bool ADD>
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(hymeta_add_rmsnorm_args a) {
+  __shared__ float s_red[4];
+  const int64_t t = blockIdx.x;
+  const uint16_t* x = reinterpret_cast<const uint16_t*>(a.x) + t * a.x_stride_t;
+  uint16_t* res = ADD ? reinterpret_cast<uint16_t*>(a.residual) + t * a.residual_stride_t : nullptr;
+  const uint16_t* w = reinterpret_cast<const uint16_t*>(a.weight);
+  uint16_t* out = reinterpret_cast<uint16_t*>(a.out) + t * a.out_stride_t;
+  const int chunks = a.hidden / 8;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+    u32x4 z = ld16(x + 8 * c);
+    if (ADD) {
+      const u32x4 r = ld16(res + 8 * c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) z[i] = pack_bf16x2(lo_bf(z[i]) + lo_bf(r[i]), hi_bf(z[i]) + hi_bf(r[i]));
+      st16(res + 8 * c, z);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float z0 = lo_bf(z[i]), z1 = hi_bf(z[i]);
+      ss += z0 * z0 + z1 * z1;
+    }
+  }
+  const float rs = rsqrtf(block_sum_256(ss, s_red) / a.hidden + a.eps);
+  const uint16_t* zsrc = ADD ? res : x;
+  for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+    const u32x4 z = ld16(zsrc + 8 * c), wv = ld16(w + 8 * c);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      o[i] = pack_bf16x2(bf16_round(lo_bf(z[i]) * rs) * lo_bf(wv[i]), bf16_round(hi_bf(z[i]) * rs) * hi_bf(wv[i]));
+    st16(out + 8 * c, o);
+  }
+}
+
 }  // namespace hymeta
 
 using namespace hymeta;
@@ -154,5 +192,20 @@ extern "C" int hymeta_hybrid_combine(const hymeta_combine_args* args, hymeta_str
   const int rc = check_combine(*args, true);
   if (rc != HYMETA_OK || args->num_tokens == 0) return rc;
   hipLaunchKernelGGL((hybrid_combine_kernel<1>), dim3(args->num_tokens), dim3(256), 0, begin_launches(stream), *args);
+  return launch_status();
+}
+
+extern "C" int hymeta_add_rmsnorm(const hymeta_add_rmsnorm_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_add_rmsnorm_args& a = *args;
+  if (a.num_tokens < 0 || a.hidden <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.num_tokens == 0) return HYMETA_OK;
+  if (!a.x || !a.weight || !a.out) return HYMETA_ERR_INVALID_ARG;
+  if (a.hidden % 8 != 0 || (a.x_stride_t | a.out_stride_t | (a.residual ? a.residual_stride_t : 0)) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.residual) | reinterpret_cast<uintptr_t>(a.weight) |
+       reinterpret_cast<uintptr_t>(a.out)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  hipStream_t s = begin_launches(stream);
+  if (a.residual != nullptr) hipLaunchKernelGGL((add_rmsnorm_kernel<true>), dim3(a.num_tokens), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((add_rmsnorm_kernel<false>), dim3(a.num_tokens), dim3(256), 0, s, a);
   return launch_status();
 }

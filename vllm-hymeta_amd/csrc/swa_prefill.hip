@@ -68,7 +68,7 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) {
 // grid = (ceil(max_seqlen_q / 256), num_seqs (+1: the meta-query rows), num_heads)
 template <bool PAGED>
 __global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefill_args a, float scale_log2) {
-  constexpr int D = kHeadDim;
+
   __shared__ __attribute__((aligned(16))) Smem sm;
 
   const int tid = threadIdx.x;

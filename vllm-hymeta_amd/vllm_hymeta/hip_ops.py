@@ -516,6 +516,28 @@ def hybrid_combine(o_attn: torch.Tensor, o_lin: torch.Tensor, weight1: torch.Ten
     return out
 
 
+def add_rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, residual: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """RMS norm of the decoder blocks.  With ``residual``: residual <- bf16(x + residual) in place
+    and the norm is taken of that sum (the blocks' ``mlp_norm(hidden, residual)`` call)."""
+    _dev(x, weight, residual, out)
+    _require(x.dim() == 2 and x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [T, hidden]")
+    _require(weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.numel() == x.shape[1],
+             "weight must be contiguous bf16 [hidden]")
+    if residual is not None:
+        _require(residual.shape == x.shape and residual.dtype == torch.bfloat16 and residual.stride(1) == 1,
+                 "residual must be row-contiguous bf16 [T, hidden]")
+    if out is None:
+        out = torch.empty_like(x)
+    _require(out.shape == x.shape and out.dtype == torch.bfloat16 and out.stride(1) == 1, "out must be row-contiguous bf16 [T, hidden]")
+    a = _C.AddRmsNormArgs(x=x.data_ptr(), residual=residual.data_ptr() if residual is not None else None,
+                          weight=weight.data_ptr(), out=out.data_ptr(), num_tokens=x.shape[0], hidden=x.shape[1],
+                          x_stride_t=x.stride(0), residual_stride_t=residual.stride(0) if residual is not None else 0,
+                          out_stride_t=out.stride(0), eps=eps)
+    _C.check(_C.load().hymeta_add_rmsnorm(C.byref(a), _stream(x)), "hymeta_add_rmsnorm")
+    return out
+
+
 # ---------------------------------------------------------------------------
 # Quantised linears
 # ---------------------------------------------------------------------------

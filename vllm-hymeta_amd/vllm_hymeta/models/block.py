@@ -1,0 +1,65 @@
+"""Decoder block around the attention layers: pre-norm, attention, norm with the residual add
+folded in, feed-forward, residual.
+
+Reference: ``HybridBlock.forward`` (``vllm_hymeta/models/modeling_hymeta.py:1009-1075``) and the 7B
+``GLAswaBlock.forward`` (``vllm_hymeta/model_for_7B/modeling_gla_swa.py:283-306``) -- the same
+sequence in both models; vLLM's ``RMSNorm`` (``:949,957`` / ``:241,271``) is ``HymetaRMSNorm`` here.
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+import torch
+
+from .. import hip_ops
+
+
+class HymetaRMSNorm(torch.nn.Module):
+    """vLLM ``RMSNorm`` call convention: ``norm(x)`` returns the normed tensor, ``norm(x, residual)``
+    returns ``(normed(x + residual), x + residual)`` and updates ``residual`` in place."""
+
+    def __init__(self, hidden_size: int, eps: float = 1e-6, weight: Optional[torch.Tensor] = None,
+                 device=None):
+        super().__init__()
+        if weight is None:
+            weight = torch.ones(hidden_size, dtype=torch.bfloat16, device=device)
+        if weight.numel() != hidden_size:
+            raise ValueError(f"weight has {weight.numel()} elements, hidden_size is {hidden_size}")
+        self.register_buffer("weight", weight.to(torch.bfloat16).contiguous())
+        self.variance_epsilon = eps
+
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None
+                ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        x2 = x.reshape(-1, x.shape[-1])
+        if residual is None:
+            return hip_ops.add_rmsnorm(x2, self.weight, self.variance_epsilon).view_as(x)
+        r2 = residual.reshape(-1, residual.shape[-1])
+        if r2.data_ptr() != residual.data_ptr():
+            raise ValueError("residual must be viewable as [tokens, hidden] without a copy (it is updated in place)")
+        out = hip_ops.add_rmsnorm(x2, self.weight, self.variance_epsilon, residual=r2)
+        return out.view_as(x), residual
+
+
+class DecoderBlock(torch.nn.Module):
+    """``attn`` is any of the attention layers of this package (its keyword arguments pass through),
+    ``mlp`` a ``HymetaMLP`` or ``HymetaMoE``.  Returns ``(hidden_states, None)`` as the reference's
+    70B block does; the 7B block's second value (its residual) is never read by its caller
+    (``model_for_7B/modeling_gla_swa.py:479-485``)."""
+
+    def __init__(self, attn_norm: HymetaRMSNorm, attn: torch.nn.Module, mlp_norm: HymetaRMSNorm, mlp: torch.nn.Module):
+        super().__init__()
+        self.attn_norm, self.attn, self.mlp_norm, self.mlp = attn_norm, attn, mlp_norm, mlp
+
+    def forward(self, hidden_states: torch.Tensor, **attn_kwargs) -> Tuple[torch.Tensor, None]:
+        # the block's input becomes the residual stream; it is updated in place by mlp_norm, so
+        # take a private copy when the caller keeps using its tensor
+        residual = hidden_states.clone()
+        normed = self.attn_norm(hidden_states)
+        attn_out = self.attn(normed, **attn_kwargs)
+        normed, residual = self.mlp_norm(attn_out, residual)
+        return residual + self.mlp(normed), None
+
+
+HybridBlock = DecoderBlock      # vllm_hymeta/models/modeling_hymeta.py:935
+GLAswaBlock = DecoderBlock      # vllm_hymeta/model_for_7B/modeling_gla_swa.py:221
