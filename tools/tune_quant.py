@@ -38,8 +38,12 @@ def main():
     dev = torch.device("cuda")
     shapes = [("qkv", 3584, 4608), ("o", 3584, 3584), ("gate_up", 3584, 37888), ("down", 18944, 3584)]
     Ms = [int(m) for m in os.environ.get("MS", "1,16,64,256,2048,8192").split(",")]
-    group = 128
+    group = int(os.environ.get("GROUP", "128"))
+    sweep = [int(v) for v in os.environ.get("SPLITS", "").split(",") if v]
+    only = os.environ.get("ONLY", "")
     for name, K, N in shapes:
+        if only and name not in only.split(","):
+            continue
         qw = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=dev)
         qz = torch.randint(-2**31, 2**31 - 1, (K // group, N // 8), dtype=torch.int32, device=dev)
         sc = (torch.rand(K // group, N, device=dev) * 0.01).to(torch.float16)
@@ -50,6 +54,9 @@ def main():
             x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
             out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             t4 = bench(lambda: hip_ops.gptq_gemm(x, qw, qz, sc, 4, group, out=out))
+            for sk in sweep:
+                ts = bench(lambda: hip_ops.gptq_gemm(x, qw, qz, sc, 4, group, out=out, split_k=sk))
+                print(f"    {name} M={M} split_k={sk}: {ts:8.1f} us", flush=True)
             t8 = bench(lambda: hip_ops.w8a8_gemm(x, w8, ws, out=out))
             tb = bench(lambda: torch.matmul(x, wb.t(), out=out))
             fl = 2.0 * M * K * N

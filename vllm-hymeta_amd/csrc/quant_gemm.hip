@@ -290,6 +290,341 @@ __global__ __launch_bounds__(256) void gptq_gemm_kernel(hymeta_gptq_gemm_args a,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The 33..64-row regime.  There the kernel above loses twice: its waves split K, so each fetches
+// the whole 64 x K activation block (four times the bytes of the weights it streams) straight
+// from L2 in fragment-shaped pieces, and at 64 rows the loop is bound by instruction issue (one
+// de-quantisation instruction per 1.1 weights beside 2 * 64 flop per weight), not by memory.
+// This kernel takes 128 columns per workgroup of 8 waves = 2 K halves x 2 row halves x 2 column
+// halves: the activation block is staged once per workgroup, two 128-deep chunks per barrier, in
+// full 256-byte row pieces, into double-buffered LDS (k already in the order the nibble trick
+// emits); a wave owns 32 rows x 64 columns of one chunk, software-pipelines its k-steps by hand
+// (operands of step t + 1 are fetched and de-quantised while the matrix cores work on step t) and
+// keeps its weights eight k-steps ahead in registers; the K halves meet in LDS at the end.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWideCols = 128;
+constexpr int kWideThreads = 512;
+constexpr int kChunkK = 128;                    // k per staged activation chunk = 4 MFMA k-steps
+constexpr int kXPitch = kChunkK * 2 + 16;       // bytes per LDS row: 16 rows x 16 B hit 64 distinct banks
+constexpr int kXBuf = 64 * kXPitch;
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// grid = (N / 128, ceil(M / 64), splits)
+template <int BITS, int KSTEPS>
+__global__ __launch_bounds__(kWideThreads) void gptq_gemm_wide_kernel(hymeta_gptq_gemm_args a, int splits, int chunks_per_split,
+                                                                      float* slabs, int* counters) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * kXBuf];   // [buffer][K half][row][pitch]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int c = lane >> 4, n = lane & 15;
+  // 8 waves = 2 K halves x 2 row halves x 2 column halves: in every round of two chunks the waves
+  // of K half kh work on chunk 2 round + kh
+  const int kh = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
+  const int m0 = blockIdx.y * 64;
+  const int split = blockIdx.z;
+  const int ch_lo = split * chunks_per_split;
+  const int ch_hi = min(a.K / kChunkK, ch_lo + chunks_per_split);
+  const int nch = ch_hi - ch_lo;                  // >= 1 (host)
+  const int col0 = blockIdx.x * kWideCols + wc * 64 + 4 * n;
+  constexpr int PACK = 32 / BITS;
+  constexpr int QL = BITS == 4 ? 1 : 2;
+  constexpr int GPC = 4 / KSTEPS;                 // groups per chunk
+  constexpr int kRing = 8;                        // weight k-steps in flight
+
+  f32x4 acc_tot[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_tot[mt][i] = {0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones_raw = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  const bf16x8 ones = as_frag(ones_raw);
+
+  // ---- activation staging, two chunks per round: piece p = rows 16p .. 16p+15; 32 lanes x 16 B =
+  // the row's two 256-byte chunk pieces (lanes 0-15: the even chunk, 16-31: the odd one)
+  const int xhalf = (tid >> 4) & 1;
+  const uint16_t* xsrc[4];
+  int xdst[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = 16 * p + (tid >> 5);
+    xsrc[p] = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(min(m0 + row, a.M - 1)) * a.x_stride_m + 8 * (tid & 15);
+    xdst[p] = xhalf * kXBuf + row * kXPitch + 16 * (tid & 15);
+  }
+  u32x4 xs[4];                                    // the next round's chunks, on their way to LDS
+  auto load_x = [&](int round, u32x4 (&xr)[4]) {
+    const int ch = ch_lo + min(2 * round + xhalf, nch - 1);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) xr[p] = ld16g(xsrc[p] + ch * kChunkK);
+  };
+  auto write_x = [&](int buf, const u32x4 (&xr)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      u32x4 v = xr[p];
+      if constexpr (BITS == 4) {
+        // k-slot order (0,4,1,5,2,6,3,7), the order the nibble trick emits
+        u32x4 t;
+        t[0] = __builtin_amdgcn_perm(v[2], v[0], 0x05040100u);
+        t[1] = __builtin_amdgcn_perm(v[2], v[0], 0x07060302u);
+        t[2] = __builtin_amdgcn_perm(v[3], v[1], 0x05040100u);
+        t[3] = __builtin_amdgcn_perm(v[3], v[1], 0x07060302u);
+        v = t;
+      }
+      *reinterpret_cast<u32x4*>(smem + buf * 2 * kXBuf + xdst[p]) = v;
+    }
+  };
+  // A fragments of this wave: rows 32 wr + 16 mt + n, 8 k at 8c of the k-step
+  const int afrag_off = kh * kXBuf + (32 * wr + n) * kXPitch + 16 * c;
+
+  // ---- weight ring and group parameters: every load unconditional, indices clamped
+  const int nrounds = (nch + 1) / 2;
+  const int last_step = 4 * nrounds - 1;
+  u32x4 qring[kRing][QL];
+  u32x2 sraw[2][GPC];
+  uint32_t zraw[2][GPC];
+  auto load_w = [&](int t, u32x4 (&q)[QL]) {
+    const int tt = min(t, last_step);
+    const int k = (ch_lo + min(2 * (tt >> 2) + kh, nch - 1)) * kChunkK + 32 * (tt & 3) + 8 * c;
+    const int32_t* qp = a.qweight + static_cast<int64_t>(k / PACK) * a.N + col0;
+#pragma unroll
+    for (int i = 0; i < QL; ++i) q[i] = ld16g(qp + static_cast<int64_t>(i) * a.N);
+  };
+  auto load_params = [&](int ci, u32x2 (&sr)[GPC], uint32_t (&zr)[GPC]) {
+    const int g0 = (ch_lo + min(2 * min(ci, nrounds - 1) + kh, nch - 1)) * GPC;
+#pragma unroll
+    for (int gq = 0; gq < GPC; ++gq) {
+      const int64_t g = g0 + gq;
+      sr[gq] = *(const __attribute__((address_space(1))) u32x2*)(reinterpret_cast<const uint16_t*>(a.scales) + g * a.N + col0);
+      zr[gq] = *(const __attribute__((address_space(1))) uint32_t*)(a.qzeros + g * (a.N / PACK) + col0 / PACK);
+    }
+  };
+
+  // ---- the k-step pipeline.  Operands of step t live in register set t & 1: while the matrix
+  // cores work on set t & 1, the same wave reads the next A fragments from LDS, turns the next
+  // packed weights into set (t + 1) & 1 and refills their ring slot.  One barrier per chunk,
+  // ahead of the MFMAs of the chunk's last step.
+  u32x4 bq[2][4];
+  bf16x8 af[2][2];
+  f32x4 acc_g[2][4], acc_x[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    acc_x[mt] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_g[mt][i] = {0.f, 0.f, 0.f, 0.f};
+  }
+  // (q >> 4w) & 0x000F000F | 0x43004300 as shift + v_and_or_b32: the mask rides in an SGPR and the
+  // exponent pattern in a VGPR (two 32-bit constants do not fit one instruction, and left to
+  // itself the compiler spends three instructions per word).
+  uint32_t exp_pattern = 0x43004300u;
+  asm volatile("" : "+v"(exp_pattern));
+  auto dequant = [&](const u32x4 (&q)[QL], u32x4 (&b)[4]) {
+    if constexpr (BITS == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t sh = w == 0 ? q[0][i] : q[0][i] >> (4 * w);
+          asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(b[i][w]) : "v"(sh), "s"(0x000F000Fu), "v"(exp_pattern));
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t lohi[2] = {q[0][i], q[QL - 1][i]};
+#pragma unroll
+        for (int hw = 0; hw < 2; ++hw) {
+          const float f0 = static_cast<float>(lohi[hw] & 0xffu);
+          const float f1 = static_cast<float>((lohi[hw] >> 8) & 0xffu);
+          const float f2 = static_cast<float>((lohi[hw] >> 16) & 0xffu);
+          const float f3 = static_cast<float>(lohi[hw] >> 24);
+          // integers <= 255 are exact in bf16: keep the high halves
+          b[i][2 * hw] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+          b[i][2 * hw + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
+        }
+      }
+    }
+  };
+  auto read_af = [&](int buf, int step, bf16x8 (&f)[2]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+      f[mt] = as_frag(*reinterpret_cast<const u32x4*>(smem + buf * 2 * kXBuf + afrag_off + 16 * mt * kXPitch + 64 * step));
+  };
+  // Half-dequantisation: B fragments i0, i0 + 1 of the four.
+  auto dequant2 = [&](const u32x4 (&q)[QL], u32x4 (&b)[4], int i0) {
+    u32x4 full[4];
+    dequant(q, full);
+    b[i0] = full[i0];
+    b[i0 + 1] = full[i0 + 1];
+  };
+  // Scalar FMAs on purpose: beside MFMAs a packed fp32 FMA costs several times its issue slot.
+  float pend_sc[4] = {0.f, 0.f, 0.f, 0.f}, pend_nzs[4] = {0.f, 0.f, 0.f, 0.f};   // s and -s * (c + z)
+  auto epilogue = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = acc_tot[mt][i][r];
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(pend_sc[i]), "v"(acc_g[mt][i][r]));
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(pend_nzs[i]), "v"(acc_x[mt][r]));
+        acc_tot[mt][i][r] = t;
+      }
+  };
+
+  // A step is two scheduling blocks the compiler cannot move code across (left alone it sinks
+  // the ring refills to the end of the chunk and the ring runs dry):
+  //   A: LDS reads of the next A fragments, ring refill of the slot this step's operands came
+  //      from, the 5 MFMAs of row tile 0, first half of the next step's weights, and the scales of
+  //      row tile 1 of a group that ended with the previous step;
+  //   B: the 5 MFMAs of row tile 1, second half of the weights, and at a group's end its
+  //      scales and zeros and their application to row tile 0.
+  // One barrier per chunk, ahead of the last step's block A.
+  auto do_chunk = [&](int ci, auto parity) {
+    constexpr int PAR = decltype(parity)::value;
+    const bool real = 2 * ci + kh < nch;
+    static_for<0, 4>([&](auto sc_) {
+      constexpr int S = decltype(sc_)::value;
+      constexpr int SP = S & 1;                       // operand set of this step
+      constexpr int GQ = S / KSTEPS;                  // group within the chunk
+      constexpr bool kFirst = S % KSTEPS == 0, kLast = S % KSTEPS == KSTEPS - 1;
+      constexpr int slot = (4 * PAR + S) % kRing, nslot = (4 * PAR + S + 1) % kRing;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (S == 3) {
+        write_x(PAR ^ 1, xs);
+        load_x(ci + 2, xs);
+        __syncthreads();
+        read_af(PAR ^ 1, 0, af[SP ^ 1]);
+      } else {
+        read_af(PAR, S + 1, af[SP ^ 1]);
+      }
+      if constexpr (S == 0) load_params(ci + 1, sraw[PAR ^ 1], zraw[PAR ^ 1]);
+      load_w(4 * ci + S + kRing, qring[slot]);
+      if constexpr (kFirst) epilogue(1);              // the previous group's row tile 1, before its sums are overwritten
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc_g[0][i] = mfma16(af[SP][0], as_frag(bq[SP][i]), kFirst ? zero : acc_g[0][i]);
+      acc_x[0] = mfma16(af[SP][0], ones, kFirst ? zero : acc_x[0]);
+      dequant2(qring[nslot], bq[SP ^ 1], 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc_g[1][i] = mfma16(af[SP][1], as_frag(bq[SP][i]), kFirst ? zero : acc_g[1][i]);
+      acc_x[1] = mfma16(af[SP][1], ones, kFirst ? zero : acc_x[1]);
+      dequant2(qring[nslot], bq[SP ^ 1], 2);
+      if constexpr (kLast) {
+        // s * (sum x (c + q) - (c + z) * sum x); zero scale for a padding chunk
+        const uint32_t zw = zraw[PAR][GQ];
+        const int first = col0 % PACK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint16_t raw = static_cast<uint16_t>(sraw[PAR][GQ][i >> 1] >> (16 * (i & 1)));
+          const float sv = a.scales_dtype == HYMETA_F16 ? static_cast<float>(__builtin_bit_cast(_Float16, raw)) : bf2f(raw);
+          const float scl = real ? sv : 0.f;
+          const uint32_t z = (zw >> (BITS * (first + i))) & ((1u << BITS) - 1u);
+          const float zf = static_cast<float>(z + a.zero_offset) + (BITS == 4 ? 128.f : 0.f);
+          pend_sc[i] = scl;
+          pend_nzs[i] = -scl * zf;
+        }
+        epilogue(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  load_x(0, xs);
+#pragma unroll
+  for (int p = 0; p < kRing; ++p) load_w(p, qring[p]);
+  load_params(0, sraw[0], zraw[0]);
+  write_x(0, xs);
+  load_x(1, xs);
+  __syncthreads();
+  read_af(0, 0, af[0]);
+  dequant(qring[0], bq[0]);
+  const int nchp = (nrounds + 1) & ~1;
+  for (int ci = 0; ci < nchp; ci += 2) {
+    do_chunk(ci, std::integral_constant<int, 0>{});
+    do_chunk(ci + 1, std::integral_constant<int, 1>{});
+  }
+  epilogue(1);   // row tile 1 of the last group
+
+  // ---- the two K halves meet in LDS: [8 accumulator quads][4 waves][64 lanes] x 16 bytes
+  __syncthreads();
+  if (kh == 1) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(smem + (((mt * 4 + i) * 4 + (wave & 3)) * 64 + lane) * 16) = acc_tot[mt][i];
+  }
+  __syncthreads();
+  const bool owner = kh == 0;
+  if (owner) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc_tot[mt][i] += *reinterpret_cast<const f32x4*>(smem + (((mt * 4 + i) * 4 + (wave & 3)) * 64 + lane) * 16);
+  }
+
+  // ---- acc_tot[mt][i][r] = C[m0 + 32 wr + 16 mt + 4c + r][col0 + i]: 16 lanes x 4 columns per row
+  if (splits > 1) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int grow = m0 + 32 * wr + 16 * mt + 4 * c + r;
+        if (owner && grow < a.M)
+          *reinterpret_cast<f32x4*>(slabs + (static_cast<int64_t>(split) * a.M + grow) * a.N + col0) =
+              f32x4{acc_tot[mt][0][r], acc_tot[mt][1][r], acc_tot[mt][2][r], acc_tot[mt][3][r]};
+      }
+    if (!last_arriver(counters + blockIdx.y * gridDim.x + blockIdx.x, splits, reinterpret_cast<int*>(smem))) return;
+    if (!owner) return;
+    // the last arriver sums the slabs, two slices' loads in flight at a time
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc_tot[mt][i] = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < splits; sp += 2) {
+      const int sp1 = min(sp + 1, splits - 1);
+      const float w1 = sp + 1 < splits ? 1.f : 0.f;
+      f32x4 va[2][4], vb[2][4];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int grow = min(m0 + 32 * wr + 16 * mt + 4 * c + r, a.M - 1);
+          va[mt][r] = *(const __attribute__((address_space(1))) f32x4*)(slabs + (static_cast<int64_t>(sp) * a.M + grow) * a.N + col0);
+          vb[mt][r] = *(const __attribute__((address_space(1))) f32x4*)(slabs + (static_cast<int64_t>(sp1) * a.M + grow) * a.N + col0);
+        }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc_tot[mt][i][r] += va[mt][r][i] + w1 * vb[mt][r][i];
+    }
+  }
+  if (!owner) return;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias != nullptr) {
+    const u32x2 bw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.bias) + col0);
+    bias = f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int grow = m0 + 32 * wr + 16 * mt + 4 * c + r;
+      if (grow >= a.M) continue;
+      const u32x2 o = {pack_bf16x2(acc_tot[mt][0][r] + bias[0], acc_tot[mt][1][r] + bias[1]),
+                       pack_bf16x2(acc_tot[mt][2][r] + bias[2], acc_tot[mt][3][r] + bias[3])};
+      *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(grow) * a.out_stride_m + col0) = o;
+    }
+}
+
 // Whole-matrix dequantisation W[k][n] = bf16(s * (q - z)) for the prefill regime, where a library
 // bf16 GEMM on the expanded weights beats re-dequantising them per 64-row block.
 // Thread = one packed word row x 4 columns: 16-byte read, PACK rows of 8-byte writes.
@@ -470,8 +805,19 @@ static int64_t gptq_tiles(int M, int N) {
   return static_cast<int64_t>(N / kColsPerBlock) * ((M + 16 * mt - 1) / (16 * mt));
 }
 
+static bool gptq_use_wide(int M, int K, int N) { return M > 32 && K % kChunkK == 0 && N % kWideCols == 0; }
+
 extern "C" int hymeta_gptq_gemm_split_k(int32_t M, int32_t K, int32_t N, int32_t group_size) {
   if (M <= 0 || K <= 0 || N <= 0 || group_size <= 0) return 1;
+  if (gptq_use_wide(M, K, N)) {
+    // one workgroup (8 waves) per compute unit; a slice keeps at least two rounds of two chunks
+    const int64_t tiles = static_cast<int64_t>(N / kWideCols) * ((M + 63) / 64);
+    int64_t want = 256 / tiles;
+    const int64_t cap = K / kChunkK / 4 > 1 ? K / kChunkK / 4 : 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    return static_cast<int>(want);
+  }
   int64_t tiles = gptq_tiles(M, N);
   if (tiles < 1) tiles = 1;
   const int G = K / group_size;
@@ -506,21 +852,38 @@ extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream
   if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.qweight) | reinterpret_cast<uintptr_t>(a.out) |
        reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.workspace)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(a.scales) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  const bool wide = gptq_use_wide(a.M, a.K, a.N);
   const int G = a.K / a.group_size;
+  const int units = wide ? a.K / kChunkK : G;       // what a K slice is counted in
   int splits = a.split_k > 0 ? a.split_k : hymeta_gptq_gemm_split_k(a.M, a.K, a.N, a.group_size);
-  if (splits > G) splits = G;
+  if (splits > units) splits = units;
   if (splits > 1) {
     if (a.workspace == nullptr || a.workspace_bytes < hymeta_gptq_gemm_workspace_bytes(a.M, a.N, splits)) return HYMETA_ERR_WORKSPACE;
   }
   const int requested = splits;
-  const int gps = (G + splits - 1) / splits;
-  splits = (G + gps - 1) / gps;
+  const int gps = (units + splits - 1) / splits;
+  splits = (units + gps - 1) / gps;
   hipStream_t s = begin_launches(stream);
   // workspace = [slabs fp32 [requested splits][M][N]][ticket counters, zeroed per call]
   float* slabs = a.workspace;
   int* counters = reinterpret_cast<int*>(reinterpret_cast<char*>(a.workspace) + static_cast<size_t>(requested) * a.M * a.N * sizeof(float));
   if (splits > 1 && hipMemsetAsync(counters, 0, static_cast<size_t>(gptq_tiles(a.M, a.N)) * sizeof(int), s) != hipSuccess)
     return HYMETA_ERR_LAUNCH;
+  if (wide) {
+    dim3 grid(a.N / kWideCols, (a.M + 63) / 64, splits), block(kWideThreads);
+#define HYMETA_LAUNCH_WIDE(B, KS) hipLaunchKernelGGL((gptq_gemm_wide_kernel<B, KS>), grid, block, 0, s, a, splits, gps, slabs, counters)
+#define HYMETA_LAUNCH_WIDE_KS(B)                     \
+  do {                                               \
+    if (a.group_size == 128) HYMETA_LAUNCH_WIDE(B, 4); \
+    else if (a.group_size == 64) HYMETA_LAUNCH_WIDE(B, 2); \
+    else HYMETA_LAUNCH_WIDE(B, 1);                   \
+  } while (0)
+    if (a.bits == 4) HYMETA_LAUNCH_WIDE_KS(4); else HYMETA_LAUNCH_WIDE_KS(8);
+#undef HYMETA_LAUNCH_WIDE_KS
+#undef HYMETA_LAUNCH_WIDE
+    return launch_status();
+  }
   const int mt = mt_for(a.M);
   dim3 grid(a.N / kColsPerBlock, (a.M + 16 * mt - 1) / (16 * mt), splits), block(256);
   const size_t lds = static_cast<size_t>(4) * 16 * mt * kColsPerBlock * sizeof(float);
