@@ -453,9 +453,13 @@ int hymeta_add_rmsnorm(const hymeta_add_rmsnorm_args* args, hymeta_stream_t stre
  *   scales  [K / group, N]  fp16 or bf16;
  *   w[k, n] = scales[k/group, n] * (q[k, n] - (qzeros[k/group, n] + zero_offset)).
  * Rows are in natural order (g_idx[k] = k / group; act-order checkpoints are not supported).
- * Split-K: when split_k > 1 the partial tiles meet in `workspace`
- * (hymeta_gptq_gemm_workspace_bytes: fp32 slabs [split_k, M, N] + ticket counters);
- * the last workgroup to reach an output tile sums its slabs and writes it.
+ * Split-K: partial tiles meet in `workspace` (ticket counters + fp32 slabs); the last workgroup
+ * to reach an output tile sums its slabs and writes it.  split_k <= 0 lets the library choose
+ * the decomposition (K slices for few output tiles; for more 64 x 128 tiles than compute units,
+ * whole tiles round by round with the remainder cut in K); its workspace,
+ * hymeta_gptq_gemm_workspace_bytes(M, N, 0), is a bound that holds for every K.  Without a
+ * workspace the library runs unsplit.  split_k > 1 forces that many slices and needs
+ * hymeta_gptq_gemm_workspace_bytes(M, N, split_k) bytes.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_gptq_gemm_args {
   const void* x;          /* bf16 [M, K] */
@@ -464,14 +468,14 @@ typedef struct hymeta_gptq_gemm_args {
   const void* scales;
   const void* bias;       /* bf16 [N] or NULL */
   void* out;              /* bf16 [M, N] */
-  float* workspace;       /* hymeta_gptq_gemm_workspace_bytes() bytes, or NULL when split_k == 1 */
+  float* workspace;       /* hymeta_gptq_gemm_workspace_bytes() bytes, or NULL (then unsplit, or an error if split_k > 1) */
   size_t workspace_bytes;
   int32_t M, K, N;
   int32_t bits;           /* 4 or 8 */
   int32_t group_size;     /* 32, 64 or 128 */
   int32_t scales_dtype;   /* HYMETA_F16 or HYMETA_BF16 */
   int32_t zero_offset;    /* 1 for the v1 format, 0 for v2 */
-  int32_t split_k;        /* <= 0: library chooses; pass the result of hymeta_gptq_gemm_split_k to size the workspace */
+  int32_t split_k;        /* <= 0: library chooses (workspace sized with split_k = 0) */
   int64_t x_stride_m, out_stride_m;
 } hymeta_gptq_gemm_args;
 

@@ -316,11 +316,47 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// grid = (N / 128, ceil(M / 64), splits)
+// How the 64 x 128 output tiles are dealt to workgroups.
+//   mode 0: grid (tiles, splits): one (tile, K slice) per workgroup; slices meet in slabs laid out
+//           [split][M][N].
+//   mode 1: more tiles than compute units: grid (wgs); workgroup w takes the whole tiles
+//           w, w + wgs, ... of the first full_rounds * wgs tiles, and the `left` tiles that remain
+//           are cut into left_slices K slices each, one per workgroup, so that the last round costs
+//           1 / left_slices of a tile instead of a whole one; their slabs are compact:
+//           [left tile][slice][64][128].
+struct WidePlan {
+  int mode, tiles_n, splits, cps, wgs, full_rounds, left, left_slices, left_cps;
+};
+
 template <int BITS, int KSTEPS>
-__global__ __launch_bounds__(kWideThreads) void gptq_gemm_wide_kernel(hymeta_gptq_gemm_args a, int splits, int chunks_per_split,
+__global__ __launch_bounds__(kWideThreads) void gptq_gemm_wide_kernel(hymeta_gptq_gemm_args a, WidePlan plan,
                                                                       float* slabs, int* counters) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * kXBuf];   // [buffer][K half][row][pitch]
+  const int njobs = plan.mode == 0 ? 1 : plan.full_rounds + (static_cast<int>(blockIdx.x) < plan.left * plan.left_slices ? 1 : 0);
+  for (int job = 0; job < njobs; ++job) {
+  int tile, split, splits, cps;
+  float* sbase;                      // this tile's slab of slice 0
+  int64_t s_split_stride, s_row_stride;
+  if (plan.mode == 0) {
+    tile = blockIdx.x, split = blockIdx.y, splits = plan.splits, cps = plan.cps;
+  } else if (job < plan.full_rounds) {
+    tile = blockIdx.x + plan.wgs * job, split = 0, splits = 1, cps = a.K / kChunkK;
+  } else {
+    tile = plan.wgs * plan.full_rounds + static_cast<int>(blockIdx.x) % plan.left;
+    split = blockIdx.x / plan.left, cps = plan.left_cps;
+    splits = (a.K / kChunkK + cps - 1) / cps;
+  }
+  const int nb = tile % plan.tiles_n, mb = tile / plan.tiles_n;
+  if (plan.mode == 0) {
+    sbase = slabs + static_cast<int64_t>(mb) * 64 * a.N + nb * kWideCols;
+    s_split_stride = static_cast<int64_t>(a.M) * a.N, s_row_stride = a.N;
+  } else {
+    sbase = slabs + static_cast<int64_t>(tile - plan.wgs * plan.full_rounds) * plan.left_slices * (64 * kWideCols);
+    s_split_stride = 64 * kWideCols, s_row_stride = kWideCols;
+  }
+  const bool active = split < splits;          // a slice past the end of K (mode 1, uneven cut) has nothing to do
+  if (job > 0) __syncthreads();                // the previous tile's last LDS reads
+  if (active) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -328,12 +364,12 @@ __global__ __launch_bounds__(kWideThreads) void gptq_gemm_wide_kernel(hymeta_gpt
   // 8 waves = 2 K halves x 2 row halves x 2 column halves: in every round of two chunks the waves
   // of K half kh work on chunk 2 round + kh
   const int kh = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
-  const int m0 = blockIdx.y * 64;
-  const int split = blockIdx.z;
-  const int ch_lo = split * chunks_per_split;
-  const int ch_hi = min(a.K / kChunkK, ch_lo + chunks_per_split);
-  const int nch = ch_hi - ch_lo;                  // >= 1 (host)
-  const int col0 = blockIdx.x * kWideCols + wc * 64 + 4 * n;
+  const int m0 = mb * 64;
+  const int ch_lo = split * cps;
+  const int ch_hi = min(a.K / kChunkK, ch_lo + cps);
+  const int nch = ch_hi - ch_lo;                  // >= 1
+  const int lcol0 = wc * 64 + 4 * n;              // column inside the tile
+  const int col0 = nb * kWideCols + lcol0;
   constexpr int PACK = 32 / BITS;
   constexpr int QL = BITS == 4 ? 1 : 2;
   constexpr int GPC = 4 / KSTEPS;                 // groups per chunk
@@ -543,10 +579,9 @@ __global__ __launch_bounds__(kWideThreads) void gptq_gemm_wide_kernel(hymeta_gpt
   __syncthreads();
   read_af(0, 0, af[0]);
   dequant(qring[0], bq[0]);
-  const int nchp = (nrounds + 1) & ~1;
-  for (int ci = 0; ci < nchp; ci += 2) {
+  for (int ci = 0; ci < nrounds; ci += 2) {
     do_chunk(ci, std::integral_constant<int, 0>{});
-    do_chunk(ci + 1, std::integral_constant<int, 1>{});
+    if (ci + 1 < nrounds) do_chunk(ci + 1, std::integral_constant<int, 1>{});
   }
   epilogue(1);   // row tile 1 of the last group
 
@@ -561,6 +596,7 @@ __global__ __launch_bounds__(kWideThreads) void gptq_gemm_wide_kernel(hymeta_gpt
   }
   __syncthreads();
   const bool owner = kh == 0;
+  bool writer = owner;
   if (owner) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -575,14 +611,14 @@ __global__ __launch_bounds__(kWideThreads) void gptq_gemm_wide_kernel(hymeta_gpt
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int grow = m0 + 32 * wr + 16 * mt + 4 * c + r;
-        if (owner && grow < a.M)
-          *reinterpret_cast<f32x4*>(slabs + (static_cast<int64_t>(split) * a.M + grow) * a.N + col0) =
+        const int lrow = 32 * wr + 16 * mt + 4 * c + r;
+        if (owner && m0 + lrow < a.M)
+          *reinterpret_cast<f32x4*>(sbase + split * s_split_stride + lrow * s_row_stride + lcol0) =
               f32x4{acc_tot[mt][0][r], acc_tot[mt][1][r], acc_tot[mt][2][r], acc_tot[mt][3][r]};
       }
-    if (!last_arriver(counters + blockIdx.y * gridDim.x + blockIdx.x, splits, reinterpret_cast<int*>(smem))) return;
-    if (!owner) return;
+    writer = last_arriver(counters + tile, splits, reinterpret_cast<int*>(smem)) && owner;
     // the last arriver sums the slabs, two slices' loads in flight at a time
+    if (writer) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -595,9 +631,9 @@ __global__ __launch_bounds__(kWideThreads) void gptq_gemm_wide_kernel(hymeta_gpt
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int grow = min(m0 + 32 * wr + 16 * mt + 4 * c + r, a.M - 1);
-          va[mt][r] = *(const __attribute__((address_space(1))) f32x4*)(slabs + (static_cast<int64_t>(sp) * a.M + grow) * a.N + col0);
-          vb[mt][r] = *(const __attribute__((address_space(1))) f32x4*)(slabs + (static_cast<int64_t>(sp1) * a.M + grow) * a.N + col0);
+          const int lrow = min(32 * wr + 16 * mt + 4 * c + r, a.M - 1 - m0);
+          va[mt][r] = *(const __attribute__((address_space(1))) f32x4*)(sbase + sp * s_split_stride + lrow * s_row_stride + lcol0);
+          vb[mt][r] = *(const __attribute__((address_space(1))) f32x4*)(sbase + sp1 * s_split_stride + lrow * s_row_stride + lcol0);
         }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -606,8 +642,9 @@ __global__ __launch_bounds__(kWideThreads) void gptq_gemm_wide_kernel(hymeta_gpt
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc_tot[mt][i][r] += va[mt][r][i] + w1 * vb[mt][r][i];
     }
+    }
   }
-  if (!owner) return;
+  if (writer) {
   f32x4 bias = {0.f, 0.f, 0.f, 0.f};
   if (a.bias != nullptr) {
     const u32x2 bw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.bias) + col0);
@@ -623,6 +660,9 @@ __global__ __launch_bounds__(kWideThreads) void gptq_gemm_wide_kernel(hymeta_gpt
                        pack_bf16x2(acc_tot[mt][2][r] + bias[2], acc_tot[mt][3][r] + bias[3])};
       *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(grow) * a.out_stride_m + col0) = o;
     }
+  }
+  }   // active
+  }   // jobs
 }
 
 // Whole-matrix dequantisation W[k][n] = bf16(s * (q - z)) for the prefill regime, where a library
@@ -805,15 +845,18 @@ static int64_t gptq_tiles(int M, int N) {
   return static_cast<int64_t>(N / kColsPerBlock) * ((M + 16 * mt - 1) / (16 * mt));
 }
 
+constexpr int kMaxPairs = 256;    // (tile, K slice) pairs the library's own choice of decomposition ever creates
+
 static bool gptq_use_wide(int M, int K, int N) { return M > 32 && K % kChunkK == 0 && N % kWideCols == 0; }
 
 extern "C" int hymeta_gptq_gemm_split_k(int32_t M, int32_t K, int32_t N, int32_t group_size) {
   if (M <= 0 || K <= 0 || N <= 0 || group_size <= 0) return 1;
   if (gptq_use_wide(M, K, N)) {
-    // one workgroup (8 waves) per compute unit; a slice keeps at least two rounds of two chunks
+    // one workgroup (8 waves) per compute unit; a slice keeps at least seven chunks (measured:
+    // below that the slab hand-off costs more than the shorter slice saves)
     const int64_t tiles = static_cast<int64_t>(N / kWideCols) * ((M + 63) / 64);
     int64_t want = 256 / tiles;
-    const int64_t cap = K / kChunkK / 4 > 1 ? K / kChunkK / 4 : 1;
+    const int64_t cap = K / kChunkK / 7 > 1 ? K / kChunkK / 7 : 1;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     return static_cast<int>(want);
@@ -830,11 +873,28 @@ extern "C" int hymeta_gptq_gemm_split_k(int32_t M, int32_t K, int32_t N, int32_t
   return static_cast<int>(want);
 }
 
+static size_t gptq_counter_bytes(int M, int N) {
+  return (static_cast<size_t>(gptq_tiles(M, N)) * sizeof(int) + 255) / 256 * 256;
+}
+
+// workspace = [ticket counters, zeroed per call][fp32 slabs]
 extern "C" size_t hymeta_gptq_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
-  if (M <= 0 || N <= 0 || split_k <= 1) return 0;
-  const size_t slabs = static_cast<size_t>(split_k) * M * N * sizeof(float);
-  const size_t counters = (static_cast<size_t>(gptq_tiles(M, N)) * sizeof(int) + 255) / 256 * 256;
-  return slabs + counters;
+  if (M <= 0 || N <= 0 || split_k == 1) return 0;
+  // split_k <= 0 (the library chooses): never more (tile, slice) pairs than kMaxPairs, whatever K is
+  if (split_k <= 0) return gptq_counter_bytes(M, N) + static_cast<size_t>(kMaxPairs) * 64 * kWideCols * sizeof(float);
+  return gptq_counter_bytes(M, N) + static_cast<size_t>(split_k) * M * N * sizeof(float);
+}
+
+static int compute_units(void) {
+  static int cached = 0;
+  if (cached == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cached = n;
+    else
+      cached = 256;
+  }
+  return cached;
 }
 
 extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream_t stream) {
@@ -856,23 +916,43 @@ extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream
   const bool wide = gptq_use_wide(a.M, a.K, a.N);
   const int G = a.K / a.group_size;
   const int units = wide ? a.K / kChunkK : G;       // what a K slice is counted in
-  int splits = a.split_k > 0 ? a.split_k : hymeta_gptq_gemm_split_k(a.M, a.K, a.N, a.group_size);
+  const bool autosplit = a.split_k <= 0;
+  int splits = autosplit ? hymeta_gptq_gemm_split_k(a.M, a.K, a.N, a.group_size) : a.split_k;
+  if (autosplit && a.workspace == nullptr) splits = 1;
   if (splits > units) splits = units;
-  if (splits > 1) {
-    if (a.workspace == nullptr || a.workspace_bytes < hymeta_gptq_gemm_workspace_bytes(a.M, a.N, splits)) return HYMETA_ERR_WORKSPACE;
-  }
-  const int requested = splits;
+  const size_t counter_bytes = gptq_counter_bytes(a.M, a.N);
+  if (a.workspace != nullptr && a.workspace_bytes < hymeta_gptq_gemm_workspace_bytes(a.M, a.N, autosplit ? 0 : splits))
+    return HYMETA_ERR_WORKSPACE;
+  if (splits > 1 && a.workspace == nullptr) return HYMETA_ERR_WORKSPACE;
   const int gps = (units + splits - 1) / splits;
   splits = (units + gps - 1) / gps;
+  // more 128-column tiles than compute units: whole tiles round by round, the remainder cut in K
+  WidePlan plan = {0, a.N / kWideCols, splits, gps, 0, 0, 0, 0, 0};
+  if (wide && autosplit && a.workspace != nullptr) {
+    const int wgs = compute_units();
+    const int tiles = plan.tiles_n * ((a.M + 63) / 64);
+    if (tiles > wgs && wgs <= kMaxPairs) {
+      plan.mode = 1, plan.wgs = wgs;
+      plan.full_rounds = tiles / wgs, plan.left = tiles % wgs;
+      if (plan.left > 0) {
+        int slices = wgs / plan.left;
+        const int cap = units / 4 > 1 ? units / 4 : 1;      // a slice keeps two rounds of two chunks
+        if (slices > cap) slices = cap;
+        plan.left_cps = (units + slices - 1) / slices;
+        plan.left_slices = (units + plan.left_cps - 1) / plan.left_cps;
+      }
+    }
+  }
+  const bool tickets = plan.mode == 1 ? plan.left_slices > 1 : splits > 1;
   hipStream_t s = begin_launches(stream);
-  // workspace = [slabs fp32 [requested splits][M][N]][ticket counters, zeroed per call]
-  float* slabs = a.workspace;
-  int* counters = reinterpret_cast<int*>(reinterpret_cast<char*>(a.workspace) + static_cast<size_t>(requested) * a.M * a.N * sizeof(float));
-  if (splits > 1 && hipMemsetAsync(counters, 0, static_cast<size_t>(gptq_tiles(a.M, a.N)) * sizeof(int), s) != hipSuccess)
+  int* counters = reinterpret_cast<int*>(a.workspace);
+  float* slabs = a.workspace == nullptr ? nullptr : reinterpret_cast<float*>(reinterpret_cast<char*>(a.workspace) + counter_bytes);
+  if (tickets && hipMemsetAsync(counters, 0, static_cast<size_t>(gptq_tiles(a.M, a.N)) * sizeof(int), s) != hipSuccess)
     return HYMETA_ERR_LAUNCH;
   if (wide) {
-    dim3 grid(a.N / kWideCols, (a.M + 63) / 64, splits), block(kWideThreads);
-#define HYMETA_LAUNCH_WIDE(B, KS) hipLaunchKernelGGL((gptq_gemm_wide_kernel<B, KS>), grid, block, 0, s, a, splits, gps, slabs, counters)
+    dim3 grid(plan.tiles_n * ((a.M + 63) / 64), splits), block(kWideThreads);
+    if (plan.mode == 1) grid = dim3(plan.wgs);
+#define HYMETA_LAUNCH_WIDE(B, KS) hipLaunchKernelGGL((gptq_gemm_wide_kernel<B, KS>), grid, block, 0, s, a, plan, slabs, counters)
 #define HYMETA_LAUNCH_WIDE_KS(B)                     \
   do {                                               \
     if (a.group_size == 128) HYMETA_LAUNCH_WIDE(B, 4); \
@@ -935,7 +1015,9 @@ extern "C" int hymeta_w8a8_gemm_split_k(int32_t M, int32_t K, int32_t N) {
 }
 
 extern "C" size_t hymeta_w8a8_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
-  return hymeta_gptq_gemm_workspace_bytes(M, N, split_k);   // same layout: 4-byte slabs + ticket counters
+  if (M <= 0 || N <= 0 || split_k <= 1) return 0;
+  // [int32 slabs [split_k][M][N]][ticket counters]
+  return static_cast<size_t>(split_k) * M * N * sizeof(int) + gptq_counter_bytes(M, N);
 }
 
 extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream) {

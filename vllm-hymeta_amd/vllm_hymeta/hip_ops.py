@@ -563,17 +563,16 @@ def gptq_gemm(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scal
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
     _require(out.shape == (M, N) and out.dtype == torch.bfloat16 and out.stride(1) == 1, "out must be bf16 [M, N]")
     lib = _C.load()
-    if split_k <= 0:
-        split_k = lib.hymeta_gptq_gemm_split_k(M, K, N, group_size)
     a = _C.GptqGemmArgs()
-    ws = None
-    if split_k > 1:
-        ws = _workspace(x.device, int(lib.hymeta_gptq_gemm_workspace_bytes(M, N, split_k)), "gptq_gemm")
+    # split_k <= 0: the library chooses how to cut the work; its workspace bound does not depend on K
+    need = int(lib.hymeta_gptq_gemm_workspace_bytes(M, N, max(split_k, 0)))
+    if need:
+        ws = _workspace(x.device, need, "gptq_gemm")
         a.workspace, a.workspace_bytes = _p(ws), ws.numel()
     a.x, a.qweight, a.qzeros, a.scales, a.bias, a.out = _p(x), _p(qweight), _p(qzeros), _p(scales), _p(bias), _p(out)
     a.M, a.K, a.N, a.bits, a.group_size = M, K, N, bits, group_size
     a.scales_dtype = _C.HYMETA_F16 if scales.dtype == torch.float16 else _C.HYMETA_BF16
-    a.zero_offset, a.split_k = zero_offset, split_k
+    a.zero_offset, a.split_k = zero_offset, max(split_k, 0)
     a.x_stride_m, a.out_stride_m = x.stride(0), out.stride(0)
     _C.check(lib.hymeta_gptq_gemm(C.byref(a), _stream(x)), "hymeta_gptq_gemm")
     return out
