@@ -177,43 +177,85 @@ __global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefil
   // they are committed), so nothing has to wait for them before the tile's compute.
   u32x4 kreg[2], vreg[2];
   bool rok[2] = {false, false};
+  // Un-paged keys: the thread's two row pointers walk down the tile sequence (one 64-bit add per
+  // pointer and tile); they are rebuilt only where the sequence of tiles changes tensor (first
+  // tile, first real tile after the meta tiles).  klast / vlast: the last valid row of the tensor
+  // being walked, what a row past the end reads instead.
+  const uint16_t* kptr[2] = {nullptr, nullptr};
+  const uint16_t* vptr[2] = {nullptr, nullptr};
+  const uint16_t* klast = nullptr;
+  const uint16_t* vlast = nullptr;
+  int64_t kstep = 0, vstep = 0;
+  int prow = 0, plimit = 0;            // row index of kptr[0] in its tensor, and that tensor's row count
   auto issue = [&](int tile) {
+    if constexpr (PAGED) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = sr + 32 * i;
-      const uint16_t* kp;
-      const uint16_t* vp;
-      if (tile < meta_tiles) {
-        const int idx = tile * kTileK + r;
-        rok[i] = idx < M;
-        const int64_t off = static_cast<int64_t>(min(idx, M - 1)) * a.meta_stride_t + static_cast<int64_t>(kvh) * a.meta_stride_h + 8 * sc;
-        kp = reinterpret_cast<const uint16_t*>(a.meta_key) + off;
-        vp = reinterpret_cast<const uint16_t*>(a.meta_value) + off;
-      } else {
-        const int p_raw = (T_lo + tile - meta_tiles) * kTileK + r;
-        rok[i] = p_raw < Lk;   // rows past the sequence end: next sequence, outside the tensor, or stale cache
-        const int p = min(p_raw, Lk - 1);
-        if constexpr (PAGED) {
+      for (int i = 0; i < 2; ++i) {
+        const int r = sr + 32 * i;
+        const uint16_t* kp;
+        const uint16_t* vp;
+        if (tile < meta_tiles) {
+          const int idx = tile * kTileK + r;
+          rok[i] = idx < M;
+          const int64_t off = static_cast<int64_t>(min(idx, M - 1)) * a.meta_stride_t + static_cast<int64_t>(kvh) * a.meta_stride_h + 8 * sc;
+          kp = reinterpret_cast<const uint16_t*>(a.meta_key) + off;
+          vp = reinterpret_cast<const uint16_t*>(a.meta_value) + off;
+        } else {
+          const int p_raw = (T_lo + tile - meta_tiles) * kTileK + r;
+          rok[i] = p_raw < Lk;   // rows past the sequence end: stale cache
+          const int p = min(p_raw, Lk - 1);
           const int64_t off = static_cast<int64_t>(bt[p / a.block_size]) * a.cache_stride_block +
                               static_cast<int64_t>(p % a.block_size) * a.cache_stride_pos + 8 * sc;
           kp = kglob + off;
           vp = vglob + off;
-        } else {
-          kp = kglob + static_cast<int64_t>(p) * a.k_stride_t + 8 * sc;
-          vp = vglob + static_cast<int64_t>(p) * a.v_stride_t + 8 * sc;
         }
+        kreg[i] = ld16(kp);
+        vreg[i] = ld16(vp);
       }
-      kreg[i] = ld16(kp);
-      vreg[i] = ld16(vp);
+    } else {
+      if (tile == 0 || tile == meta_tiles) {       // workgroup-uniform, at most twice per workgroup
+        const bool meta = tile < meta_tiles;
+        const uint16_t* kb = meta ? reinterpret_cast<const uint16_t*>(a.meta_key) + static_cast<int64_t>(kvh) * a.meta_stride_h : kglob;
+        const uint16_t* vb = meta ? reinterpret_cast<const uint16_t*>(a.meta_value) + static_cast<int64_t>(kvh) * a.meta_stride_h : vglob;
+        const int64_t ks = meta ? a.meta_stride_t : a.k_stride_t, vs = meta ? a.meta_stride_t : a.v_stride_t;
+        plimit = meta ? M : Lk;
+        prow = (meta ? 0 : T_lo * kTileK) + sr;
+        kstep = ks * kTileK, vstep = vs * kTileK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          kptr[i] = kb + static_cast<int64_t>(prow + 32 * i) * ks + 8 * sc;
+          vptr[i] = vb + static_cast<int64_t>(prow + 32 * i) * vs + 8 * sc;
+        }
+        klast = kb + static_cast<int64_t>(plimit - 1) * ks + 8 * sc;
+        vlast = vb + static_cast<int64_t>(plimit - 1) * vs + 8 * sc;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        rok[i] = prow + 32 * i < plimit;           // rows past the end: next sequence, or outside the tensor
+        kreg[i] = ld16(rok[i] ? kptr[i] : klast);
+        vreg[i] = ld16(rok[i] ? vptr[i] : vlast);
+        kptr[i] += kstep;
+        vptr[i] += vstep;
+      }
+      prow += kTileK;
     }
   };
   auto commit = [&](int buf) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    if (__all(rok[0] && rok[1])) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = sr + 32 * i;
-      const u32x4 z = {0u, 0u, 0u, 0u};
-      st16(&sm.k[buf][r * kKPitch + 16 * (sc ^ (r & 15))], rok[i] ? kreg[i] : z);
-      st16(&sm.v[buf][r * kVPitch + 16 * sc], rok[i] ? vreg[i] : z);
+      for (int i = 0; i < 2; ++i) {
+        const int r = sr + 32 * i;
+        st16(&sm.k[buf][r * kKPitch + 16 * (sc ^ (r & 15))], kreg[i]);
+        st16(&sm.v[buf][r * kVPitch + 16 * sc], vreg[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = sr + 32 * i;
+        st16(&sm.k[buf][r * kKPitch + 16 * (sc ^ (r & 15))], rok[i] ? kreg[i] : z);
+        st16(&sm.v[buf][r * kVPitch + 16 * sc], rok[i] ? vreg[i] : z);
+      }
     }
   };
 
