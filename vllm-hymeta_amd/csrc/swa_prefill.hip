@@ -338,8 +338,12 @@ __global__ __launch_bounds__(kThreads) void swa_prefill_kernel(hymeta_swa_prefil
         tmax = max3(tmax, st[qt][2][3], st[qt][3][0]);
         tmax = max3(tmax, st[qt][3][1], st[qt][3][2]);
         tmax = max3(tmax, st[qt][3][3], st[qt][3][3]);
-        tmax = max3(tmax, __shfl_xor(tmax, 16), tmax);
-        const float m_new = max3(m_run[qt], tmax, __shfl_xor(tmax, 32));
+        // across the four 16-lane groups (the tile's other keys) with the two row-swap
+        // instructions: ALU latency on the tile's critical path instead of two LDS round trips
+        const auto h16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = max3(__uint_as_float(h16[0]), __uint_as_float(h16[1]), tmax);
+        const auto h32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        const float m_new = max3(m_run[qt], __uint_as_float(h32[0]), __uint_as_float(h32[1]));
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
         alpha[qt] = __builtin_amdgcn_exp2f((m_run[qt] - m_use) * scale_log2);
         const float ms = m_use * scale_log2;
