@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="skip the 32k prefill (TTFT) side measurement")
     ap.add_argument("--prefill-ctx", type=int, default=32768)
+    ap.add_argument("--no-model", action="store_true",
+                    help="skip the whole-model decode step (projections + MLP around the hot path) side measurement")
     return ap.parse_args()
 
 
@@ -175,6 +177,97 @@ def prefill_side_measurement(dev, L):
         "swa_prefill_tflops": round(4.0 * D * H * vis / (t_swa * 1e-3) / 1e12, 1),
         "prefill_tokens_per_s": round(L / ((N_GLA * t_gla + N_SWA * t_swa) * 1e-3), 1),
     }
+
+
+def model_decode_side_measurement(dev, w, B, s, quant):
+    """One decode token for every sequence through the WHOLE 28-layer stack (random-init Hymeta-7B
+    geometry): block norms, qkv / gate / output projections and the gated MLP around the same
+    attention kernels, caches and metadata as the timed hot path.  ``quant`` = "bf16" (library GEMMs)
+    or "gptq4" (GPTQ 4-bit, group 128, the fused dequant-GEMM).  Replayed from one HIP graph, as the
+    serving engine replays its decode step.  Outside the timed region; reported beside the value."""
+    from vllm_hymeta import _C, hip_ops
+    from vllm_hymeta.linear import HymetaLinear
+    from vllm_hymeta.model_for_7B.window_attention import rope_cos_sin_cache
+
+    hidden, inter, group = 3584, 18944, 128
+    g = torch.Generator(device="cpu")
+    g.manual_seed(2)
+
+    def linear(out_f, in_f, bias=False):
+        b = torch.zeros(out_f, dtype=torch.bfloat16, device=dev) if bias else None
+        if quant == "bf16":
+            wt = (torch.randn(out_f, in_f, device=dev, dtype=torch.float32) * in_f ** -0.5).to(torch.bfloat16)
+            return HymetaLinear.from_weight(wt, b)
+        qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // 8, out_f), dtype=torch.int32, device=dev)
+        qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // group, out_f // 8), dtype=torch.int32, device=dev)
+        sc = (torch.rand(in_f // group, out_f, device=dev) * (0.25 * in_f ** -0.5)).to(torch.float16)
+        return HymetaLinear.from_gptq(qw, qz, sc, 4, group, bias=b)
+
+    qkv_n = (H + 2 * HKV) * D
+    layers = []
+    for li in range(N_GLA + N_SWA):
+        lay = {"gla": li % 2 == 0, "qkv": linear(qkv_n, hidden, True), "o": linear(hidden, H * D),
+               "gate_up": linear(2 * inter, hidden), "down": linear(hidden, inter),
+               "n1": torch.ones(hidden, dtype=torch.bfloat16, device=dev),
+               "n2": torch.ones(hidden, dtype=torch.bfloat16, device=dev)}
+        if lay["gla"]:   # the rank-16 gate projection stays bf16 (hf_7B_model/gla_swa_gptq.py:18-24)
+            lay["gk0"] = (torch.randn(16, hidden, device=dev) * hidden ** -0.5).to(torch.bfloat16)
+            lay["gk1"] = (torch.randn(HKV * D, 16, device=dev) * 0.25).to(torch.bfloat16)
+            lay["gk1_b"] = torch.zeros(HKV * D, dtype=torch.bfloat16, device=dev)
+        layers.append(lay)
+    rope = rope_cos_sin_cache(D, 65536, 1e6, device=dev)
+    positions = w["seq_lens"][s].to(torch.int64) - 1
+    x0 = (torch.randn(B, hidden, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+
+    def step():
+        x = x0
+        i_gla = i_swa = 0
+        for lay in layers:
+            res = x.clone()
+            h = hip_ops.add_rmsnorm(x, lay["n1"], 1e-6)
+            qkv = lay["qkv"](h)
+            q, k, v = split_qkv(qkv, B)
+            if lay["gla"]:
+                gk = torch.nn.functional.linear(torch.nn.functional.linear(h, lay["gk0"]), lay["gk1"], lay["gk1_b"])
+                att = hip_ops.gla_decode(q, k, v, gk.view(B, HKV, D), w["state"][i_gla], w["slot_idx"],
+                                         gate_mode=_C.GATE_7B, out_norm_weight=w["g_norm"], out_norm_eps=1e-6)
+                i_gla += 1
+            else:
+                hip_ops.rope_neox_(positions, q, k, rope)
+                kv = w["kv"][i_swa]
+                att = hip_ops.meta_swa_paged_decode(q, kv[0], kv[1], w["seq_lens"][s], w["block_tables"],
+                                                    window_left=WINDOW, max_seqlen_k=w["max_seqlen_k"],
+                                                    num_splits=w["splits"], new_key=k, new_value=v,
+                                                    slot_mapping=w["slot_mapping"][s])
+                i_swa += 1
+            a_out = lay["o"](att.view(B, H * D))
+            n2 = hip_ops.add_rmsnorm(a_out, lay["n2"], 1e-6, residual=res)
+            x = res + lay["down"](hip_ops.silu_and_mul(lay["gate_up"](n2)))
+        return x
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        step()
+        with torch.cuda.graph(graph, stream=side):
+            step()
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    iters = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    wbytes = (N_GLA + N_SWA) * (qkv_n * hidden + hidden * H * D + 3 * inter * hidden) * (2.0 if quant == "bf16" else 0.5)
+    return {"ms_per_step": round(ms, 4), "tokens_per_s": round(B / (ms * 1e-3), 1),
+            "linear_weight_bytes": int(wbytes), "layers": N_GLA + N_SWA, "sequences": B}
 
 
 def cpu_baseline(args):
@@ -314,6 +407,8 @@ def main():
     }
     if world == 1 and not args.no_prefill:
         line["prefill"] = prefill_side_measurement(dev, args.prefill_ctx)
+    if world == 1 and not args.no_model:
+        line["model_decode"] = {q: model_decode_side_measurement(dev, w, B, total - 1, q) for q in ("bf16", "gptq4")}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(line), flush=True)
