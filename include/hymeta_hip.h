@@ -522,6 +522,16 @@ size_t hymeta_w8a8_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 
 int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream);
 
+/* The two ends of the same linear for prefill-sized M, where the host side puts a library int8
+ * GEMM (exact int32 sums) between them instead of the fused kernel, the choice vLLM's scaled_mm
+ * makes for the layers cited above:
+ *   hymeta_w8a8_quantize : x bf16 [M, K] -> xq int8 [M, K], x_scale fp32 [M]   (same arithmetic as above)
+ *   hymeta_w8a8_scale_out: acc int32 [M, N] -> out bf16 = acc * x_scale[m] * w_scale[n] + bias[n] */
+int hymeta_w8a8_quantize(const void* x, int8_t* xq, float* x_scale, int32_t M, int32_t K, int64_t x_stride_m,
+                         hymeta_stream_t stream);
+int hymeta_w8a8_scale_out(const int32_t* acc, const float* x_scale, const float* w_scale, const void* bias, void* out,
+                          int32_t M, int32_t N, int64_t acc_stride_m, int64_t out_stride_m, hymeta_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Sparse mixture-of-experts block (70B, 16 experts, top-1, shared expert on the
  * side): replaces HymetaMoE.forward -> vLLM FusedMoE(renormalize=False,

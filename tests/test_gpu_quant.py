@@ -123,3 +123,26 @@ def test_gptq_linear_large_m_uses_expanded_weights():
         out = lin(x.cuda())
         torch.cuda.synchronize()
         assert_bf16_close(out.cpu(), ref, f"gptq linear M={M}", rel=8e-3)
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 512, 256), (1024, 3584, 4608)])
+def test_w8a8_linear_prefill_regime_matches_fused_kernel_exactly(M, K, N):
+    """Above the row threshold the linear runs quantise -> library int8 GEMM -> scale; the int32 sums
+    are exact on both paths, so the outputs agree bit for bit with the fused kernel's and with the
+    oracle within the bf16 tolerance."""
+    from oracle.quant import w8a8_gemm_ref
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta.linear import HymetaLinear, W8A8_LIBRARY_ROWS
+
+    assert M > W8A8_LIBRARY_ROWS
+    g_ = gen(21)
+    x = randn_bf16(g_, M, K)
+    wq = torch.randint(-127, 128, (N, K), generator=g_, dtype=torch.int8)
+    ws = torch.rand(N, generator=g_) * 0.02 + 0.001
+    bias = randn_bf16(g_, N, scale=0.1)
+    lin = HymetaLinear.from_w8a8(wq.cuda(), ws.cuda(), bias.cuda())
+    out = lin(x.cuda())
+    fused = hip_ops.w8a8_gemm(x.cuda(), wq.cuda(), ws.cuda(), bias=bias.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(out, fused)
+    assert_bf16_close(out.cpu(), w8a8_gemm_ref(x, wq, ws, bias), f"w8a8 linear M={M}", rel=6e-3)

@@ -738,6 +738,29 @@ __global__ __launch_bounds__(256) void w8a8_quant_kernel(hymeta_w8a8_gemm_args a
   }
 }
 
+// out = bf16(acc * x_scale[m] * w_scale[n] + bias[n]): thread = 4 columns of one row
+__global__ __launch_bounds__(256) void w8a8_scale_out_kernel(const int32_t* __restrict__ acc, const float* __restrict__ x_scale,
+                                                             const float* __restrict__ w_scale, const uint16_t* __restrict__ bias,
+                                                             uint16_t* __restrict__ out, int M, int N, int64_t acc_stride_m,
+                                                             int64_t out_stride_m) {
+  const int ncg = N / 4;
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= static_cast<int64_t>(M) * ncg) return;
+  const int m = static_cast<int>(idx / ncg), col = static_cast<int>(idx % ncg) * 4;
+  const i32x4 v = *reinterpret_cast<const i32x4*>(acc + m * acc_stride_m + col);
+  const f32x4 ws = *reinterpret_cast<const f32x4*>(w_scale + col);
+  const float xs = x_scale[m];
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  if (bias != nullptr) {
+    const u32x2 bw = *reinterpret_cast<const u32x2*>(bias + col);
+    b = f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+  }
+  float y[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) y[i] = static_cast<float>(v[i]) * xs * ws[i] + b[i];
+  *reinterpret_cast<u32x2*>(out + m * out_stride_m + col) = u32x2{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+}
+
 // grid = (N / 64, ceil(M / (16 MT)), splits); the 4 waves take alternate 64-deep k-steps of the
 // workgroup's K slice; slices meet in int32 slabs (exact), the last arriver scales and writes.
 template <int MT>
@@ -1053,5 +1076,34 @@ extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream
   if (mt == 1) hipLaunchKernelGGL((w8a8_gemm_kernel<1>), grid, block, lds, s, a, splits, sps, slabs, counters);
   else if (mt == 2) hipLaunchKernelGGL((w8a8_gemm_kernel<2>), grid, block, lds, s, a, splits, sps, slabs, counters);
   else hipLaunchKernelGGL((w8a8_gemm_kernel<4>), grid, block, lds, s, a, splits, sps, slabs, counters);
+  return launch_status();
+}
+
+extern "C" int hymeta_w8a8_quantize(const void* x, int8_t* xq, float* x_scale, int32_t M, int32_t K, int64_t x_stride_m,
+                                    hymeta_stream_t stream) {
+  if (M < 0 || K <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (M == 0) return HYMETA_OK;
+  if (!x || !xq || !x_scale) return HYMETA_ERR_INVALID_ARG;
+  if (K % 8 != 0 || x_stride_m % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xq)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  hymeta_w8a8_gemm_args a = {};
+  a.x = x, a.xq = xq, a.x_scale = x_scale, a.M = M, a.K = K, a.x_stride_m = x_stride_m;
+  hipLaunchKernelGGL(w8a8_quant_kernel, dim3(M), dim3(256), 0, begin_launches(stream), a);
+  return launch_status();
+}
+
+extern "C" int hymeta_w8a8_scale_out(const int32_t* acc, const float* x_scale, const float* w_scale, const void* bias, void* out,
+                                     int32_t M, int32_t N, int64_t acc_stride_m, int64_t out_stride_m, hymeta_stream_t stream) {
+  if (M < 0 || N <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (M == 0) return HYMETA_OK;
+  if (!acc || !x_scale || !w_scale || !out) return HYMETA_ERR_INVALID_ARG;
+  if (N % 4 != 0 || acc_stride_m % 4 != 0 || out_stride_m % 4 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(acc) | reinterpret_cast<uintptr_t>(w_scale)) % 16 != 0 ||
+      (reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias)) % 8 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  const int64_t threads = static_cast<int64_t>(M) * (N / 4);
+  hipLaunchKernelGGL(w8a8_scale_out_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, begin_launches(stream),
+                     acc, x_scale, w_scale, static_cast<const uint16_t*>(bias), static_cast<uint16_t*>(out), M, N, acc_stride_m,
+                     out_stride_m);
   return launch_status();
 }

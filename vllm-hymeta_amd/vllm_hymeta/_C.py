@@ -220,6 +220,8 @@ _SIGNATURES = {
     "hymeta_moe_gemm": (C.c_int, [C.POINTER(MoeGemmArgs), _ptr]),
     "hymeta_silu_and_mul": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),
     "hymeta_moe_combine": (C.c_int, [C.POINTER(MoeCombineArgs), _ptr]),
+    "hymeta_w8a8_quantize": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i64, _ptr]),
+    "hymeta_w8a8_scale_out": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),
     "hymeta_w8a8_gemm_split_k": (C.c_int, [_i32, _i32, _i32]),
     "hymeta_w8a8_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),
 }

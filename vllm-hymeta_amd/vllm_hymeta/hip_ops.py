@@ -630,6 +630,35 @@ def w8a8_gemm(x: torch.Tensor, qweight: torch.Tensor, w_scale: torch.Tensor,
     return out
 
 
+def w8a8_quantize(x: torch.Tensor):
+    """Dynamic per-token int8 quantisation: x bf16 [M,K] -> (xq int8 [M,K], x_scale fp32 [M])."""
+    _dev(x)
+    M, K = x.shape
+    _require(x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [M, K]")
+    xq = torch.empty(M, K, dtype=torch.int8, device=x.device)
+    xs = torch.empty(M, dtype=torch.float32, device=x.device)
+    _C.check(_C.load().hymeta_w8a8_quantize(_p(x), _p(xq), _p(xs), M, K, x.stride(0), _stream(x)), "hymeta_w8a8_quantize")
+    return xq, xs
+
+
+def w8a8_scale_out(acc: torch.Tensor, x_scale: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """acc int32 [M,N] (exact sums of int8 products) -> bf16(acc * x_scale[m] * w_scale[n] + bias[n])."""
+    _dev(acc, x_scale, w_scale, bias, out)
+    M, N = acc.shape
+    _require(acc.dtype == torch.int32 and acc.stride(1) == 1, "acc must be row-contiguous int32 [M, N]")
+    _require(x_scale.dtype == torch.float32 and x_scale.is_contiguous() and x_scale.numel() == M, "x_scale must be fp32 [M]")
+    _require(w_scale.dtype == torch.float32 and w_scale.is_contiguous() and w_scale.numel() == N, "w_scale must be fp32 [N]")
+    if bias is not None:
+        _require(bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N, "bias must be bf16 [N]")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=acc.device)
+    _require(out.shape == (M, N) and out.dtype == torch.bfloat16 and out.stride(1) == 1, "out must be bf16 [M, N]")
+    _C.check(_C.load().hymeta_w8a8_scale_out(_p(acc), _p(x_scale), _p(w_scale), _p(bias), _p(out), M, N, acc.stride(0),
+                                             out.stride(0), _stream(acc)), "hymeta_w8a8_scale_out")
+    return out
+
+
 # ---------------------------------------------------------------------------
 # Sparse mixture of experts
 # ---------------------------------------------------------------------------

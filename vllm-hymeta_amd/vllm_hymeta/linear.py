@@ -16,6 +16,9 @@ from . import hip_ops
 # Rows above which a GPTQ linear expands its weights and calls the library GEMM (measured on the 7B
 # projection shapes: the fused kernel wins up to a few hundred rows, the library from there on).
 GPTQ_EXPAND_ROWS = 256
+# Rows above which a W8A8 linear puts the library int8 GEMM between its own quantisation and
+# scaling kernels (measured: level at 256 rows, the library ahead beyond).
+W8A8_LIBRARY_ROWS = 256
 
 
 class HymetaLinear(torch.nn.Module):
@@ -59,4 +62,10 @@ class HymetaLinear(torch.nn.Module):
             return hip_ops.gptq_gemm(x, self.qweight, self.qzeros, self.scales, self.meta["bits"],
                                      self.meta["group_size"], bias=self.bias,
                                      zero_offset=self.meta.get("zero_offset", 1))
+        if x.shape[0] > W8A8_LIBRARY_ROWS:
+            # prefill regime: the same per-token quantisation and scaling, exact int32 sums from the
+            # library GEMM in between
+            xq, xs = hip_ops.w8a8_quantize(x)
+            acc = torch._int_mm(xq, self.qweight.t())
+            return hip_ops.w8a8_scale_out(acc, xs, self.w_scale, bias=self.bias)
         return hip_ops.w8a8_gemm(x, self.qweight, self.w_scale, bias=self.bias)
