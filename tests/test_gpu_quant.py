@@ -63,7 +63,8 @@ def test_gptq_gemm_7b_qkv_shape_and_strided_input():
     assert_bf16_close(out.cpu(), ref, "gptq qkv 7B")
 
 
-@pytest.mark.parametrize("M,K,N", [(1, 256, 64), (9, 1024, 192), (70, 512, 128), (4, 3584, 4608)])
+@pytest.mark.parametrize("M,K,N", [(1, 256, 64), (9, 1024, 192), (70, 512, 128), (4, 3584, 4608),
+                                   (33, 256, 128), (64, 3584, 4608), (50, 768, 256), (200, 3584, 3584), (64, 18944, 128)])
 def test_w8a8_gemm(M, K, N):
     from oracle.quant import w8a8_gemm_ref
     from vllm_hymeta import hip_ops
