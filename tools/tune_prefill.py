@@ -49,6 +49,28 @@ def swa(lens, H, Hkv, M, wl):
     print(f"swa_prefill lens={lens} H={H} Hkv={Hkv} M={M} wl={wl}: {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
 
 
+def swa_paged(chunk, ctx, H, Hkv, M, wl, bs=256):
+    """One chunk of `chunk` queries of a sequence that already holds ctx - chunk keys in a paged cache
+    (the chunked-prefill call of the 70B configuration)."""
+    dev = torch.device("cuda")
+    nblk = (ctx + bs - 1) // bs
+    kv = torch.randn(2, nblk + 3, bs, Hkv, D, device=dev).to(torch.bfloat16)
+    bt = torch.randperm(nblk + 3)[:nblk].to(torch.int32).view(1, nblk).to(dev)
+    q = torch.randn(chunk, H, D, device=dev).to(torch.bfloat16)
+    k2 = torch.randn(M, Hkv, D, device=dev).to(torch.bfloat16) if M else None
+    v2 = torch.randn(M, Hkv, D, device=dev).to(torch.bfloat16) if M else None
+    cu = torch.tensor([0, chunk], dtype=torch.int32, device=dev)
+    sl = torch.tensor([ctx], dtype=torch.int32, device=dev)
+    out = torch.empty(chunk, H, D, dtype=torch.bfloat16, device=dev)
+    us = bench(lambda: hip_ops.meta_swa_prefill(q, cu, chunk, key_cache=kv[0], value_cache=kv[1], block_tables=bt,
+                                               seq_lens_k=sl, meta_key=k2, meta_value=v2, window_left=wl, out=out))
+    import numpy as np
+    pos = np.arange(ctx - chunk, ctx)
+    vis = np.minimum(pos + 1, wl + 1) if wl >= 0 else pos + 1
+    flops = 4.0 * D * H * float((vis + M).sum())
+    print(f"swa_prefill PAGED chunk={chunk} ctx={ctx} H={H} Hkv={Hkv} M={M} wl={wl} bs={bs}: {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
+
+
 def gla(lens, H, Hkv, nseg=0):
     dev = torch.device("cuda")
     T = sum(lens)
@@ -76,6 +98,12 @@ if __name__ == "__main__":
         swa([32768], 7, 1, 128, 4095)
         swa([32768], 7, 1, 128, -1)
         swa([2048] * 8, 28, 4, 0, 4096)
+    if "paged" in which:
+        swa_paged(8192, 32768, 7, 1, 128, 4095)
+        swa_paged(2048, 32768, 7, 1, 128, 4095)
+        swa_paged(8192, 32768, 7, 1, 128, -1)
+        swa_paged(8192, 32768, 28, 4, 0, 4096)
+        swa_paged(8192, 32768, 28, 4, 0, 4096, bs=16)
     if "gla" in which:
         for nseg in (1, 0, 9, 18, 27, 36, 64):
             gla([32768], 28, 4, nseg)
