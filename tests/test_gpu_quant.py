@@ -147,3 +147,30 @@ def test_w8a8_linear_prefill_regime_matches_fused_kernel_exactly(M, K, N):
     torch.cuda.synchronize()
     assert torch.equal(out, fused)
     assert_bf16_close(out.cpu(), w8a8_gemm_ref(x, wq, ws, bias), f"w8a8 linear M={M}", rel=6e-3)
+
+
+@pytest.mark.parametrize("tp", [2, 4])
+def test_tensor_parallel_gptq_mlp_shards_sum_to_the_unsharded_layer(tp):
+    """gate_up (column parallel) and down (row parallel) cut for tp ranks by the checkpoint loader:
+    the ranks' partial outputs, summed as the layer's all-reduce would, equal the unsharded MLP."""
+    from oracle.moe import silu_and_mul_ref
+    from oracle.quant import gptq_gemm_ref
+    from vllm_hymeta import hip_ops, loader
+
+    g_ = gen(31)
+    hidden, inter, M, group = 512, 1024, 24, 128
+    def mk(seed, K, N):
+        qw, qz, sc = _gptq_problem(seed, K, N, 4, group, torch.float16)
+        return {"qweight": qw, "qzeros": qz, "scales": sc}
+    gate, up, down = mk(1, hidden, inter), mk(2, hidden, inter), mk(3, inter, hidden)
+    x = randn_bf16(g_, M, hidden)
+    h_ref = silu_and_mul_ref(torch.cat([gptq_gemm_ref(x, gate["qweight"], gate["qzeros"], gate["scales"], 4, group),
+                                        gptq_gemm_ref(x, up["qweight"], up["qzeros"], up["scales"], 4, group)], dim=1).to(torch.bfloat16))
+    ref = gptq_gemm_ref(h_ref, down["qweight"], down["qzeros"], down["scales"], 4, group)
+    total = torch.zeros(M, hidden, dtype=torch.float32, device="cuda")
+    for rank in range(tp):
+        gu = loader.make_linear(loader.shard_gate_up(gate, up, tp, rank), 4, group, device="cuda")
+        dn = loader.make_linear(loader.shard_row_parallel(down, tp, rank, 4, group), 4, group, device="cuda")
+        total += dn(hip_ops.silu_and_mul(gu(x.cuda()))).float()
+    torch.cuda.synchronize()
+    assert_bf16_close(total.cpu(), ref, f"tp={tp} GPTQ MLP", rel=1e-2)
