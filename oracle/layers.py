@@ -200,7 +200,7 @@ def hybrid_layer_70b_ref(x: torch.Tensor, meta_x: torch.Tensor, positions: torch
                          num_heads: int, num_kv_heads: int, sliding_window: Optional[int],
                          lower_bound: Optional[torch.Tensor], first_layer: bool,
                          rope_theta: float = 1e6, max_position: int = 131072,
-                         norm_eps: float = 1e-6) -> torch.Tensor:
+                         norm_eps: float = 1e-6, return_meta: bool = False) -> torch.Tensor:
     """One 70B intra-hybrid attention block on ONE sequence, prefill form, with the meta tokens
     already "cached": the softmax branch sees the roped K/V of ``meta_x`` (positions 0..M-1) as
     always-visible keys and ropes the real tokens at ``positions + M``; the GLA branch starts from
@@ -210,7 +210,9 @@ def hybrid_layer_70b_ref(x: torch.Tensor, meta_x: torch.Tensor, positions: torch
 
     ``p``: ``vanilla_attn.{q,k,v}_proj.{weight,bias}``, ``linear_attn.{q,k,v}_proj.{weight,bias}``,
     ``norm1.weight``, ``norm2.weight`` (fp32), ``out_proj.weight``.  ``sliding_window`` = W keys
-    including the query (None: full attention).  Returns ``[T, hidden]`` bf16."""
+    including the query (None: full attention).  Returns ``[T, hidden]`` bf16; with ``return_meta``
+    ``[M + T, hidden]``, the meta tokens' own rows first (their queries see every meta key and no
+    real key; their GLA output is the pass from the zero state)."""
     from .gla import gla_recurrent_ref
     from .meta_swa import meta_swa_dense_ref
 
@@ -227,12 +229,12 @@ def hybrid_layer_70b_ref(x: torch.Tensor, meta_x: torch.Tensor, positions: torch
 
     # softmax branch
     q2, k2, v2 = qkv("vanilla_attn", meta_x)
-    _, k2 = rope_neox_ref(torch.arange(M), q2, k2, cache)
+    q2, k2 = rope_neox_ref(torch.arange(M), q2, k2, cache)
     q, k, v = qkv("vanilla_attn", x)
     q, k = rope_neox_ref(positions + M, q, k, cache)
     wl = -1 if not sliding_window else sliding_window - 1
-    o_attn, _ = meta_swa_dense_ref(q, k, v, k2, v2, None, wl)
-    o_attn = o_attn.to(x.dtype).reshape(T, num_heads * D)
+    o_attn, _ = meta_swa_dense_ref(q, k, v, k2, v2, q2 if return_meta else None, wl)
+    o_attn = o_attn.to(x.dtype).reshape(-1, num_heads * D)
 
     # GLA branch: meta tokens first (zero state), then the sequence from the meta state
     def gla(h, init):
@@ -240,9 +242,11 @@ def hybrid_layer_70b_ref(x: torch.Tensor, meta_x: torch.Tensor, positions: torch
         qg, kg, gg = gate_70b_ref(ql, kl.repeat_interleave(rep, dim=1), lower_bound, first_layer)
         return gla_recurrent_ref(qg, kg, vl.repeat_interleave(rep, dim=1), gg, init)
 
-    _, meta_state = gla(meta_x, None)
+    o_meta, meta_state = gla(meta_x, None)
     o_lin, _ = gla(x, meta_state.to(x.dtype))          # the shared meta state is stored in bf16
-    o_lin = o_lin.to(x.dtype).reshape(T, num_heads * D)
+    if return_meta:
+        o_lin = torch.cat([o_meta, o_lin])
+    o_lin = o_lin.to(x.dtype).reshape(-1, num_heads * D)
     y = hybrid_combine_ref(o_attn, o_lin, p["norm1.weight"], p["norm2.weight"], norm_eps)
     return _linear(y, p["out_proj.weight"])
 

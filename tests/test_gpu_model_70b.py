@@ -1,0 +1,103 @@
+"""The 70B-family model class end to end on a tiny configuration (4 layers: dense and expert
+feed-forward, windowed and full attention, clamp and lower-bound gates, 32 meta tokens):
+checkpoint-name loading, the meta tokens' one-off pass, a batch of two prompts, then a decode step
+of both, against the CPU restatement that carries the meta rows in front of each whole sequence."""
+import pytest
+import torch
+
+from _util import assert_bf16_close, gen, randn_bf16
+from test_gpu_layers import _md
+
+pytestmark = pytest.mark.gpu
+D = 128
+
+
+def _checkpoint(g_, cfg):
+    from oracle.layers import xavier_linear_params_ref as lin
+    hidden, H, Hkv, inter = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size
+    norm = lambda n: (1 + 0.1 * torch.randn(n, generator=g_)).to(torch.bfloat16)
+    w = {"model.embeddings.weight": randn_bf16(g_, cfg.vocab_size, hidden),
+         "mode.norm.weight": norm(hidden),                      # the published checkpoint's spelling
+         "lm_head.weight": randn_bf16(g_, cfg.vocab_size, hidden, scale=0.05),
+         "model.meta_tokens": randn_bf16(g_, cfg.num_meta_tokens, hidden),
+         "model.lower_bounds": torch.randn(cfg.num_hidden_layers, hidden, generator=g_)}
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        for br in ("vanilla_attn", "linear_attn"):
+            for n, o in (("q_proj", H * D), ("k_proj", Hkv * D), ("v_proj", Hkv * D)):
+                w[p + f"attn.{br}.{n}.weight"] = lin(g_, o, hidden, False)["weight"]
+                w[p + f"attn.{br}.{n}.bias"] = randn_bf16(g_, o, scale=0.1)
+        w[p + "attn.vanilla_attn.rotary_emb.inv_freq"] = torch.zeros(D // 2)       # routed, never used
+        w[p + "attn.out_proj.weight"] = lin(g_, hidden, H * D, False)["weight"]
+        w[p + "attn.norm1.weight"], w[p + "attn.norm2.weight"] = norm(hidden).float(), norm(hidden).float()
+        w[p + "attn_norm.weight"], w[p + "mlp_norm.weight"] = norm(hidden), norm(hidden)
+
+        def mlp(name, size):
+            w[p + name + ".gate_proj.weight"] = lin(g_, size, hidden, False)["weight"]
+            w[p + name + ".up_proj.weight"] = lin(g_, size, hidden, False)["weight"]
+            w[p + name + ".down_proj.weight"] = lin(g_, hidden, size, False)["weight"]
+
+        if cfg.num_layer_experts[i] == 1:
+            mlp("mlp", inter)
+        else:
+            # a wide router keeps the experts' probabilities apart, so that the two sides pick the same expert
+            w[p + "block_sparse_moe.gate.weight"] = randn_bf16(g_, cfg.num_layer_experts[i], hidden, scale=0.5)
+            for e in range(cfg.num_layer_experts[i]):
+                mlp(f"block_sparse_moe.experts.{e}", inter)
+            mlp("shared_mlp", cfg.shared_intermediate_size)
+    return w
+
+
+def test_hymeta_for_causal_lm_prefill_then_decode():
+    from oracle.model import hymeta_model_ref
+    from vllm_hymeta.models.configuration_hymeta import HymetaConfig
+    from vllm_hymeta.models.modeling_hymeta import HymetaForCausalLM
+
+    dev = torch.device("cuda")
+    g_ = gen(12)
+    cfg = HymetaConfig(vocab_size=512, hidden_size=512, num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=2,
+                       intermediate_size=512, shared_intermediate_size=256, num_local_experts=4, num_meta_tokens=32,
+                       sliding_window=48, max_position_embeddings=1024)
+    assert cfg.num_layer_experts == [1, 1, 1, 4] and cfg.interleaved_sliding_window == [48, 48, 48, 0]
+    ckpt = _checkpoint(g_, cfg)
+    model = HymetaForCausalLM(cfg, max_num_seqs=4, device=dev)
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, dtype=torch.long, device=dev), torch.zeros(1, dtype=torch.long, device=dev), attn_metadata=object())
+    loaded = model.load_weights(ckpt.items())
+    assert "model.norm.weight" in loaded and "model.layers.3.block_sparse_moe.experts.w13_weight" in loaded
+    assert "model.layers.0.attn.linear_attn.qkv_proj.bias" in loaded
+    assert model.model.has_meta_cache
+
+    lens = [75, 40]
+    ids = [torch.randint(0, cfg.vocab_size, (L + 1,), generator=g_) for L in lens]
+    refs = [hymeta_model_ref(x, ckpt, cfg) for x in ids]
+
+    bs = 16
+    per_seq = (max(lens) + 1 + bs - 1) // bs
+    kv_caches = [torch.zeros(2, 2 * per_seq + 1, bs, cfg.num_key_value_heads, D, dtype=torch.bfloat16, device=dev)
+                 for _ in range(cfg.num_hidden_layers)]
+    bt = torch.randperm(2 * per_seq + 1, generator=g_)[: 2 * per_seq].to(torch.int32).view(2, per_seq).to(dev)
+    slot = lambda s, t: int(bt[s, t // bs]) * bs + t % bs
+    run = dict(request_ids_to_seq_ids={"a": [0], "b": [1]}, finished_requests_ids=[])
+
+    pre_ids = torch.cat([x[:L] for x, L in zip(ids, lens)]).to(dev)
+    pre_pos = torch.cat([torch.arange(L) for L in lens]).to(dev)
+    pre_slots = torch.tensor([slot(s, t) for s, L in enumerate(lens) for t in range(L)], device=dev)
+    md = _md(dev, prefill_lens=lens, context_lens=[0, 0], slot_mapping=pre_slots)
+    h_pre = model(pre_ids, pre_pos, attn_metadata=md, kv_caches=kv_caches, **run)
+
+    dec_ids = torch.stack([x[L] for x, L in zip(ids, lens)]).to(dev)
+    dec_pos = torch.tensor(lens, device=dev)
+    dec_slots = torch.tensor([slot(s, L) for s, L in enumerate(lens)], device=dev)
+    md = _md(dev, decode_seq_lens=[L + 1 for L in lens], block_tables=bt, slot_mapping=dec_slots)
+    h_dec = model(dec_ids, dec_pos, attn_metadata=md, kv_caches=kv_caches, **run)
+    logits = model.compute_logits(h_dec)
+    torch.cuda.synchronize()
+
+    ref_pre = torch.cat([r[0][:L] for r, L in zip(refs, lens)])
+    ref_dec = torch.stack([r[0][L] for r, L in zip(refs, lens)])
+    ref_logits = torch.stack([r[1][L] for r, L in zip(refs, lens)])
+    assert h_pre.shape == (sum(lens), cfg.hidden_size), "a serving step carries no meta rows"
+    assert_bf16_close(h_pre.cpu(), ref_pre, "70B model, prefill hidden states", rel=2e-2, frac=2.0 ** -4)
+    assert_bf16_close(h_dec.cpu(), ref_dec, "70B model, decode hidden states", rel=2e-2, frac=2.0 ** -4)
+    assert_bf16_close(logits.cpu(), ref_logits, "70B model, decode logits", rel=2e-2, frac=2.0 ** -4)

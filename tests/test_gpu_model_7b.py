@@ -1,0 +1,96 @@
+"""The 7B model class end to end on a tiny configuration: checkpoint-name loading, a batch of two
+prompts, then a decode step of both, against the CPU restatement run on each whole sequence."""
+import pytest
+import torch
+
+from _util import assert_bf16_close, gen, randn_bf16
+from test_gpu_layers import _md
+
+pytestmark = pytest.mark.gpu
+D = 128
+
+
+def _checkpoint(g_, cfg):
+    from oracle.layers import xavier_linear_params_ref as lin
+    hidden, H, Hkv, inter = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size
+    w = {"model.embeddings.weight": randn_bf16(g_, cfg.vocab_size, hidden),
+         "model.norm.weight": (1 + 0.1 * torch.randn(hidden, generator=g_)).to(torch.bfloat16),
+         "lm_head.weight": randn_bf16(g_, cfg.vocab_size, hidden, scale=0.05)}
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        for n, o in (("q_proj", H * D), ("k_proj", Hkv * D), ("v_proj", Hkv * D)):
+            w[p + f"attn.{n}.weight"] = lin(g_, o, hidden, False)["weight"]
+            w[p + f"attn.{n}.bias"] = randn_bf16(g_, o, scale=0.1)
+        w[p + "attn.o_proj.weight"] = lin(g_, hidden, H * D, False)["weight"]
+        if i not in cfg.attn_layers:
+            w[p + "attn.gk_proj.0.weight"] = lin(g_, 16, hidden, False)["weight"]
+            w[p + "attn.gk_proj.1.weight"] = lin(g_, Hkv * D, 16, False)["weight"]
+            w[p + "attn.gk_proj.1.bias"] = randn_bf16(g_, Hkv * D, scale=0.1)
+            w[p + "attn.g_norm.weight"] = (1 + 0.1 * torch.randn(D, generator=g_)).to(torch.bfloat16)
+        for n in ("attn_norm", "mlp_norm"):
+            w[p + n + ".weight"] = (1 + 0.1 * torch.randn(hidden, generator=g_)).to(torch.bfloat16)
+        w[p + "mlp.gate_proj.weight"] = lin(g_, inter, hidden, False)["weight"]
+        w[p + "mlp.up_proj.weight"] = lin(g_, inter, hidden, False)["weight"]
+        w[p + "mlp.down_proj.weight"] = lin(g_, hidden, inter, False)["weight"]
+    # a tensor of a layer the configuration does not have must be dropped, not loaded
+    w[f"model.layers.{cfg.num_hidden_layers}.mlp.down_proj.weight"] = torch.zeros(hidden, inter, dtype=torch.bfloat16)
+    return w
+
+
+def test_glaswa_for_causal_lm_prefill_then_decode():
+    from oracle.model import glaswa_model_ref
+    from vllm_hymeta.model_for_7B.configuration_gla_swa import GLAswaConfig
+    from vllm_hymeta.model_for_7B.modeling_gla_swa import GLAswaForCausalLM
+
+    dev = torch.device("cuda")
+    g_ = gen(11)
+    cfg = GLAswaConfig(vocab_size=512, hidden_size=512, num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=2,
+                       intermediate_size=1024, sliding_window=48, max_position_embeddings=1024)
+    ckpt = _checkpoint(g_, cfg)
+    model = GLAswaForCausalLM(cfg, max_num_seqs=4, device=dev)
+    loaded = model.load_weights(ckpt.items())
+    assert "model.layers.0.attn.qkv_proj.weight" in loaded and "model.layers.1.mlp.gate_up_proj.weight" in loaded
+    assert not any(".layers.4." in n for n in loaded)
+    assert model.model.cache_shape == (2, 4, 4, D, D)
+
+    lens = [70, 41]
+    ids = [torch.randint(0, cfg.vocab_size, (L + 1,), generator=g_) for L in lens]     # prompt + the decode step's token
+    refs = [glaswa_model_ref(x, ckpt, cfg) for x in ids]
+
+    bs = 16
+    per_seq = (max(lens) + 1 + bs - 1) // bs
+    n_swa = len(cfg.attn_layers)
+    kv_caches = [torch.zeros(2, 2 * per_seq + 1, bs, cfg.num_key_value_heads, D, dtype=torch.bfloat16, device=dev)
+                 for _ in range(n_swa)]
+    bt = torch.randperm(2 * per_seq + 1, generator=g_)[: 2 * per_seq].to(torch.int32).view(2, per_seq).to(dev)
+    slot = lambda s, t: int(bt[s, t // bs]) * bs + t % bs
+    run = dict(request_ids_to_seq_ids={"a": [0], "b": [1]}, finished_requests_ids=[])
+
+    pre_ids = torch.cat([x[:L] for x, L in zip(ids, lens)]).to(dev)
+    pre_pos = torch.cat([torch.arange(L) for L in lens]).to(dev)
+    pre_slots = torch.tensor([slot(s, t) for s, L in enumerate(lens) for t in range(L)], device=dev)
+    md = _md(dev, prefill_lens=lens, context_lens=[0, 0], slot_mapping=pre_slots)
+    h_pre = model(pre_ids, pre_pos, attn_metadata=md, kv_caches=kv_caches, **run)
+
+    dec_ids = torch.stack([x[L] for x, L in zip(ids, lens)]).to(dev)
+    dec_pos = torch.tensor(lens, device=dev)
+    dec_slots = torch.tensor([slot(s, L) for s, L in enumerate(lens)], device=dev)
+    md = _md(dev, decode_seq_lens=[L + 1 for L in lens], block_tables=bt, slot_mapping=dec_slots)
+    h_dec = model(dec_ids, dec_pos, attn_metadata=md, kv_caches=kv_caches, **run)
+    logits = model.compute_logits(h_dec)
+    torch.cuda.synchronize()
+
+    ref_pre = torch.cat([r[0][:L] for r, L in zip(refs, lens)])
+    ref_dec = torch.stack([r[0][L] for r, L in zip(refs, lens)])
+    ref_logits = torch.stack([r[1][L] for r, L in zip(refs, lens)])
+    assert_bf16_close(h_pre.cpu(), ref_pre, "7B model, prefill hidden states", rel=2e-2, frac=2.0 ** -4)
+    assert_bf16_close(h_dec.cpu(), ref_dec, "7B model, decode hidden states", rel=2e-2, frac=2.0 ** -4)
+    assert logits.dtype == torch.float32
+    assert_bf16_close(logits.cpu(), ref_logits, "7B model, decode logits", rel=2e-2, frac=2.0 ** -4)
+
+    # the same request ids keep their slots; a finished request frees its slot
+    slots_before = [model.model.gla_cache.slots.slot_of("a", 0), model.model.gla_cache.slots.slot_of("b", 1)]
+    assert len(set(slots_before)) == 2
+    assert model(None, dec_pos, attn_metadata=None) is None          # profiling run: no metadata, no work
+    with pytest.raises(ValueError):
+        model.model(None, dec_pos, attn_metadata=md)

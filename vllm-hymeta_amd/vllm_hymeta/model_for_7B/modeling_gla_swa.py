@@ -1,0 +1,184 @@
+"""The 7B "gla_swa" model on the HIP kernels: embedding, 28 decoder blocks (even layers gated
+linear attention, odd layers sliding-window attention), final norm, LM head.
+
+Reference: ``GLAswaModel`` / ``GLAswaForCausalLM``
+(``vllm_hymeta/model_for_7B/modeling_gla_swa.py:309-724``).  Same class names, parameter names
+(``packed_modules_mapping``, ``load_weights`` routing), state-cache calls and keyword arguments
+(``request_ids_to_seq_ids``, ``finished_requests_ids``, ``seqlen_agnostic_capture_inputs``).
+
+What differs in mechanism:
+* the step's attention metadata and the per-layer KV caches are taken from vLLM's forward context
+  when vLLM drives the model, and may be passed explicitly (``attn_metadata=``, ``kv_caches=``)
+  when it does not (tests, benchmarks);
+* a new sequence's state slot is not zeroed on the host (``_clear_prefill_cache``, ``:391-414``,
+  three device reads per prefill): the prefill kernel starts from zeros where
+  ``context_lens == 0``;
+* tensors are ingested in checkpoint format (bf16, GPTQ, W8A8) and cut for the rank by
+  ``vllm_hymeta.loader``; there are no vLLM parameter classes underneath.
+"""
+
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Set, Tuple
+
+import torch
+
+from .. import loader
+from ..linear import HymetaLinear
+from ..models.block import GLAswaBlock, HymetaRMSNorm
+from ..models.moe import HymetaMLP
+from ..parallel import shard_heads, tp_rank_and_size
+from .gla_attention import GatedLinearAttention
+from .gla_cache import GLACacheManager, GLACacheParams
+from .window_attention import SlidingWindowAttention, rope_cos_sin_cache
+
+GLAswaGLU = HymetaMLP     # vllm_hymeta/model_for_7B/modeling_gla_swa.py:60-131
+
+
+def _forward_context_metadata():
+    try:   # pragma: no cover - only where vLLM is installed
+        from vllm.forward_context import get_forward_context
+        return get_forward_context().attn_metadata
+    except Exception:
+        return None
+
+
+class GLAswaModel(torch.nn.Module):
+    def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda"):
+        """``quant``: ``{"bits", "group_size", "zero_offset"}`` of a GPTQ checkpoint (ignored for bf16 /
+        W8A8 tensors, which identify themselves by dtype)."""
+        super().__init__()
+        self.config = config
+        self.device = torch.device(device)
+        self.tp_group = tp_group
+        self.tp_rank, self.tp_size = tp_rank_and_size(tp_group)
+        self.quant = dict(bits=4, group_size=128, zero_offset=1)
+        self.quant.update(quant or {})
+        self.shard = shard_heads(config.num_attention_heads, config.num_key_value_heads, self.tp_size, self.tp_rank)
+        self.gla_layers = [i for i in range(config.num_hidden_layers) if i not in config.attn_layers]
+        self.cache_shape = (len(self.gla_layers), max_num_seqs, self.shard.num_heads, config.head_dim, config.head_dim)
+        self.gla_cache = GLACacheManager(dtype=torch.bfloat16, cache_shape=self.cache_shape, device=self.device)
+        max_pos = min(config.max_position_embeddings, getattr(config, "max_model_len", config.max_position_embeddings))
+        self.register_buffer("cos_sin_cache", rope_cos_sin_cache(config.head_dim, max_pos, config.rope_theta, device=self.device),
+                             persistent=False)
+        self.embeddings: Optional[torch.Tensor] = None          # [vocab, hidden] bf16, set by load_weights
+        self.layers = torch.nn.ModuleList()                      # filled by load_weights
+        self.norm: Optional[HymetaRMSNorm] = None
+
+    def get_input_embeddings(self, input_ids: torch.Tensor) -> torch.Tensor:
+        return torch.nn.functional.embedding(input_ids, self.embeddings)
+
+    def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor, intermediate_tensors=None,
+                inputs_embeds: Optional[torch.Tensor] = None, attn_metadata=None,
+                kv_caches: Optional[List[torch.Tensor]] = None, **kwargs) -> Optional[torch.Tensor]:
+        if attn_metadata is None:
+            attn_metadata = _forward_context_metadata()
+        if attn_metadata is None:
+            return None
+        if input_ids is not None and inputs_embeds is not None:
+            raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        if input_ids is None and inputs_embeds is None:
+            raise ValueError("You have to specify either input_ids or inputs_embeds")
+        kwargs.setdefault("request_ids_to_seq_ids", {})
+        kwargs.setdefault("finished_requests_ids", [])
+        gla_cache_tensors, state_indices_tensor = self.gla_cache.current_run_tensors(**kwargs)
+        params = GLACacheParams(gla_cache_tensors, state_indices_tensor)
+        hidden_states = self.get_input_embeddings(input_ids) if inputs_embeds is None else inputs_embeds
+
+        gla_index = swa_index = 0
+        for i, layer in enumerate(self.layers):
+            if i in self.config.attn_layers:
+                kv = kv_caches[swa_index] if kv_caches is not None else torch.empty(0, device=hidden_states.device)
+                swa_index += 1
+                hidden_states, _ = layer(hidden_states, positions=positions, kv_cache=kv, attn_metadata=attn_metadata)
+            else:
+                p = params.at_layer_idx(gla_index)
+                gla_index += 1
+                hidden_states, _ = layer(hidden_states, gla_cache=p.gla_cache, state_indices_tensor=p.state_indices_tensor,
+                                         attn_metadata=attn_metadata)
+        return self.norm(hidden_states)
+
+
+class GLAswaForCausalLM(torch.nn.Module):
+    packed_modules_mapping = {
+        "qkv_proj": ["q_proj", "k_proj", "v_proj"],
+        "gate_up_proj": ["gate_proj", "up_proj"],
+    }
+
+    def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda"):
+        super().__init__()
+        self.config = config
+        self.CONCAT_FFN = True
+        self.model = GLAswaModel(config, max_num_seqs=max_num_seqs, quant=quant, tp_group=tp_group, device=device)
+        self.lm_head: Optional[torch.Tensor] = None             # [vocab, hidden] fp32 (the reference's lm_head.float())
+        self.kv_cache = [torch.tensor([]) for _ in config.attn_layers]
+
+    def copy_inputs_before_cuda_graphs(self, input_buffers, **kwargs):
+        return self.model.gla_cache.copy_inputs_before_cuda_graphs(input_buffers, **kwargs)
+
+    def get_seqlen_agnostic_capture_inputs(self, batch_size: int):
+        return self.model.gla_cache.get_seqlen_agnostic_capture_inputs(batch_size)
+
+    def get_input_embeddings(self, input_ids: torch.Tensor) -> torch.Tensor:
+        return self.model.get_input_embeddings(input_ids)
+
+    def forward(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None, **kwargs):
+        return self.model(input_ids, positions, intermediate_tensors, inputs_embeds, **kwargs)
+
+    def compute_logits(self, hidden_states: torch.Tensor, sampling_metadata=None) -> torch.Tensor:
+        return torch.nn.functional.linear(hidden_states.float(), self.lm_head)
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]) -> Set[str]:
+        """Checkpoint tensors (any of bf16 / GPTQ / W8A8 per linear) -> this rank's modules.  Returns
+        the destination parameter names, as the reference's ``load_weights`` does."""
+        cfg, m = self.config, self.model
+        q = m.quant
+        dev = m.device
+        loaded: Set[str] = set()
+        parts: Dict[str, Dict[object, Dict[str, torch.Tensor]]] = {}    # module -> shard id -> tensors
+        plain: Dict[str, torch.Tensor] = {}
+        for name, tensor in weights:
+            route = loader.route_7b(name, cfg.num_hidden_layers)
+            if route is None:
+                continue
+            loaded.add(route.param)
+            module, _, leaf = route.param.rpartition(".")
+            if leaf in ("weight", "bias", "qweight", "qzeros", "scales", "g_idx", "weight_scale") and (
+                    "proj" in module or module == "lm_head" or module.endswith("embeddings")):
+                parts.setdefault(module, {}).setdefault(route.shard_id, {})[leaf] = tensor
+            else:
+                plain[route.param] = tensor
+
+        def lin(module: str, shard=None) -> Dict[str, torch.Tensor]:
+            return parts[module][shard]
+
+        def make(t: Dict[str, torch.Tensor]) -> HymetaLinear:
+            return loader.make_linear(t, q["bits"], q["group_size"], q["zero_offset"], device=dev)
+
+        H, KVH, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        m.embeddings = lin("model.embeddings")["weight"].to(torch.bfloat16).to(dev)
+        m.norm = HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain["model.norm.weight"].to(dev))
+        self.lm_head = lin("lm_head")["weight"].float().to(dev)
+        m.layers = torch.nn.ModuleList()
+        for i in range(cfg.num_hidden_layers):
+            p = f"model.layers.{i}"
+            qkv, sh = loader.shard_qkv(lin(f"{p}.attn.qkv_proj", "q"), lin(f"{p}.attn.qkv_proj", "k"), lin(f"{p}.attn.qkv_proj", "v"),
+                                       H, KVH, D, m.tp_size, m.tp_rank, q["bits"])
+            o_proj = make(loader.shard_row_parallel(lin(f"{p}.attn.o_proj"), m.tp_size, m.tp_rank, q["bits"], q["group_size"]))
+            if i in cfg.attn_layers:
+                attn = SlidingWindowAttention(cfg.hidden_size, H, KVH, cfg.sliding_window, make(qkv), o_proj, m.cos_sin_cache,
+                                              shard=sh, tp_group=m.tp_group)
+            else:
+                gk1 = loader.slice_out_features(lin(f"{p}.attn.gk_proj.linear1"), sh.kv_head_start * D,
+                                                (sh.kv_head_start + sh.num_kv_heads) * D, q["bits"])
+                attn = GatedLinearAttention(cfg.hidden_size, H, KVH, make(qkv), make(lin(f"{p}.attn.gk_proj.linear0")), make(gk1),
+                                            o_proj, plain[f"{p}.attn.g_norm.weight"].to(torch.bfloat16).to(dev), cfg.norm_eps,
+                                            cfg.gate_logit_normalizer, shard=sh, tp_group=m.tp_group)
+            mlp = GLAswaGLU(make(loader.shard_gate_up(lin(f"{p}.mlp.gate_up_proj", 0), lin(f"{p}.mlp.gate_up_proj", 1),
+                                                       m.tp_size, m.tp_rank, q["bits"])),
+                            make(loader.shard_row_parallel(lin(f"{p}.mlp.down_proj"), m.tp_size, m.tp_rank, q["bits"], q["group_size"])),
+                            tp_group=m.tp_group)
+            m.layers.append(GLAswaBlock(HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.attn_norm.weight"].to(dev)), attn,
+                                        HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.mlp_norm.weight"].to(dev)), mlp))
+        return loaded

@@ -51,12 +51,14 @@ class DecoderBlock(torch.nn.Module):
         super().__init__()
         self.attn_norm, self.attn, self.mlp_norm, self.mlp = attn_norm, attn, mlp_norm, mlp
 
-    def forward(self, hidden_states: torch.Tensor, **attn_kwargs) -> Tuple[torch.Tensor, None]:
+    def forward(self, hidden_states: torch.Tensor, attn_fn=None, **attn_kwargs) -> Tuple[torch.Tensor, None]:
+        """``attn_fn``: call this on the normed input instead of ``self.attn(normed, **attn_kwargs)``
+        (the 70B model's one-off pass of the meta tokens uses the layer's ``prepare_meta_state``)."""
         # the block's input becomes the residual stream; it is updated in place by mlp_norm, so
         # take a private copy when the caller keeps using its tensor
         residual = hidden_states.clone()
         normed = self.attn_norm(hidden_states)
-        attn_out = self.attn(normed, **attn_kwargs)
+        attn_out = attn_fn(normed) if attn_fn is not None else self.attn(normed, **attn_kwargs)
         normed, residual = self.mlp_norm(attn_out, residual)
         return residual + self.mlp(normed), None
 

@@ -166,6 +166,16 @@ class IntraHybridAttention(torch.nn.Module):
         return hip_ops.hybrid_combine(out_attn, out_linear, self.norm1_weight, self.norm2_weight,
                                       self.norm_eps, stats=stats)
 
+    def prepare_meta_state(self, meta_hidden: torch.Tensor, meta_linear_cache: torch.Tensor,
+                           meta_fattn_cache: torch.Tensor, lower_bound=None) -> torch.Tensor:
+        """Fill this layer's shared meta caches from the meta tokens' (normed) hidden states and
+        return the block output of the meta rows, which feeds the next layer's meta pass
+        (reference: the first forward passes, ``:776-788`` and ``:445-467``)."""
+        out_attn = self.vanilla_attn.prepare_meta_state(meta_hidden, meta_fattn_cache)
+        out_linear = self.linear_attn.prepare_meta_state(meta_hidden, meta_linear_cache, lower_bound)
+        out_linear = out_linear.reshape(meta_hidden.shape[0], -1)
+        return all_reduce_sum(self.out_proj(self.combine(out_attn, out_linear)), self.tp_group)
+
     def forward(self, hidden_states, positions, kv_cache, hymeta_cache, meta_linear_cache, meta_fattn_cache,
                 state_indices_tensor, attn_metadata, lower_bound=None) -> torch.Tensor:
         out_attn = self.vanilla_attn(hidden_states, positions, kv_cache, meta_fattn_cache, attn_metadata)

@@ -1,0 +1,255 @@
+"""The 70B "hybrid" model on the HIP kernels: embedding, decoder blocks (each with a softmax branch
+and a GLA branch run on the same input, 128 shared meta tokens in front of every sequence, dense
+MLP or mixture of experts with a shared expert), final norm, LM head.
+
+Reference: ``HymetaModel`` / ``HymetaForCausalLM``
+(``vllm_hymeta/models/modeling_hymeta.py:1084-1691``).  Same class names, checkpoint routing,
+state-cache calls and keyword arguments.
+
+What differs in mechanism:
+* the meta tokens are run through the layers ONCE, when the weights are loaded
+  (``prepare_meta_caches``): every layer keeps their roped K/V and their GLA end state in the
+  shared caches, and a serving step never carries the 128 extra rows.  The reference re-inserts
+  them into the batch until a forward-call counter passes a threshold (``:1160-1164,
+  1278-1292, 1372-1373``), which makes its first requests depend on how many warm-up runs vLLM
+  happened to make;
+* a new sequence's state slot is seeded from the meta state by the prefill kernel
+  (``context_lens == 0``), not zeroed on the host (``_clear_prefill_cache``, ``:1202-1227``);
+* tensors are ingested in checkpoint format and cut for the rank by ``vllm_hymeta.loader``.
+Pipeline parallelism (``IntermediateTensors``) is vLLM's and is not restated here.
+"""
+
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Set, Tuple
+
+import torch
+
+from .. import loader
+from ..linear import HymetaLinear
+from ..model_for_7B.window_attention import rope_cos_sin_cache
+from ..parallel import shard_heads, tp_rank_and_size
+from .block import HybridBlock, HymetaRMSNorm
+from .hybrid_attention import HLinearAttention, IntraHybridAttention, MetaFlashAttention
+from .hymeta_cache import HymetaCacheManager, HymetaCacheParams
+from .moe import HymetaMLP, HymetaMoE
+
+
+def _forward_context_metadata():
+    try:   # pragma: no cover - only where vLLM is installed
+        from vllm.forward_context import get_forward_context
+        return get_forward_context().attn_metadata
+    except Exception:
+        return None
+
+
+def _layer_experts(config, layer_idx: int) -> int:
+    n = getattr(config, "num_layer_experts", 1)          # reference :1116-1122
+    return n[layer_idx] if isinstance(n, list) else int(n)
+
+
+def _shared_intermediate(config, layer_idx: int) -> int:
+    s = getattr(config, "shared_intermediate_size", 0)   # reference :981-986
+    if isinstance(s, list):
+        return s[layer_idx] if len(s) > layer_idx else 0
+    return int(s)
+
+
+def _layer_window(config, layer_idx: int) -> Optional[int]:
+    w = getattr(config, "interleaved_sliding_window", None)   # reference :711-722
+    if w is None:
+        return None
+    if isinstance(w, int):
+        return w
+    if isinstance(w, list):
+        return w[layer_idx % len(w)]
+    raise ValueError(f"{type(w)} is not supported.")
+
+
+class HymetaModel(torch.nn.Module):
+    def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda"):
+        super().__init__()
+        self.config = config
+        self.device = torch.device(device)
+        self.tp_group = tp_group
+        self.tp_rank, self.tp_size = tp_rank_and_size(tp_group)
+        self.quant = dict(bits=4, group_size=128, zero_offset=1)
+        self.quant.update(quant or {})
+        self.use_lower_bound = config.use_lower_bound
+        self.num_meta_tokens = config.num_meta_tokens
+        self.shard = shard_heads(config.num_attention_heads, config.num_key_value_heads, self.tp_size, self.tp_rank)
+        L, D = config.num_hidden_layers, config.head_dim
+        self.cache_shape = (L, max_num_seqs, self.shard.num_heads, D, D)
+        self.meta_linear_cache_shape = (L, self.shard.num_heads, D, D)
+        self.meta_fattn_cache_shape = (L, 2, self.num_meta_tokens, self.shard.num_kv_heads, D)
+        self.hymeta_cache = HymetaCacheManager(torch.bfloat16, self.cache_shape, self.meta_linear_cache_shape,
+                                               self.meta_fattn_cache_shape, device=self.device)
+        max_pos = min(config.max_position_embeddings, getattr(config, "max_model_len", config.max_position_embeddings))
+        self.register_buffer("cos_sin_cache", rope_cos_sin_cache(D, max_pos, int(config.rope_theta), device=self.device),
+                             persistent=False)
+        self.embeddings: Optional[torch.Tensor] = None
+        self.layers = torch.nn.ModuleList()
+        self.norm: Optional[HymetaRMSNorm] = None
+        self.lower_bounds: Optional[torch.Tensor] = None     # [L, hidden] fp32 AFTER softmax/cumsum (:1309-1311)
+        self.meta_tokens: Optional[torch.Tensor] = None      # [M, hidden] bf16
+        self.has_meta_cache = False
+
+    def get_input_embeddings(self, input_ids: torch.Tensor) -> torch.Tensor:
+        return torch.nn.functional.embedding(input_ids, self.embeddings)
+
+    def _lower_bound(self, layer_idx: int) -> Optional[torch.Tensor]:
+        return self.lower_bounds[layer_idx % 7] if self.use_lower_bound else None
+
+    @torch.no_grad()
+    def prepare_meta_caches(self) -> None:
+        """The meta tokens' pass through every layer: fills ``meta_linear_cache`` and
+        ``meta_fattn_cache`` of each layer; the rows' own outputs only feed the next layer."""
+        if self.num_meta_tokens == 0:
+            self.has_meta_cache = True
+            return
+        _, meta_linear, meta_fattn = self.hymeta_cache.cache
+        h = self.meta_tokens
+        for i, layer in enumerate(self.layers):
+            lb = self._lower_bound(i)
+            h, _ = layer(h, attn_fn=lambda x, i=i, layer=layer, lb=lb: layer.attn.prepare_meta_state(
+                x, meta_linear[i], meta_fattn[i], lb))
+        self.has_meta_cache = True
+
+    def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor, intermediate_tensors=None,
+                inputs_embeds: Optional[torch.Tensor] = None, attn_metadata=None,
+                kv_caches: Optional[List[torch.Tensor]] = None, **kwargs) -> Optional[torch.Tensor]:
+        if attn_metadata is None:
+            attn_metadata = _forward_context_metadata()
+        if attn_metadata is None:
+            return None
+        if input_ids is not None and inputs_embeds is not None:
+            raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        if input_ids is None and inputs_embeds is None:
+            raise ValueError("You have to specify either input_ids or inputs_embeds")
+        if not self.has_meta_cache:
+            raise RuntimeError("meta caches are empty: load_weights() / prepare_meta_caches() must run before forward()")
+        kwargs.setdefault("request_ids_to_seq_ids", {})
+        kwargs.setdefault("finished_requests_ids", [])
+        params = HymetaCacheParams(*self.hymeta_cache.current_run_tensors(**kwargs))
+        hidden_states = self.get_input_embeddings(input_ids) if inputs_embeds is None else inputs_embeds
+        for i, layer in enumerate(self.layers):
+            c = params.at_layer_idx(i)
+            kv = kv_caches[i] if kv_caches is not None else torch.empty(0, device=hidden_states.device)
+            hidden_states, _ = layer(hidden_states, positions=positions, kv_cache=kv, hymeta_cache=c.hymeta_cache,
+                                     meta_linear_cache=c.meta_linear_cache, meta_fattn_cache=c.meta_fattn_cache,
+                                     state_indices_tensor=c.state_indices_tensor, attn_metadata=attn_metadata,
+                                     lower_bound=self._lower_bound(i))
+        return self.norm(hidden_states)
+
+
+class HymetaForCausalLM(torch.nn.Module):
+    packed_modules_mapping = {
+        "qkv_proj": ["q_proj", "k_proj", "v_proj"],
+        "gate_up_proj": ["gate_proj", "up_proj"],
+    }
+
+    def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda"):
+        super().__init__()
+        self.config = config
+        self.CONCAT_FFN = True
+        if not hasattr(config, "sliding_window"):
+            config.sliding_window = None
+        self.model = HymetaModel(config, max_num_seqs=max_num_seqs, quant=quant, tp_group=tp_group, device=device)
+        self.lm_head: Optional[torch.Tensor] = None             # [vocab, hidden] fp32 (:1429)
+        self.kv_cache = [torch.tensor([]) for _ in range(config.num_hidden_layers)]
+
+    def copy_inputs_before_cuda_graphs(self, input_buffers, **kwargs):
+        return self.model.hymeta_cache.copy_inputs_before_cuda_graphs(input_buffers, **kwargs)
+
+    def get_seqlen_agnostic_capture_inputs(self, batch_size: int):
+        return self.model.hymeta_cache.get_seqlen_agnostic_capture_inputs(batch_size)
+
+    def get_input_embeddings(self, input_ids: torch.Tensor) -> torch.Tensor:
+        return self.model.get_input_embeddings(input_ids)
+
+    def forward(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None, **kwargs):
+        return self.model(input_ids, positions, intermediate_tensors, inputs_embeds, **kwargs)
+
+    def compute_logits(self, hidden_states: torch.Tensor, sampling_metadata=None) -> torch.Tensor:
+        return torch.nn.functional.linear(hidden_states.float(), self.lm_head)
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]) -> Set[str]:
+        """Checkpoint tensors -> this rank's modules, then the meta tokens' pass.  Returns the
+        destination parameter names, as the reference's ``load_weights`` does."""
+        cfg, m = self.config, self.model
+        q, dev = m.quant, m.device
+        loaded: Set[str] = set()
+        parts: Dict[str, Dict[object, Dict[str, torch.Tensor]]] = {}       # linear module -> shard id -> tensors
+        experts: Dict[int, Dict[int, Dict[str, torch.Tensor]]] = {}        # layer -> expert -> projection -> weight
+        plain: Dict[str, torch.Tensor] = {}
+        proj_of = {"w1": "gate_proj", "w3": "up_proj", "w2": "down_proj"}
+        for name, tensor in weights:
+            route = loader.route_70b(name, cfg.num_hidden_layers)
+            if route is None:
+                continue
+            loaded.add(route.param)
+            if route.expert_id is not None:
+                if tensor.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+                    raise ValueError(f"{name}: quantised experts are not supported, expected a floating-point weight")
+                layer = loader._layer_of(name)
+                experts.setdefault(layer, {}).setdefault(route.expert_id, {})[proj_of[route.shard_id]] = tensor.to(torch.bfloat16)
+                continue
+            module, _, leaf = route.param.rpartition(".")
+            if "proj" in module and "norm" not in module:
+                parts.setdefault(module, {}).setdefault(route.shard_id, {})[leaf] = tensor
+            else:
+                plain[route.param] = tensor
+
+        def lin(module: str, shard=None) -> Dict[str, torch.Tensor]:
+            return parts[module][shard]
+
+        def make(t: Dict[str, torch.Tensor]) -> HymetaLinear:
+            return loader.make_linear(t, q["bits"], q["group_size"], q["zero_offset"], device=dev)
+
+        def mlp(prefix: str, reduce_results: bool = True) -> HymetaMLP:
+            gate_up = loader.shard_gate_up(lin(f"{prefix}.gate_up_proj", 0), lin(f"{prefix}.gate_up_proj", 1),
+                                           m.tp_size, m.tp_rank, q["bits"])
+            down = loader.shard_row_parallel(lin(f"{prefix}.down_proj"), m.tp_size, m.tp_rank, q["bits"], q["group_size"])
+            return HymetaMLP(make(gate_up), make(down), tp_group=m.tp_group, reduce_results=reduce_results)
+
+        H, KVH, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        sh = m.shard
+        hs = slice(sh.head_start * D, (sh.head_start + sh.num_heads) * D)
+        m.embeddings = plain["model.embeddings.weight"].to(torch.bfloat16).to(dev)
+        m.norm = HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain["model.norm.weight"].to(dev))
+        self.lm_head = plain["lm_head.weight"].float().to(dev)
+        if m.use_lower_bound:
+            lb = plain["model.lower_bounds"].float().to(dev).softmax(0)
+            m.lower_bounds = (lb.cumsum(0) - lb[0]).contiguous()
+        if m.num_meta_tokens > 0:
+            m.meta_tokens = plain["model.meta_tokens"].to(torch.bfloat16).to(dev).contiguous()
+        m.layers = torch.nn.ModuleList()
+        for i in range(cfg.num_hidden_layers):
+            p = f"model.layers.{i}"
+
+            def qkv(branch: str) -> HymetaLinear:
+                fused, _ = loader.shard_qkv(lin(f"{p}.attn.{branch}.qkv_proj", "q"), lin(f"{p}.attn.{branch}.qkv_proj", "k"),
+                                            lin(f"{p}.attn.{branch}.qkv_proj", "v"), H, KVH, D, m.tp_size, m.tp_rank, q["bits"])
+                return make(fused)
+
+            vanilla = MetaFlashAttention(cfg.hidden_size, H, KVH, qkv("vanilla_attn"), m.cos_sin_cache, _layer_window(cfg, i),
+                                         num_meta_tokens=m.num_meta_tokens, shard=sh)
+            linear = HLinearAttention(cfg.hidden_size, H, KVH, qkv("linear_attn"), i, num_meta_tokens=m.num_meta_tokens, shard=sh)
+            out_proj = make(loader.shard_row_parallel(lin(f"{p}.attn.out_proj"), m.tp_size, m.tp_rank, q["bits"], q["group_size"]))
+            attn = IntraHybridAttention(vanilla, linear, out_proj, plain[f"{p}.attn.norm1.weight"][hs].to(dev),
+                                        plain[f"{p}.attn.norm2.weight"][hs].to(dev), cfg.norm_eps, tp_group=m.tp_group)
+            n_experts = _layer_experts(cfg, i)
+            if n_experts == 1:
+                ffn = mlp(f"{p}.mlp")
+            else:
+                w13, w2 = loader.stack_experts([experts[i][e] for e in range(n_experts)], m.tp_size, m.tp_rank)
+                # the shared expert's partial sums ride in the experts' all-reduce
+                shared = mlp(f"{p}.shared_mlp", reduce_results=False) if _shared_intermediate(cfg, i) > 0 else None
+                ffn = HymetaMoE(plain[f"{p}.block_sparse_moe.gate.weight"].to(torch.bfloat16).to(dev), w13.to(dev), w2.to(dev),
+                                top_k=cfg.num_experts_per_topk, renormalize=False, shared_mlp=shared, group=m.tp_group)
+            m.layers.append(HybridBlock(HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.attn_norm.weight"].to(dev)), attn,
+                                        HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.mlp_norm.weight"].to(dev)), ffn))
+        if dev.type == "cuda":
+            m.prepare_meta_caches()
+        return loaded
