@@ -115,3 +115,27 @@ def test_swa_prefill_softmax_spike():
     out = hip_ops.meta_swa_prefill(q.cuda(), cu.cuda(), T, key=k.cuda(), value=v.cuda(), cu_seqlens_k=cu.cuda())
     torch.cuda.synchronize()
     assert_bf16_close(out.cpu(), ref, "prefill spike")
+
+
+@pytest.mark.parametrize("ramp", [1.5, 6.0, 40.0])
+def test_swa_prefill_growing_scores(ramp):
+    """Key norms grow along the sequence, so row maxima keep rising: slowly (the softmax reference
+    lags behind the true maximum and no rescale happens), at the threshold, and fast (a rescale in
+    most tiles, for some rows of a 32-query block and not for others)."""
+    from oracle import meta_swa_varlen_ref
+    from vllm_hymeta import hip_ops
+
+    H, Hkv, lens = 4, 2, [700, 130]
+    T = sum(lens)
+    g_ = gen(5)
+    q, k, v = randn_bf16(g_, T, H, D), randn_bf16(g_, T, Hkv, D), randn_bf16(g_, T, Hkv, D)
+    pos = torch.cat([torch.arange(L) / L for L in lens])
+    k = (k.float() * (1 + ramp * pos)[:, None, None]).to(torch.bfloat16)
+    q[::3] = (q[::3].float() * 0.2).to(torch.bfloat16)          # every third query: flat softmax, no growth
+    cu = _cu(lens)
+    for wl in (-1, 200):
+        ref = meta_swa_varlen_ref(q, k, v, cu, cu, None, None, None, wl)
+        out = hip_ops.meta_swa_prefill(q.cuda(), cu.cuda(), max(lens), key=k.cuda(), value=v.cuda(), cu_seqlens_k=cu.cuda(),
+                                       window_left=wl)
+        torch.cuda.synchronize()
+        assert_bf16_close(out.cpu(), ref, f"prefill, scores growing x{ramp}, window {wl}")

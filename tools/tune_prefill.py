@@ -92,7 +92,10 @@ def gla(lens, H, Hkv, nseg=0):
 
 if __name__ == "__main__":
     which = os.environ.get("WHICH", "swa,gla")
-    if "swa" in which:
+    if "swa" in which and os.environ.get("ONLY32K"):
+        swa([32768], 28, 4, 0, 4096)
+        swa([32768], 7, 1, 128, -1)
+    elif "swa" in which:
         swa([8192], 28, 4, 0, 4096)
         swa([32768], 28, 4, 0, 4096)
         swa([32768], 7, 1, 128, 4095)

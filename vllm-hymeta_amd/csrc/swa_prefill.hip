@@ -4,9 +4,10 @@
 // MFMA-bound.  A 512-thread workgroup owns 256 consecutive queries of one
 // (sequence, q-head); each of its 8 waves owns 32 of them as two 16-row MFMA
 // tiles.  The workgroup walks the visible keys in tiles of 64: all threads
-// stage the tile's K and V rows once (global -> registers issued before the
-// tile's compute, registers -> LDS after it, one barrier per tile, two LDS
-// buffers), and every wave reads its operands from that shared image:
+// stage the tile's K and V rows once (global -> registers one tile ahead,
+// registers -> LDS right after the barrier that frees the buffer, one barrier
+// per tile, two LDS buffers), and every wave reads its operands from that
+// shared image:
 //   S^T = K Q^T   A = 16 key rows x 32 channels, ds_read_b128 from the K image
 //                 (256-byte rows, 16-byte chunks XOR-ed with the row so the
 //                 sixteen rows of a read hit distinct banks);
@@ -35,6 +36,7 @@ constexpr int kKBytes = kTileK * kKPitch;
 constexpr int kVBytes = kTileK * kVPitch;
 constexpr int kOPitch = 272;         // output staging rows (bf16 x 128 + pad)
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLazyLog2 = 8.f;     // the softmax reference may trail the true row maximum by a factor 2^8
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
     for (int t = 0; t < 8; ++t) o[qt][t] = {0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-INFINITY, -INFINITY};
+  float m_run[2] = {-INFINITY, -INFINITY};   // reference score of the exponentials (a lazy running maximum)
+  float ms_run[2] = {0.f, 0.f};              // m_run * scale_log2, 0 while m_run is -inf
   f32x4 l_acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // l_acc[qt][r]: softmax denominator of query 16qt + 4c + r
   const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
 
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
     issue(0);
     commit(0);
   }
+  if (ntiles > 1) issue(1);
   // Pin the Q fragments as landed here: otherwise the first MFMA of EVERY tile waits for all
   // outstanding global loads (the just-issued next tile included) on behalf of the Q loads above.
 #pragma unroll
@@ -279,7 +283,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
 
   for (int tile = 0; tile < ntiles; ++tile) {
     const int buf = tile & 1;
-    if (tile + 1 < ntiles) issue(tile + 1);
+    // Tile t + 1 (loaded during the previous tile) goes to the other buffer now, behind the barrier
+    // that ended its last reads, and tile t + 2 is requested at once: the stores overlap the
+    // other waves' matrix work instead of standing between every wave's last MFMA and the barrier.
+    if (tile + 1 < ntiles) commit(buf ^ 1);
+    if (tile + 2 < ntiles) issue(tile + 2);
 
     const bool is_meta = tile < meta_tiles;
     const int rt = T_lo + tile - meta_tiles;   // real tile index
@@ -330,10 +338,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
         }
       }
 
-      // online softmax per query column; P re-packed as the A operand of P V:
-      // fragment kh, slot j <-> key 32kh + (j < 4 ? 4c + j : 16 + 4c + j - 4)
+      // online softmax per query column
       bf16x8 pf[2][2];
-      float alpha[2];
+      float tnew[2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         float tmax = max3(st[qt][0][0], st[qt][0][1], st[qt][0][2]);
@@ -349,10 +356,38 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
         const auto h16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
         tmax = max3(__uint_as_float(h16[0]), __uint_as_float(h16[1]), tmax);
         const auto h32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
-        const float m_new = max3(m_run[qt], __uint_as_float(h32[0]), __uint_as_float(h32[1]));
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;
-        alpha[qt] = __builtin_amdgcn_exp2f((m_run[qt] - m_use) * scale_log2);
-        const float ms = m_use * scale_log2;
+        tnew[qt] = max3(__uint_as_float(h32[0]), __uint_as_float(h32[1]), tmax);
+      }
+      // The running reference m_run follows the row maximum lazily: it moves (and the running
+      // output is rescaled) only when some query's scores exceed it by more than 2^kLazyLog2, so
+      // P stays <= 2^kLazyLog2 and most tiles skip the pass over the 64 output registers.  The
+      // decision precedes this tile's exponentials and follows the previous tile's P V.
+      const bool grow = (tnew[0] - m_run[0]) * scale_log2 > kLazyLog2 || (tnew[1] - m_run[1]) * scale_log2 > kLazyLog2;
+      if (__any(grow)) {
+        float alpha[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const float m_new = max3(m_run[qt], tnew[qt], tnew[qt]);
+          const float m_use = m_new == -INFINITY ? 0.f : m_new;
+          alpha[qt] = __builtin_amdgcn_exp2f((m_run[qt] - m_use) * scale_log2);
+          m_run[qt] = m_new;
+          ms_run[qt] = m_use * scale_log2;
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(alpha[qt], 4 * c + r);  // o rows are queries 4c + r
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[qt][t][r] *= ar;
+            l_acc[qt][r] *= ar;
+          }
+      }
+      // P re-packed as the A operand of P V:
+      // fragment kh, slot j <-> key 32kh + (j < 4 ? 4c + j : 16 + 4c + j - 4)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const float ms = ms_run[qt];
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
           float p[8];
@@ -364,18 +399,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
           for (int i = 0; i < 4; ++i) pw[i] = pack_bf16x2(p[2 * i], p[2 * i + 1]);
           pf[qt][kh] = as_frag(pw);
         }
-        m_run[qt] = m_new;
-      }
-      if (!__all(alpha[0] == 1.f && alpha[1] == 1.f)) {
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float ar = __shfl(alpha[qt], 4 * c + r);  // o rows are queries 4c + r
-#pragma unroll
-            for (int t = 0; t < 8; ++t) o[qt][t][r] *= ar;
-            l_acc[qt][r] *= ar;
-          }
       }
 
       // O += P V : o[qt][t][r] = O[query 16qt + 4c + r][dim 16t + n]
@@ -396,7 +419,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
       }
     }
 
-    if (tile + 1 < ntiles) commit(buf ^ 1);
     __syncthreads();
   }
 
