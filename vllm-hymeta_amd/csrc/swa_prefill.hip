@@ -52,11 +52,10 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const 
 }
 __device__ __forceinline__ bf16x8 as_frag(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
-// max of three as ONE instruction (the plain fmaxf chain gets a canonicalising v_max per MFMA output).
+// max of three as ONE instruction: v_maximum3_f32 (NaN-propagating, so the compiler adds no
+// canonicalising v_max per MFMA output as it does for fmaxf, and no wait states as after inline asm).
 __device__ __forceinline__ float max3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
+  return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
 }
 
 // 4 keys x 16 dims block read column-major: lane i of a 16-lane group gets dim i of the 4 keys.
