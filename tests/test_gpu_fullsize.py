@@ -104,7 +104,9 @@ def test_swa_32k_chunked_paged_prefill_and_decode_agree_with_single_pass(H, Hkv,
         o_dec = hip_ops.meta_swa_paged_decode(q[L:], kv_d[0], kv_d[1], lens, bt, meta_key=k2, meta_value=v2, window_left=wl,
                                               num_splits=splits, new_key=k[L:], new_value=v[L:], slot_mapping=slots[L:])
         torch.cuda.synchronize()
-        assert_bf16_close(o_dec.float().cpu(), ref[L:].float().cpu(), f"decode at 32k, splits={splits}", rel=3e-3)
+        # two bf16 kernels against each other (each within 5e-3 of the fp64 oracle at test sizes): both
+        # round their P and their output, so the pair sits near sqrt(2) x one kernel's error
+        assert_bf16_close(o_dec.float().cpu(), ref[L:].float().cpu(), f"decode at 32k, splits={splits}", rel=4e-3)
     assert torch.equal(kv_d[0].view(-1, Hkv, D)[slots[L]], k[L])      # the fused write landed
 
     # linearity in V: attn(V1 + V2) == attn(V1) + attn(V2) up to bf16 rounding of the three outputs
