@@ -94,3 +94,58 @@ def test_glaswa_for_causal_lm_prefill_then_decode():
     assert model(None, dec_pos, attn_metadata=None) is None          # profiling run: no metadata, no work
     with pytest.raises(ValueError):
         model.model(None, dec_pos, attn_metadata=md)
+
+
+def test_glaswa_for_causal_lm_gptq_checkpoint():
+    """The same model from a 4-bit GPTQ checkpoint (qweight / qzeros / scales / g_idx per projection, the
+    low-rank gate projections left in bf16 as quant_7B.py leaves them): loaded by name, run on the
+    fused de-quantising GEMMs, against the restatement run on the de-quantised weights."""
+    import re
+
+    from oracle.model import glaswa_model_ref
+    from oracle.quant import gptq_dequant_ref, gptq_pack_ref
+    from vllm_hymeta.model_for_7B.configuration_gla_swa import GLAswaConfig
+    from vllm_hymeta.model_for_7B.modeling_gla_swa import GLAswaForCausalLM
+
+    dev = torch.device("cuda")
+    g_ = gen(13)
+    group = 128
+    cfg = GLAswaConfig(vocab_size=512, hidden_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                       intermediate_size=1024, sliding_window=48, max_position_embeddings=1024)
+    dense = _checkpoint(g_, cfg)
+    quantised = {}
+    for name, w in dense.items():
+        m = re.match(r"(.*\.(?:q_proj|k_proj|v_proj|o_proj|gate_proj|up_proj|down_proj))\.weight$", name)
+        if m is None or f"layers.{cfg.num_hidden_layers}." in name:
+            quantised[name] = w
+            continue
+        N, K = w.shape
+        wi = torch.randint(0, 16, (K, N), generator=g_)
+        z = torch.randint(1, 16, (K // group, N), generator=g_)
+        s = (torch.rand(K // group, N, generator=g_) * 0.002 + 0.0005).to(torch.float16)
+        qw, qz = gptq_pack_ref(wi, z, 4)
+        quantised[m.group(1) + ".qweight"], quantised[m.group(1) + ".qzeros"], quantised[m.group(1) + ".scales"] = qw, qz, s
+        quantised[m.group(1) + ".g_idx"] = torch.arange(K, dtype=torch.int32) // group
+        dense[name] = gptq_dequant_ref(qw, qz, s, 4, group).t().contiguous().to(torch.bfloat16)
+    model = GLAswaForCausalLM(cfg, max_num_seqs=2, quant={"bits": 4, "group_size": group}, device=dev)
+    loaded = model.load_weights(quantised.items())
+    assert "model.layers.0.attn.qkv_proj.qweight" in loaded and "model.layers.1.mlp.gate_up_proj.scales" in loaded
+    assert model.model.layers[0].mlp.down_proj.kind == "gptq" and model.model.layers[0].attn.gk_proj0.kind == "bf16"
+
+    L = 50
+    ids = torch.randint(0, cfg.vocab_size, (L + 1,), generator=g_)
+    ref_h, ref_logits = glaswa_model_ref(ids, dense, cfg)
+    bs = 16
+    nblk = (L + 1 + bs - 1) // bs
+    kv_caches = [torch.zeros(2, nblk, bs, cfg.num_key_value_heads, D, dtype=torch.bfloat16, device=dev)]
+    bt = torch.arange(nblk, dtype=torch.int32, device=dev).view(1, -1)
+    run = dict(request_ids_to_seq_ids={"r": [0]}, finished_requests_ids=[])
+    pos = torch.arange(L + 1, device=dev)
+    h_pre = model(ids[:L].to(dev), pos[:L], attn_metadata=_md(dev, prefill_lens=[L], context_lens=[0], slot_mapping=pos[:L]),
+                  kv_caches=kv_caches, **run)
+    h_dec = model(ids[L:].to(dev), pos[L:], attn_metadata=_md(dev, decode_seq_lens=[L + 1], block_tables=bt, slot_mapping=pos[L:]),
+                  kv_caches=kv_caches, **run)
+    logits = model.compute_logits(h_dec)
+    torch.cuda.synchronize()
+    assert_bf16_close(torch.cat([h_pre, h_dec]).cpu(), ref_h, "7B model from a GPTQ checkpoint, hidden states", rel=2e-2, frac=2.0 ** -4)
+    assert_bf16_close(logits.cpu(), ref_logits[L:], "7B model from a GPTQ checkpoint, logits", rel=2e-2, frac=2.0 ** -4)
