@@ -3,7 +3,7 @@ dense MLP vs the CPU restatement."""
 import pytest
 import torch
 
-from _util import assert_bf16_close, gen, randn_bf16
+from _util import assert_bf16_close, assert_bf16_ulp, gen, randn_bf16
 
 pytestmark = pytest.mark.gpu
 
@@ -37,6 +37,8 @@ def test_silu_and_mul_bit_exact():
     (300, 16, 1, False, True),      # prefill chunk: 64-row tiles, ragged expert sizes
     (50, 8, 2, True, False),        # the eager module's top-2 with renormalised weights
     (40, 4, 2, False, True),
+    (900, 4, 1, False, True),       # many rows per expert: the 128 x 128 tiled grouped GEMM, ragged last tiles
+    (700, 4, 2, True, False),       # the same with two choices per token
 ])
 def test_moe_forward(T, E, top_k, renorm, with_shared):
     from oracle.moe import moe_ref
@@ -70,10 +72,23 @@ def test_moe_expert_parallel_shares_sum_to_the_whole():
         torch.cuda.synchronize()
         assert_bf16_close(part.cpu(), moe_ref(x, logits, w13, w2, local_experts=lo_hi), f"EP share {r}", rel=8e-3)
         parts.append(part.float())
-    # top-1: every token belongs to exactly one rank, so the sum is bit-identical to the whole
-    assert torch.equal((parts[0] + parts[1]).to(torch.bfloat16), full)
+    # top-1: every token belongs to exactly one rank, so the sum is the whole -- up to the fp32
+    # summation order of the GEMM variant that each call's rows-per-expert average selects
+    assert_bf16_ulp((parts[0] + parts[1]).to(torch.bfloat16), full, "EP shares summed vs single rank", ulps=1)
     with pytest.raises(ValueError):
         expert_range(16, 3, 0)
+
+
+def test_moe_tiled_regime_expert_parallel_share():
+    """Prefill-sized chunk on the tiled grouped GEMM, one expert-parallel rank's experts only."""
+    from oracle.moe import moe_ref
+    from vllm_hymeta import hip_ops
+
+    T, H, inter, E = 1000, 256, 256, 4      # both GEMMs on the 256 x 256 tile
+    x, gate_w, w13, w2, logits = _problem(5, T, H, inter, E)
+    part = hip_ops.moe_forward(x.cuda(), logits.cuda(), w13.cuda(), w2.cuda(), local_experts=(2, 4))
+    torch.cuda.synchronize()
+    assert_bf16_close(part.cpu(), moe_ref(x, logits, w13, w2, local_experts=(2, 4)), "tiled EP share", rel=8e-3)
 
 
 def test_hymeta_moe_module_and_dense_mlp():

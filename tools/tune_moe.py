@@ -18,7 +18,7 @@ def main():
     w13 = (torch.randn(E, 2 * inter, H, device=dev) * H ** -0.5).to(torch.bfloat16)
     w2 = (torch.randn(E, H, inter, device=dev) * inter ** -0.5).to(torch.bfloat16)
     wbytes = (w13.numel() + w2.numel()) * 2
-    for T in (1, 16, 64, 256, 2048, 8192):
+    for T in (1, 16, 64, 256, 512, 1024, 2048, 4096, 8192):
         x = torch.randn(T, H, device=dev).to(torch.bfloat16)
         logits = torch.randn(T, E, device=dev).to(torch.bfloat16)
         out = torch.empty(T, H, device=dev, dtype=torch.bfloat16)
