@@ -492,6 +492,34 @@ int hymeta_gptq_dequant(const int32_t* qweight, const int32_t* qzeros, const voi
                         int32_t zero_offset, hymeta_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * bf16 linear for decode-sized batches (M <= 64): out = bf16(x W^T + bias), fp32 accumulation,
+ * one rounding; W [N, K] as torch stores a Linear weight.  Replaces the un-quantised linear
+ * method (F.linear through vLLM's ColumnParallelLinear / RowParallelLinear, third party) at the
+ * call sites vllm_hymeta/models/modeling_hymeta.py:249-262,422-430,724-732,858-861 and
+ * vllm_hymeta/model_for_7B/gla_attention.py:118-160 when the weights are not quantised: at these
+ * row counts the weights are the traffic and a library GEMM reads them at 2-3 TB/s.
+ * Needs K % 32 == 0, N % 64 == 0; larger M is HYMETA_ERR_UNSUPPORTED (use a library GEMM).
+ * Split-K meets in fp32 slabs summed in slice order (deterministic): split_k <= 0 lets the
+ * library choose when a workspace is given (size it with hymeta_bf16_gemm_workspace_bytes(M, N, 0),
+ * a bound that does not depend on K) and means 1 without one.
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_bf16_gemm_args {
+  const void* x;          /* bf16 [M, K] */
+  const void* weight;     /* bf16 [N, K] */
+  const void* bias;       /* bf16 [N] or NULL */
+  void* out;              /* bf16 [M, N] */
+  void* workspace;        /* [ticket counters][fp32 slabs], or NULL */
+  size_t workspace_bytes;
+  int32_t M, K, N;
+  int32_t split_k;
+  int64_t x_stride_m, w_stride_n, out_stride_m;
+} hymeta_bf16_gemm_args;
+
+int hymeta_bf16_gemm_split_k(int32_t M, int32_t K, int32_t N);
+size_t hymeta_bf16_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
+int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * W8A8 int8 linear: per-output-channel int8 weights, dynamic per-token int8
  * activations (compressed-tensors "W8A8" as written by hf_model/quant_w8a8.py:121-132
  * with llmcompressor; executed in the reference by vLLM's scaled_int8_quant +

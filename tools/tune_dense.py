@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Time the decode-sized bf16 linear against the library GEMM at the 7B shapes (needs a GPU)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vllm-hymeta_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa: E402
+from tune_quant import bench  # noqa: E402
+from vllm_hymeta import hip_ops  # noqa: E402
+
+dev = torch.device("cuda")
+SHAPES = [("qkv", 3584, 4608), ("o", 3584, 3584), ("gate_up", 3584, 37888), ("down", 18944, 3584)]
+for M in (1, 16, 64):
+    for name, K, N in SHAPES:
+        x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        # cold weights, as inside a model step: rotate over copies that together exceed the 256 MB
+        # last-level cache several times
+        copies = max(2, min(40, int(1.2e9 // (N * K * 2))))
+        ws = [(torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(copies)]
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+
+        def lib():
+            for w in ws:
+                torch.nn.functional.linear(x, w)
+
+        t_lib = bench(lib, iters=2) / copies
+        line = f"M={M:3d} {name:8s} library {t_lib:7.1f} us ({N * K * 2 / t_lib / 1e6:5.2f} TB/s)"
+        for sk in [0] + [int(s) for s in os.environ.get("SPLITS", "").split(",") if s]:
+            def mine(sk=sk):
+                for w in ws:
+                    hip_ops.bf16_gemm(x, w, out=out, split_k=sk)
+
+            t = bench(mine, iters=2) / copies
+            line += f" | split {sk}: {t:6.1f} us ({N * K * 2 / t / 1e6:5.2f} TB/s)"
+        print(line, flush=True)
+        del ws

@@ -59,6 +59,28 @@ __device__ __forceinline__ float logsigmoidf(float x) {
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// Split-K meeting point of the skinny GEMMs: every K-slice workgroup of an output tile stores its
+// fp32 partial tile ("slab") with plain stores, publishes it with one agent-scope release and
+// draws a ticket; the workgroup that draws the last ticket acquires and returns true: it sums the
+// slabs and writes the tile.  `flag` is one int of the caller's (already idle) LDS array.
+__device__ __forceinline__ bool last_arriver(int* counter, int splits, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = ticket == splits - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *flag = last ? 1 : 0;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
 // Entry points report launch failures through hipGetLastError(), which is sticky per host thread:
 // a benign error left behind by an earlier runtime call of the host program (a not-ready event
 // or stream query, for instance) must not be mistaken for ours, so the state is cleared first.

@@ -39,28 +39,6 @@ __device__ __forceinline__ float load_scale(const void* p, int64_t idx, int dtyp
 
 constexpr int kColsPerBlock = 64;  // output columns per workgroup: lane n owns columns 4n .. 4n+3
 
-// Split-K meeting point shared by both GEMMs: every K-slice workgroup of an output tile stores its
-// fp32 partial tile ("slab") with plain stores, publishes it with one agent-scope release and
-// draws a ticket; the workgroup that draws the last ticket acquires and returns true: it sums the
-// slabs and writes the tile.  `flag` is one int of the caller's (already idle) LDS array.
-__device__ __forceinline__ bool last_arriver(int* counter, int splits, int* flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = ticket == splits - 1;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    *flag = last ? 1 : 0;
-  }
-  __syncthreads();
-  return *flag != 0;
-}
-
 }  // namespace
 
 // grid = (N / 64, ceil(M / (16 MT)), splits); 256 threads: the 4 waves take alternate groups of

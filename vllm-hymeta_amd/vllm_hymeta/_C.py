@@ -156,6 +156,14 @@ class GptqGemmArgs(C.Structure):
     ]
 
 
+class Bf16GemmArgs(C.Structure):
+    _fields_ = [
+        ("x", _ptr), ("weight", _ptr), ("bias", _ptr), ("out", _ptr), ("workspace", _ptr), ("workspace_bytes", _sz),
+        ("M", _i32), ("K", _i32), ("N", _i32), ("split_k", _i32),
+        ("x_stride_m", _i64), ("w_stride_n", _i64), ("out_stride_m", _i64),
+    ]
+
+
 class W8A8GemmArgs(C.Structure):
     _fields_ = [
         ("x", _ptr), ("qweight", _ptr), ("w_scale", _ptr), ("bias", _ptr), ("out", _ptr),
@@ -215,6 +223,9 @@ _SIGNATURES = {
     "hymeta_gptq_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "hymeta_gptq_gemm": (C.c_int, [C.POINTER(GptqGemmArgs), _ptr]),
     "hymeta_gptq_dequant": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    "hymeta_bf16_gemm": (C.c_int, [C.POINTER(Bf16GemmArgs), _ptr]),
+    "hymeta_bf16_gemm_split_k": (C.c_int, [_i32, _i32, _i32]),
+    "hymeta_bf16_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "hymeta_w8a8_gemm": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),
     "hymeta_moe_route": (C.c_int, [C.POINTER(MoeRouteArgs), _ptr]),
     "hymeta_moe_gemm": (C.c_int, [C.POINTER(MoeGemmArgs), _ptr]),

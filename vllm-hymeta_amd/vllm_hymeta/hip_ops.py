@@ -598,6 +598,50 @@ def gptq_dequant(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tens
     return out
 
 
+BF16_GEMM_MAX_ROWS = 64
+
+
+def bf16_gemm_preferred(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Where the kernel beats the library GEMM (measured with cold weights): deep, narrow linears,
+    which the library does not cut along K."""
+    return bf16_gemm_supported(x, weight) and weight.shape[1] >= 4 * weight.shape[0]
+
+
+def bf16_gemm_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Shapes the decode-sized bf16 linear kernel takes."""
+    return (x.dim() == 2 and 0 < x.shape[0] <= BF16_GEMM_MAX_ROWS and x.is_cuda and x.dtype == torch.bfloat16
+            and weight.dtype == torch.bfloat16 and x.stride(1) == 1 and weight.stride(1) == 1
+            and weight.shape[1] % 32 == 0 and weight.shape[0] % 64 == 0
+            and x.stride(0) % 8 == 0 and weight.stride(0) % 8 == 0)
+
+
+def bf16_gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None, split_k: int = 0) -> torch.Tensor:
+    """x bf16 [M <= 64, K] @ weight bf16 [N, K]^T (+ bias bf16 [N]) -> bf16 [M, N]; ``split_k`` 0: library's choice."""
+    _dev(x, weight, bias, out)
+    M, K = x.shape
+    N = weight.shape[0]
+    _require(x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [M, K]")
+    _require(weight.dtype == torch.bfloat16 and weight.stride(1) == 1 and weight.shape == (N, K),
+             "weight must be row-contiguous bf16 [N, K]")
+    if bias is not None:
+        _require(bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N, "bias must be bf16 [N]")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    a = _C.Bf16GemmArgs()
+    a.x, a.weight, a.bias, a.out = _p(x), _p(weight), _p(bias), _p(out)
+    a.M, a.K, a.N = M, K, N
+    a.x_stride_m, a.w_stride_n, a.out_stride_m = x.stride(0), weight.stride(0), out.stride(0)
+    lib = _C.load()
+    a.split_k = max(int(split_k), 0)
+    nbytes = int(lib.hymeta_bf16_gemm_workspace_bytes(M, N, a.split_k))
+    if nbytes > 0:
+        ws = _workspace(x.device, nbytes, "bf16_gemm")
+        a.workspace, a.workspace_bytes = _p(ws), ws.numel()
+    _C.check(lib.hymeta_bf16_gemm(C.byref(a), _stream(x)), "hymeta_bf16_gemm")
+    return out
+
+
 def w8a8_gemm(x: torch.Tensor, qweight: torch.Tensor, w_scale: torch.Tensor,
               bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x bf16 [M,K] -> dynamic per-token int8; qweight int8 [N,K]; w_scale fp32 [N] -> bf16 [M,N]."""

@@ -51,6 +51,10 @@ class HymetaLinear(torch.nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.kind == "bf16":
+            # decode-sized batches of a deep, narrow linear (the 7B down projection): K cut across
+            # workgroups; everything else is a plain library GEMM
+            if hip_ops.bf16_gemm_preferred(x, self.weight):
+                return hip_ops.bf16_gemm(x, self.weight, self.bias)
             return torch.nn.functional.linear(x, self.weight, self.bias)
         if self.kind == "gptq":
             if x.shape[0] > GPTQ_EXPAND_ROWS:
