@@ -337,8 +337,23 @@ typedef struct hymeta_swa_prefill_args {
   int64_t meta_q_stride_t, meta_q_stride_h;
   int64_t meta_stride_t, meta_stride_h;
   float scale;
+  /* Key slices (a short chunk of a long sequence leaves most compute units without a workgroup:
+   * the visible keys of a query block are then cut into num_splits slices whose partial results a
+   * second launch merges).  num_splits <= 0: the library chooses -- 1 unless `workspace` holds
+   * hymeta_meta_swa_prefill_workspace_bytes(out rows, num_heads, 0) bytes; 1: never; 2..4: as
+   * given (HYMETA_ERR_WORKSPACE without the room).  max_seqlen_k: upper bound on any key length,
+   * 0 = unknown (then layers without a window are never sliced). */
+  void* workspace;
+  size_t workspace_bytes;
+  int32_t num_splits;
+  int32_t max_seqlen_k;
 } hymeta_swa_prefill_args;
 
+/* The library's choice of key slices; meta_rows = num_meta when meta_query is given, else 0. */
+int hymeta_meta_swa_prefill_splits(int32_t total_q, int32_t num_heads, int32_t num_meta, int32_t meta_rows,
+                                   int32_t window_left, int32_t max_seqlen_k);
+/* out_rows = total_q (+ num_meta with meta_query); num_splits <= 0: room for any choice. */
+size_t hymeta_meta_swa_prefill_workspace_bytes(int32_t out_rows, int32_t num_heads, int32_t num_splits);
 int hymeta_meta_swa_prefill(const hymeta_swa_prefill_args* args, hymeta_stream_t stream);
 
 

@@ -139,3 +139,52 @@ def test_swa_prefill_growing_scores(ramp):
                                        window_left=wl)
         torch.cuda.synchronize()
         assert_bf16_close(out.cpu(), ref, f"prefill, scores growing x{ramp}, window {wl}")
+
+
+@pytest.mark.parametrize("splits", [2, 3, 4, 0])
+@pytest.mark.parametrize("wl,M,with_q2", [(-1, 32, True), (200, 0, False), (63, 32, False)])
+def test_swa_prefill_key_slices(splits, wl, M, with_q2):
+    """A short chunk of long sequences with its visible keys cut into slices (partials + merge)
+    equals the oracle like the single pass does; slices may be empty (short sequences, early rows)."""
+    from oracle import meta_swa_varlen_ref
+    from vllm_hymeta import hip_ops
+
+    H, Hkv, lens = 2, 1, [700, 3, 130]
+    T = sum(lens)
+    g_ = gen(9)
+    q, k, v = randn_bf16(g_, T, H, D), randn_bf16(g_, T, Hkv, D), randn_bf16(g_, T, Hkv, D)
+    k2 = randn_bf16(g_, M, Hkv, D) if M else None
+    v2 = randn_bf16(g_, M, Hkv, D) if M else None
+    q2 = randn_bf16(g_, M, H, D) if with_q2 else None
+    cu = _cu(lens)
+    ref = meta_swa_varlen_ref(q, k, v, cu, cu, k2, v2, q2, wl)
+    dev = lambda t: None if t is None else t.cuda()
+    out = hip_ops.meta_swa_prefill(q.cuda(), cu.cuda(), max(lens), key=k.cuda(), value=v.cuda(), cu_seqlens_k=cu.cuda(),
+                                   meta_query=dev(q2), meta_key=dev(k2), meta_value=dev(v2), window_left=wl,
+                                   max_seqlen_k=max(lens), num_splits=splits)
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), ref, f"swa prefill, {splits} key slices, wl={wl} M={M}")
+
+
+def test_swa_prefill_key_slices_paged_chunk():
+    """Chunked prefill through the block table with the library's own choice of slices."""
+    from oracle.meta_swa import meta_swa_paged_prefill_ref
+    from vllm_hymeta import hip_ops
+
+    H, Hkv, bs, M, wl = 2, 1, 16, 32, 1000
+    seq_lens, q_lens = [1500], [100]
+    g_ = gen(10)
+    nblk = (seq_lens[0] + bs - 1) // bs
+    bt = torch.randperm(nblk + 2, generator=g_)[:nblk].to(torch.int32).view(1, -1)
+    kc, vc = randn_bf16(g_, nblk + 2, bs, Hkv, D), randn_bf16(g_, nblk + 2, bs, Hkv, D)
+    q = randn_bf16(g_, q_lens[0], H, D)
+    k2, v2 = randn_bf16(g_, M, Hkv, D), randn_bf16(g_, M, Hkv, D)
+    cuq = _cu(q_lens)
+    ref = meta_swa_paged_prefill_ref(q, kc, vc, cuq, seq_lens, bt, k2, v2, wl)
+    lib = hip_ops._C.load()
+    assert lib.hymeta_meta_swa_prefill_splits(q_lens[0], H, M, 0, wl, seq_lens[0]) == 2      # 20 tiles at most, 8 or more per slice
+    out = hip_ops.meta_swa_prefill(q.cuda(), cuq.cuda(), q_lens[0], key_cache=kc.cuda(), value_cache=vc.cuda(),
+                                   block_tables=bt.cuda(), seq_lens_k=torch.tensor(seq_lens, dtype=torch.int32).cuda(),
+                                   meta_key=k2.cuda(), meta_value=v2.cuda(), window_left=wl, max_seqlen_k=seq_lens[0])
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), ref, "paged chunk, key slices")

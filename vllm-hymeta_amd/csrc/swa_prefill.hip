@@ -67,8 +67,14 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) {
 
 // grid = (ceil(max_seqlen_q / (32 NW)), num_seqs (+1: the meta-query rows), num_heads); NW waves of
 // 32 queries per workgroup: 8 by default, 4 when that leaves compute units without a workgroup.
+//
+// splits > 1 (few workgroups, long key ranges: a short chunk of a long sequence): blockIdx.x also
+// numbers the key slice; a workgroup walks only its share of the tiles and leaves an un-normalised
+// partial (fp32 O, the reference exponent and the row sum per query) in the workspace; a second
+// launch merges the slices in slice order.
 template <bool PAGED, int NW>
-__global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa_prefill_args a, float scale_log2) {
+__global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa_prefill_args a, float scale_log2, int splits,
+                                                                      int64_t part_rows) {
   constexpr int kRowsPerBlock = kRowsPerWave * NW;
   constexpr int kPasses = 16 / NW;     // staging passes: 4 NW key rows of a 64-key tile per pass
 
@@ -112,7 +118,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
     q_stride_t = a.q_stride_t;
     out_first = out_row0 + q_first;
   }
-  const int blk0 = blockIdx.x * kRowsPerBlock;
+  const int split = splits > 1 ? blockIdx.x % splits : 0;
+  const int blk0 = (splits > 1 ? blockIdx.x / splits : blockIdx.x) * kRowsPerBlock;
   if (blk0 >= Lq) return;                      // workgroup-uniform
   const int row0 = blk0 + wave * kRowsPerWave;  // first query of this wave
   const bool active = row0 < Lq;               // idle waves still stage tiles and meet the barriers
@@ -161,7 +168,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
       T_hi = k_hi / kTileK;
     }
   }
-  const int ntiles = meta_tiles + (T_hi - T_lo + 1);
+  const int all_tiles = meta_tiles + (T_hi - T_lo + 1);
+  // this workgroup's share of the tile sequence (all of it when there is one slice)
+  const int per_split = (all_tiles + splits - 1) / splits;
+  const int t_begin = min(split * per_split, all_tiles);
+  const int ntiles = min(t_begin + per_split, all_tiles);     // one past the last tile walked here
 
   const uint16_t* kglob = nullptr;
   const uint16_t* vglob = nullptr;
@@ -218,13 +229,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
         vreg[i] = ld16(vp);
       }
     } else {
-      if (tile == 0 || tile == meta_tiles) {       // workgroup-uniform, at most twice per workgroup
+      if (tile == t_begin || tile == meta_tiles) { // workgroup-uniform, at most twice per workgroup
         const bool meta = tile < meta_tiles;
         const uint16_t* kb = meta ? reinterpret_cast<const uint16_t*>(a.meta_key) + static_cast<int64_t>(kvh) * a.meta_stride_h : kglob;
         const uint16_t* vb = meta ? reinterpret_cast<const uint16_t*>(a.meta_value) + static_cast<int64_t>(kvh) * a.meta_stride_h : vglob;
         const int64_t ks = meta ? a.meta_stride_t : a.k_stride_t, vs = meta ? a.meta_stride_t : a.v_stride_t;
         plimit = meta ? M : Lk;
-        prow = (meta ? 0 : T_lo * kTileK) + sr;
+        prow = (meta ? tile : T_lo + tile - meta_tiles) * kTileK + sr;
         kstep = ks * kTileK, vstep = vs * kTileK;
 #pragma unroll
         for (int i = 0; i < kPasses; ++i) {
@@ -267,11 +278,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
     }
   };
 
-  if (ntiles > 0) {
-    issue(0);
+  if (ntiles > t_begin) {
+    issue(t_begin);
     commit(0);
   }
-  if (ntiles > 1) issue(1);
+  if (ntiles > t_begin + 1) issue(t_begin + 1);
   // Pin the Q fragments as landed here: otherwise the first MFMA of EVERY tile waits for all
   // outstanding global loads (the just-issued next tile included) on behalf of the Q loads above.
 #pragma unroll
@@ -280,8 +291,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qt][ks]));
   __syncthreads();
 
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int buf = tile & 1;
+  for (int tile = t_begin; tile < ntiles; ++tile) {
+    const int buf = (tile - t_begin) & 1;
     // Tile t + 1 (loaded during the previous tile) goes to the other buffer now, behind the barrier
     // that ended its last reads, and tile t + 2 is requested at once: the stores overlap the
     // other waves' matrix work instead of standing between every wave's last MFMA and the barrier.
@@ -421,6 +432,31 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
     __syncthreads();
   }
 
+  if (splits > 1) {
+    // partial of this key slice: O un-normalised (fp32), per query its reference exponent (the
+    // lanes of the first 16-lane group hold the queries' references) and its row sum
+    float* po = static_cast<float*>(a.workspace);
+    float* pm = po + static_cast<int64_t>(splits) * part_rows * a.num_heads * kHeadDim;
+    float* pl = pm + static_cast<int64_t>(splits) * part_rows * a.num_heads;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      if (c == 0) {
+        const int qr = row0 + 16 * qt + n;
+        if (qr < Lq) pm[(split * part_rows + out_first + qr) * a.num_heads + h] = m_run[qt] == -INFINITY ? -INFINITY : ms_run[qt];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qr = row0 + 16 * qt + 4 * c + r;
+        if (qr >= Lq) continue;
+        const int64_t prow_ = (split * part_rows + out_first + qr) * a.num_heads + h;
+        if (n == 0) pl[prow_] = l_acc[qt][r];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) po[prow_ * kHeadDim + 16 * t + n] = o[qt][t][r];
+      }
+    }
+    return;
+  }
+
   // epilogue: normalise, stage the wave's 32 x 128 outputs in LDS (the K/V images are free after
   // the loop's last barrier), store whole rows.
   char* ost = reinterpret_cast<char*>(&sm) + wave * (kRowsPerWave * kOPitch);
@@ -449,9 +485,66 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void swa_prefill_kernel(hymeta_swa
   }
 }
 
+// One wave per (output row, head): out = sum_s 2^(m_s - m) O_s / sum_s 2^(m_s - m) l_s, slices in order.
+__global__ __launch_bounds__(256) void swa_prefill_merge_kernel(hymeta_swa_prefill_args a, int splits, int64_t part_rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pair = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);     // row * H + head
+  if (pair >= part_rows * a.num_heads) return;
+  const float* po = static_cast<const float*>(a.workspace);
+  const float* pm = po + static_cast<int64_t>(splits) * part_rows * a.num_heads * kHeadDim;
+  const float* pl = pm + static_cast<int64_t>(splits) * part_rows * a.num_heads;
+  float m = -INFINITY;
+  for (int s = 0; s < splits; ++s) m = fmaxf(m, pm[s * part_rows * a.num_heads + pair]);
+  float o0 = 0.f, o1 = 0.f, l = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const float ms = pm[s * part_rows * a.num_heads + pair];
+    if (ms == -INFINITY) continue;           // a slice without a visible key for this query
+    const float w = __builtin_amdgcn_exp2f(ms - m);
+    const f32x2 v = *reinterpret_cast<const f32x2*>(po + (s * part_rows * a.num_heads + pair) * kHeadDim + 2 * lane);
+    o0 += w * v[0];
+    o1 += w * v[1];
+    l += w * pl[s * part_rows * a.num_heads + pair];
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  const int64_t row = pair / a.num_heads;
+  const int head = static_cast<int>(pair % a.num_heads);
+  uint32_t* op = reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(a.out) + row * a.out_stride_t +
+                                             static_cast<int64_t>(head) * a.out_stride_h) + lane;
+  *op = pack_bf16x2(o0 * inv, o1 * inv);
+}
+
 }  // namespace hymeta
 
 using namespace hymeta;
+
+constexpr int kMaxPrefillSplits = 4;
+
+static size_t prefill_partial_bytes(int64_t rows, int heads, int splits) {
+  return static_cast<size_t>(splits) * rows * heads * (kHeadDim + 2) * sizeof(float);
+}
+
+// Key slices for a call: only when 128-query workgroups leave most compute units idle and every
+// slice still walks a fair number of tiles (a bound from the window or max_seqlen_k; unknown: 1).
+extern "C" int hymeta_meta_swa_prefill_splits(int32_t total_q, int32_t num_heads, int32_t num_meta, int32_t meta_rows,
+                                              int32_t window_left, int32_t max_seqlen_k) {
+  if (total_q <= 0 || num_heads <= 0) return 1;
+  const int64_t wgs256 = (static_cast<int64_t>(total_q) + 255) / 256 * num_heads + static_cast<int64_t>(num_heads) * ((meta_rows + 255) / 256);
+  if (wgs256 >= 128) return 1;
+  const int64_t wgs128 = (static_cast<int64_t>(total_q) + 127) / 128 * num_heads + static_cast<int64_t>(num_heads) * ((meta_rows + 127) / 128);
+  int64_t keys = max_seqlen_k > 0 ? max_seqlen_k : -1;
+  if (window_left >= 0 && (keys < 0 || window_left + 128 < keys)) keys = window_left + 128;
+  if (keys < 0) return 1;
+  const int64_t tiles = (keys + kTileK - 1) / kTileK + 1 + (num_meta + kTileK - 1) / kTileK;
+  int64_t splits = 256 / (wgs128 > 0 ? wgs128 : 1);
+  if (splits > tiles / 8) splits = tiles / 8;
+  if (splits > kMaxPrefillSplits) splits = kMaxPrefillSplits;
+  return splits < 2 ? 1 : static_cast<int>(splits);
+}
+
+extern "C" size_t hymeta_meta_swa_prefill_workspace_bytes(int32_t out_rows, int32_t num_heads, int32_t num_splits) {
+  if (out_rows <= 0 || num_heads <= 0 || num_splits == 1) return 0;
+  return prefill_partial_bytes(out_rows, num_heads, num_splits <= 0 ? kMaxPrefillSplits : num_splits);
+}
 
 extern "C" int hymeta_meta_swa_prefill(const hymeta_swa_prefill_args* args, hymeta_stream_t stream) {
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
@@ -502,15 +595,31 @@ extern "C" int hymeta_meta_swa_prefill(const hymeta_swa_prefill_args* args, hyme
                          (a.meta_query != nullptr ? static_cast<int64_t>(a.num_heads) * ((a.num_meta + 255) / 256) : 0);
   const int nw = wgs256 < 128 ? 4 : 8;
   const int rows_per_block = kRowsPerWave * nw;
-  dim3 grid((max_rows + rows_per_block - 1) / rows_per_block, seqs + (a.meta_query != nullptr ? 1 : 0), a.num_heads);
+  // key slices: the library's choice needs a workspace that holds it (without one: a single slice)
+  const int64_t out_rows = static_cast<int64_t>(have_rows ? a.total_q : 0) + (a.meta_query != nullptr ? a.num_meta : 0);
+  int splits = a.num_splits > 0 ? a.num_splits
+                                : hymeta_meta_swa_prefill_splits(have_rows ? a.total_q : 0, a.num_heads, a.num_meta,
+                                                                 a.meta_query != nullptr ? a.num_meta : 0, a.window_left, a.max_seqlen_k);
+  if (splits > kMaxPrefillSplits) return HYMETA_ERR_UNSUPPORTED;
+  if (splits > 1 && (a.workspace == nullptr || a.workspace_bytes < prefill_partial_bytes(out_rows, a.num_heads, splits))) {
+    if (a.num_splits > 1) return HYMETA_ERR_WORKSPACE;
+    splits = 1;
+  }
+  if (splits > 1 && reinterpret_cast<uintptr_t>(a.workspace) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  dim3 grid((max_rows + rows_per_block - 1) / rows_per_block * splits, seqs + (a.meta_query != nullptr ? 1 : 0), a.num_heads);
   hipStream_t s = begin_launches(stream);
   const float sl2 = scale * kLog2e;
   if (paged) {
-    if (nw == 8) hipLaunchKernelGGL((swa_prefill_kernel<true, 8>), grid, dim3(512), 0, s, a, sl2);
-    else hipLaunchKernelGGL((swa_prefill_kernel<true, 4>), grid, dim3(256), 0, s, a, sl2);
+    if (nw == 8) hipLaunchKernelGGL((swa_prefill_kernel<true, 8>), grid, dim3(512), 0, s, a, sl2, splits, out_rows);
+    else hipLaunchKernelGGL((swa_prefill_kernel<true, 4>), grid, dim3(256), 0, s, a, sl2, splits, out_rows);
   } else {
-    if (nw == 8) hipLaunchKernelGGL((swa_prefill_kernel<false, 8>), grid, dim3(512), 0, s, a, sl2);
-    else hipLaunchKernelGGL((swa_prefill_kernel<false, 4>), grid, dim3(256), 0, s, a, sl2);
+    if (nw == 8) hipLaunchKernelGGL((swa_prefill_kernel<false, 8>), grid, dim3(512), 0, s, a, sl2, splits, out_rows);
+    else hipLaunchKernelGGL((swa_prefill_kernel<false, 4>), grid, dim3(256), 0, s, a, sl2, splits, out_rows);
+  }
+  if (splits > 1) {
+    if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+    const int64_t pairs = out_rows * a.num_heads;
+    hipLaunchKernelGGL(swa_prefill_merge_kernel, dim3(static_cast<unsigned>((pairs + 3) / 4)), dim3(256), 0, s, a, splits, out_rows);
   }
   return launch_status();
 }

@@ -114,6 +114,7 @@ class SwaPrefillArgs(C.Structure):
         ("meta_q_stride_t", _i64), ("meta_q_stride_h", _i64),
         ("meta_stride_t", _i64), ("meta_stride_h", _i64),
         ("scale", _f32),
+        ("workspace", _ptr), ("workspace_bytes", _sz), ("num_splits", _i32), ("max_seqlen_k", _i32),
     ]
 
 
@@ -215,6 +216,8 @@ _SIGNATURES = {
     "hymeta_meta_swa_paged_decode_splits": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "hymeta_meta_swa_paged_decode": (C.c_int, [C.POINTER(PagedDecodeArgs), _ptr]),
     "hymeta_meta_swa_prefill": (C.c_int, [C.POINTER(SwaPrefillArgs), _ptr]),
+    "hymeta_meta_swa_prefill_splits": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "hymeta_meta_swa_prefill_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "hymeta_rope_neox": (C.c_int, [C.POINTER(RopeArgs), _ptr]),
     "hymeta_rms_sumsq2": (C.c_int, [C.POINTER(CombineArgs), _ptr]),
     "hymeta_hybrid_combine": (C.c_int, [C.POINTER(CombineArgs), _ptr]),

@@ -70,11 +70,12 @@ def metatoken_flash_attn_varlen_func(
         out = hip_ops.meta_swa_prefill(
             q1, cu_seqlens_q, max_seqlen_q, key_cache=k1, value_cache=v1, block_tables=block_tables,
             seq_lens_k=seq_lens_k, meta_query=q2, meta_key=k2, meta_value=v2,
-            window_left=window_size[0], scale=softmax_scale)
+            window_left=window_size[0], scale=softmax_scale, max_seqlen_k=max_seqlen_k or 0)
     else:
         out = hip_ops.meta_swa_prefill(
             q1, cu_seqlens_q, max_seqlen_q, key=k1, value=v1, cu_seqlens_k=cu_seqlens_k,
-            meta_query=q2, meta_key=k2, meta_value=v2, window_left=window_size[0], scale=softmax_scale)
+            meta_query=q2, meta_key=k2, meta_value=v2, window_left=window_size[0], scale=softmax_scale,
+            max_seqlen_k=max_seqlen_k or 0)
     return out.unsqueeze(0)
 
 

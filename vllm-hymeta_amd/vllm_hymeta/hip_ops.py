@@ -371,9 +371,13 @@ def meta_swa_prefill(
     window_left: int = -1,
     scale: Optional[float] = None,
     out: Optional[torch.Tensor] = None,
+    max_seqlen_k: int = 0,
+    num_splits: int = 0,
 ) -> torch.Tensor:
     """q [T,H,D].  Un-paged keys: key/value [Tk,Hkv,D] + cu_seqlens_k; paged keys: caches +
-    block_tables + seq_lens_k.  Returns [(M if meta_query)+T, H, D] bf16, meta rows first."""
+    block_tables + seq_lens_k.  Returns [(M if meta_query)+T, H, D] bf16, meta rows first.
+    ``max_seqlen_k`` (0: unknown) and ``num_splits`` (0: library's choice) steer the key slicing of
+    short chunks of long sequences."""
     _dev(q, cu_seqlens_q, key, value, cu_seqlens_k, key_cache, value_cache, block_tables,
          seq_lens_k, meta_query, meta_key, meta_value, out)
     T, H, D = q.shape
@@ -440,7 +444,15 @@ def meta_swa_prefill(
     a.q_stride_t, a.q_stride_h = q.stride(0), q.stride(1)
     a.out_stride_t, a.out_stride_h = out.stride(0), out.stride(1)
     a.scale = float(scale) if scale is not None else 0.0
-    _C.check(_C.load().hymeta_meta_swa_prefill(C.byref(a), _stream(q)), "hymeta_meta_swa_prefill")
+    lib = _C.load()
+    a.max_seqlen_k = max(int(max_seqlen_k), 0)
+    splits = int(num_splits) if num_splits > 0 else int(lib.hymeta_meta_swa_prefill_splits(
+        T, H, M, M if meta_query is not None else 0, int(window_left), a.max_seqlen_k))
+    a.num_splits = splits
+    if splits > 1:
+        ws = _workspace(q.device, int(lib.hymeta_meta_swa_prefill_workspace_bytes(rows, H, splits)), "swa_prefill")
+        a.workspace, a.workspace_bytes = _p(ws), ws.numel()
+    _C.check(lib.hymeta_meta_swa_prefill(C.byref(a), _stream(q)), "hymeta_meta_swa_prefill")
     return out
 
 

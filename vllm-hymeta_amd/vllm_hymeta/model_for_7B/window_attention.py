@@ -64,11 +64,13 @@ class SlidingWindowAttention(torch.nn.Module):
                 hip_ops.meta_swa_prefill(q[:t_pre], pre.query_start_loc, pre.max_query_len,
                                          key_cache=kv_cache[0], value_cache=kv_cache[1],
                                          block_tables=pre.block_tables, seq_lens_k=pre.seq_lens_tensor,
-                                         window_left=self.window_left, out=out[:t_pre])
+                                         window_left=self.window_left, out=out[:t_pre],
+                                         max_seqlen_k=pre.max_prefill_seq_len or 0)
             else:
                 hip_ops.meta_swa_prefill(q[:t_pre], pre.seq_start_loc, pre.max_prefill_seq_len,
                                          key=k[:t_pre], value=v[:t_pre], cu_seqlens_k=pre.seq_start_loc,
-                                         window_left=self.window_left, out=out[:t_pre])
+                                         window_left=self.window_left, out=out[:t_pre],
+                                         max_seqlen_k=pre.max_prefill_seq_len or 0)
         if T > t_pre:
             dec = attn_metadata.decode_metadata
             hip_ops.meta_swa_paged_decode(q[t_pre:], kv_cache[0], kv_cache[1], dec.seq_lens_tensor,
