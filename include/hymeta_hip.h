@@ -340,7 +340,7 @@ typedef struct hymeta_swa_prefill_args {
   /* Key slices (a short chunk of a long sequence leaves most compute units without a workgroup:
    * the visible keys of a query block are then cut into num_splits slices whose partial results a
    * second launch merges).  num_splits <= 0: the library chooses -- 1 unless `workspace` holds
-   * hymeta_meta_swa_prefill_workspace_bytes(out rows, num_heads, 0) bytes; 1: never; 2..4: as
+   * hymeta_meta_swa_prefill_workspace_bytes(out rows, num_heads, 0) bytes; 1: never; 2..8: as
    * given (HYMETA_ERR_WORKSPACE without the room).  max_seqlen_k: upper bound on any key length,
    * 0 = unknown (then layers without a window are never sliced). */
   void* workspace;

@@ -141,7 +141,7 @@ def test_swa_prefill_growing_scores(ramp):
         assert_bf16_close(out.cpu(), ref, f"prefill, scores growing x{ramp}, window {wl}")
 
 
-@pytest.mark.parametrize("splits", [2, 3, 4, 0])
+@pytest.mark.parametrize("splits", [2, 3, 8, 0])
 @pytest.mark.parametrize("wl,M,with_q2", [(-1, 32, True), (200, 0, False), (63, 32, False)])
 def test_swa_prefill_key_slices(splits, wl, M, with_q2):
     """A short chunk of long sequences with its visible keys cut into slices (partials + merge)

@@ -63,7 +63,8 @@ def swa_paged(chunk, ctx, H, Hkv, M, wl, bs=256):
     sl = torch.tensor([ctx], dtype=torch.int32, device=dev)
     out = torch.empty(chunk, H, D, dtype=torch.bfloat16, device=dev)
     us = bench(lambda: hip_ops.meta_swa_prefill(q, cu, chunk, key_cache=kv[0], value_cache=kv[1], block_tables=bt,
-                                               seq_lens_k=sl, meta_key=k2, meta_value=v2, window_left=wl, out=out))
+                                               seq_lens_k=sl, meta_key=k2, meta_value=v2, window_left=wl, out=out,
+                                               max_seqlen_k=ctx, num_splits=int(os.environ.get("NSPLIT", "0"))))
     import numpy as np
     pos = np.arange(ctx - chunk, ctx)
     vis = np.minimum(pos + 1, wl + 1) if wl >= 0 else pos + 1
@@ -101,6 +102,11 @@ if __name__ == "__main__":
         swa([32768], 7, 1, 128, 4095)
         swa([32768], 7, 1, 128, -1)
         swa([2048] * 8, 28, 4, 0, 4096)
+    if "chunks" in which:
+        for chunk in (256, 512, 1024, 2048, 4096):
+            swa_paged(chunk, 32768, 7, 1, 128, 4095)
+        swa_paged(2048, 32768, 7, 1, 128, -1)
+        swa_paged(2048, 32768, 28, 4, 0, 4096)
     if "paged" in which:
         swa_paged(8192, 32768, 7, 1, 128, 4095)
         swa_paged(2048, 32768, 7, 1, 128, 4095)

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void swa_prefill_merge_kernel(hymeta_swa_prefi
 
 using namespace hymeta;
 
-constexpr int kMaxPrefillSplits = 4;
+constexpr int kMaxPrefillSplits = 8;
 
 static size_t prefill_partial_bytes(int64_t rows, int heads, int splits) {
   return static_cast<size_t>(splits) * rows * heads * (kHeadDim + 2) * sizeof(float);
@@ -535,7 +535,7 @@ extern "C" int hymeta_meta_swa_prefill_splits(int32_t total_q, int32_t num_heads
   if (window_left >= 0 && (keys < 0 || window_left + 128 < keys)) keys = window_left + 128;
   if (keys < 0) return 1;
   const int64_t tiles = (keys + kTileK - 1) / kTileK + 1 + (num_meta + kTileK - 1) / kTileK;
-  int64_t splits = 256 / (wgs128 > 0 ? wgs128 : 1);
+  int64_t splits = 512 / (wgs128 > 0 ? wgs128 : 1);          // two 128-query workgroups fit a compute unit
   if (splits > tiles / 8) splits = tiles / 8;
   if (splits > kMaxPrefillSplits) splits = kMaxPrefillSplits;
   return splits < 2 ? 1 : static_cast<int>(splits);
