@@ -179,6 +179,102 @@ def prefill_side_measurement(dev, L):
     }
 
 
+def shard70b_side_measurement(dev, B=64, ctx=32768, chunk=2048):
+    """One tensor-parallel rank (TP=4: 7 q-heads, 1 kv-head, 128 meta tokens) of the 70B family's
+    attention hot path at 32k context: a decode step of 28 layers (each: GLA decode with the
+    key-derived gate + paged window / full attention over the sequence and the meta keys, KV write
+    fused), and one 2048-token chunk of chunked prefill per layer kind.  Outside the timed region."""
+    from vllm_hymeta import _C, hip_ops
+
+    Hs, Ks, M, W = 7, 1, 128, 4096
+    g = torch.Generator(device="cpu")
+    g.manual_seed(2)
+    bps = (ctx + 1 + BLOCK - 1) // BLOCK
+    nblk = B * bps
+    kvs = [torch.randn(2, nblk, BLOCK, Ks, D, device=dev, dtype=torch.bfloat16) for _ in range(2)]   # alternated: cold reads
+    bt = torch.randperm(nblk, generator=g).to(torch.int32).view(B, bps).to(dev)
+    seq_lens = torch.full((B,), ctx + 1, dtype=torch.int32, device=dev)
+    slots = (bt[:, ctx // BLOCK].long() * BLOCK + ctx % BLOCK).contiguous()
+    meta_k = torch.randn(M, Ks, D, device=dev).to(torch.bfloat16)
+    meta_v = torch.randn(M, Ks, D, device=dev).to(torch.bfloat16)
+    states = [(torch.randn(B, Hs, D, D, device=dev) * 0.1).to(torch.bfloat16) for _ in range(2)]
+    slot_idx = torch.arange(B, dtype=torch.int32, device=dev)
+    qkv = torch.randn(B, (Hs + 2 * Ks) * D, device=dev).to(torch.bfloat16)
+    q, k, v = qkv[:, : Hs * D].view(B, Hs, D), qkv[:, Hs * D:(Hs + Ks) * D].view(B, Ks, D), qkv[:, (Hs + Ks) * D:].view(B, Ks, D)
+    lb = torch.rand(Hs, D, device=dev) * 0.5
+    out = torch.empty(B, Hs, D, device=dev, dtype=torch.bfloat16)
+    full_layers = (3, 10, 17, 24)
+
+    def attn(layer):
+        wl = -1 if layer in full_layers else W - 1
+        kv = kvs[layer & 1]
+        hip_ops.meta_swa_paged_decode(q, kv[0], kv[1], seq_lens, bt, meta_key=meta_k, meta_value=meta_v, window_left=wl,
+                                      max_seqlen_k=ctx + 1, out=out, new_key=k, new_value=v, slot_mapping=slots)
+
+    def gla(layer):
+        gate = dict(gate_mode=_C.GATE_70B_CLAMP, gate_clamp=0.95) if layer % 7 == 0 else \
+            dict(gate_mode=_C.GATE_70B_LOWER_BOUND, lower_bound=lb)
+        hip_ops.gla_decode(q, k, v, None, states[layer & 1], slot_idx, out=out, **gate)
+
+    def step():
+        for layer in range(28):
+            gla(layer)
+            attn(layer)
+
+    def timed(fn, iters=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    t_step = timed(step, 5)
+    t_win, t_full, t_gla = timed(lambda: attn(0)), timed(lambda: attn(3)), timed(lambda: gla(1))
+    # algorithmic bytes of the step: states read + written, visible K/V rows (+ meta) per layer kind
+    b_gla = B * (2 * Hs * D * D * 2)
+    b_win = B * 2 * Ks * D * 2 * (W + M)
+    b_full = B * 2 * Ks * D * 2 * (ctx + 1 + M)
+    step_bytes = 28 * b_gla + 24 * b_win + 4 * b_full
+
+    # chunked prefill: one chunk of one sequence that already holds ctx - chunk keys
+    cq = torch.randn(chunk, Hs, D, device=dev).to(torch.bfloat16)
+    cuq = torch.tensor([0, chunk], dtype=torch.int32, device=dev)
+    sl1 = torch.tensor([ctx], dtype=torch.int32, device=dev)
+    cout = torch.empty(chunk, Hs, D, device=dev, dtype=torch.bfloat16)
+
+    def chunk_attn(wl):
+        hip_ops.meta_swa_prefill(cq, cuq, chunk, key_cache=kvs[0][0], value_cache=kvs[0][1], block_tables=bt[:1], seq_lens_k=sl1,
+                                 meta_key=meta_k, meta_value=meta_v, window_left=wl, out=cout, max_seqlen_k=ctx)
+
+    ck = torch.randn(chunk, Ks, D, device=dev).to(torch.bfloat16)
+    cstate = torch.zeros(1, Hs, D, D, dtype=torch.bfloat16, device=dev)
+    mstate = torch.zeros(Hs, D, D, dtype=torch.bfloat16, device=dev)
+    ctx_len = torch.tensor([ctx - chunk], dtype=torch.int32, device=dev)
+
+    def chunk_gla():
+        hip_ops.gla_prefill_varlen(cq, ck, ck, None, cstate, slot_idx[:1], cuq, chunk, context_lens=ctx_len, meta_state=mstate,
+                                   out=cout, gate_mode=_C.GATE_70B_LOWER_BOUND, lower_bound=lb)
+
+    t_cw, t_cf, t_cg = timed(lambda: chunk_attn(W - 1)), timed(lambda: chunk_attn(-1)), timed(chunk_gla)
+    return {
+        "shape": f"TP=4 rank: {Hs} q-heads, {Ks} kv-head, {M} meta tokens, ctx {ctx}, {B} sequences, block_size {BLOCK}",
+        "decode_ms_per_step": round(t_step, 4),
+        "decode_tokens_per_s": round(B / (t_step * 1e-3), 1),
+        "decode_hbm_gbs": round(step_bytes / (t_step * 1e-3) / 1e9, 1),
+        "window_layer_decode_us": round(t_win * 1e3, 1),
+        "full_layer_decode_us": round(t_full * 1e3, 1),
+        "gla_decode_us": round(t_gla * 1e3, 1),
+        f"chunk{chunk}_window_layer_us": round(t_cw * 1e3, 1),
+        f"chunk{chunk}_full_layer_us": round(t_cf * 1e3, 1),
+        f"chunk{chunk}_gla_us": round(t_cg * 1e3, 1),
+        f"chunk{chunk}_attention_ms_28_layers": round(24 * t_cw + 4 * t_cf + 28 * t_cg, 3),
+    }
+
+
 def model_decode_side_measurement(dev, w, B, s, quant):
     """One decode token for every sequence through the WHOLE 28-layer stack (random-init Hymeta-7B
     geometry): block norms, qkv / gate / output projections and the gated MLP around the same
@@ -409,6 +505,10 @@ def main():
         line["prefill"] = prefill_side_measurement(dev, args.prefill_ctx)
     if world == 1 and not args.no_model:
         line["model_decode"] = {q: model_decode_side_measurement(dev, w, B, total - 1, q) for q in ("bf16", "gptq4")}
+    if world == 1 and not args.no_model:
+        del w
+        torch.cuda.empty_cache()
+        line["shard_70b_tp4"] = shard70b_side_measurement(dev)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(line), flush=True)
