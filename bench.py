@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="decode sequences per GPU")
     ap.add_argument("--ctx", type=int, default=8192)
+    ap.add_argument("--gla-state", choices=("kv_head", "query_head"), default="kv_head",
+                    help="GLA state layout: one state per key/value head (the package's default; the 7 query heads "
+                         "of a group hold identical states) or one per query head (the reference's cache shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="skip the 32k prefill (TTFT) side measurement")
     ap.add_argument("--prefill-ctx", type=int, default=32768)
@@ -78,9 +81,9 @@ def build_workload(args, dev, total_steps):
         slots.append(bt_cpu[:, pos // BLOCK] * BLOCK + pos % BLOCK)
     w["seq_lens"] = [t.to(dev) for t in seq_lens]
     w["slot_mapping"] = [t.to(dev) for t in slots]
-    # GLA recurrent state per layer [slots, H, D, D] bf16 (gla_cache.py:9-33)
-    w["state"] = [(torch.randn(B, H, D, D, device=dev, dtype=torch.float32) * 0.1).to(torch.bfloat16)
-                  for _ in range(N_GLA)]
+    # GLA recurrent state per layer: [slots, H, D, D] bf16 in the reference (gla_cache.py:9-33), whose 7
+    # query heads per group hold identical states; [slots, Hkv, D, D] in this package's model class
+    w["state"] = gla_states(B, HKV if args.gla_state == "kv_head" else H, dev)
     w["slot_idx"] = torch.arange(B, dtype=torch.int32, device=dev)
     w["g_norm"] = torch.ones(D, dtype=torch.bfloat16, device=dev)
     # fused qkv(+gk) projection outputs of the step (synthetic), one buffer per layer kind
@@ -92,6 +95,10 @@ def build_workload(args, dev, total_steps):
     w["max_seqlen_k"] = max_k
     w["splits"] = hip_ops.paged_decode_splits(B, HKV, max_k, WINDOW, 0)
     return w
+
+
+def gla_states(B, heads, dev):
+    return [(torch.randn(B, heads, D, D, device=dev, dtype=torch.float32) * 0.1).to(torch.bfloat16) for _ in range(N_GLA)]
 
 
 def split_qkv(buf, B):
@@ -137,7 +144,7 @@ def prefill_side_measurement(dev, L):
     k = qkv[:, H * D:(H + HKV) * D].view(L, HKV, D)
     v = qkv[:, (H + HKV) * D:].view(L, HKV, D)
     gk = torch.randn(L, HKV, D, generator=g).to(torch.bfloat16).to(dev)
-    state = torch.zeros(1, H, D, D, dtype=torch.bfloat16, device=dev)
+    state = torch.zeros(1, HKV, D, D, dtype=torch.bfloat16, device=dev)
     slot = torch.zeros(1, dtype=torch.int32, device=dev)
     cu = torch.tensor([0, L], dtype=torch.int32, device=dev)
     ctx0 = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -501,6 +508,25 @@ def main():
             "avg_launch_ms": round(kern_ms, 5),
         },
     }
+    line["config"]["gla_state"] = ("one state per kv-head, shared by its 7 query heads (identical in the reference)"
+                                   if args.gla_state == "kv_head" else "one state per query head (the reference's cache shape)")
+    if world == 1 and not args.no_model:
+        # the same step with the other state layout, outside the timed region
+        other = H if args.gla_state == "kv_head" else HKV
+        kept, w["state"] = w["state"], gla_states(B, other, dev)
+        for s in range(args.warmup):
+            run_step(w, s, B)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(args.warmup, total):
+            run_step(w, s, B)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        w["state"] = kept
+        line["other_gla_state_layout"] = {"gla_state": "per query head" if other == H else "per kv-head",
+                                          "ms_per_step": round(el / args.steps * 1e3, 4),
+                                          "tokens_per_s": round(B * args.steps / el, 1)}
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_prefill:
         line["prefill"] = prefill_side_measurement(dev, args.prefill_ctx)
     if world == 1 and not args.no_model:

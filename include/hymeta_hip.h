@@ -82,6 +82,16 @@ int hymeta_abi_version(void);
  * Optional fused prologue (gate_mode) and epilogue (per-head RMS norm over Dv
  * with weight out_norm_weight[Dv] and out_norm_eps, the g_norm of
  * vllm_hymeta/model_for_7B/gla_attention.py:233).
+ *
+ * One state per key/value head (state_heads == num_kv_heads).  The reference
+ * expands k, v and g to the query heads (repeat_kv,
+ * vllm_hymeta/model_for_7B/gla_attention.py:246-282) and keeps one state per
+ * query head; where the gate does not depend on the query head (every gate mode
+ * but HYMETA_GATE_70B_LOWER_BOUND) the states of the query heads of one group
+ * receive the same update at every token and are equal for ever.  With
+ * state_heads == num_kv_heads the tensor is [slots, num_kv_heads, Dk, Dv], the
+ * group's state is read and written once per step and contracted with every
+ * query of the group; out is bit-identical to the per-query-head layout.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_gla_decode_args {
   const void* q;            /* bf16 [batch, num_heads,    head_dim] */
@@ -89,7 +99,7 @@ typedef struct hymeta_gla_decode_args {
   const void* v;            /* bf16 [batch, num_kv_heads, head_dim] */
   const void* g;            /* g_dtype [batch, num_kv_heads, head_dim]; may be NULL for HYMETA_GATE_70B_* */
   void* out;                /* bf16 [batch, num_heads, head_dim] */
-  void* state;              /* state_dtype [slots, num_heads, head_dim, head_dim] */
+  void* state;              /* state_dtype [slots, state_heads, head_dim, head_dim] */
   const int32_t* slot_idx;  /* [batch] */
   const float* lower_bound;     /* fp32 [num_heads, head_dim], HYMETA_GATE_70B_LOWER_BOUND only */
   const void* out_norm_weight;  /* bf16 [head_dim] or NULL (no epilogue norm) */
@@ -110,6 +120,8 @@ typedef struct hymeta_gla_decode_args {
   float gate_normalizer;    /* HYMETA_GATE_7B, 16 in the reference */
   float gate_clamp;         /* HYMETA_GATE_70B_CLAMP, 0.95 in the reference */
   float out_norm_eps;
+  int32_t state_heads;      /* heads the state tensor holds: 0 or num_heads = one state per query head (the
+                             * reference's layout); num_kv_heads = one state per key/value head, see above */
 } hymeta_gla_decode_args;
 
 int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stream_t stream);
@@ -140,6 +152,12 @@ int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stream_t stream
  *   num_segments == 0, workspace != NULL   : hymeta_gla_prefill_segments() decides
  *   num_segments == 0, workspace == NULL   : single run
  *   num_segments  > 1                      : as given (clamped to the chunk count)
+ *
+ * With one state per key/value head (state_heads == num_kv_heads < num_heads)
+ * the query heads of a group run as separate workgroups that all read the
+ * group's initial state, so a single-run call stages the final states in the
+ * workspace and a second launch commits them to state[slot]: the workspace is
+ * then required for every segment count (size: the function below).
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_gla_prefill_args {
   const void* q;            /* bf16 [total_tokens, num_heads,    head_dim] */
@@ -147,11 +165,11 @@ typedef struct hymeta_gla_prefill_args {
   const void* v;            /* bf16 [total_tokens, num_kv_heads, head_dim] */
   const void* g;            /* g_dtype [total_tokens, num_kv_heads, head_dim] */
   void* out;                /* bf16 [total_tokens, num_heads, head_dim] */
-  void* state;              /* state_dtype [slots, num_heads, head_dim, head_dim] */
+  void* state;              /* state_dtype [slots, state_heads, head_dim, head_dim] */
   const int32_t* slot_idx;      /* [num_seqs] */
   const int32_t* cu_seqlens;    /* [num_seqs + 1] */
   const int32_t* context_lens;  /* [num_seqs] or NULL */
-  const void* meta_state;       /* state_dtype [num_heads, head_dim, head_dim] or NULL */
+  const void* meta_state;       /* state_dtype [state_heads, head_dim, head_dim] or NULL */
   const float* lower_bound;     /* as in hymeta_gla_decode_args */
   const void* out_norm_weight;  /* as in hymeta_gla_decode_args */
   int32_t num_seqs;
@@ -177,12 +195,14 @@ typedef struct hymeta_gla_prefill_args {
   void* workspace;          /* device scratch, 16-byte aligned, or NULL */
   size_t workspace_bytes;
   int32_t num_segments;     /* see above */
+  int32_t state_heads;      /* as in hymeta_gla_decode_args; state and meta_state hold that many heads */
 } hymeta_gla_prefill_args;
 
 /* Segment count the library would choose for this shape (1 = single run). */
 int hymeta_gla_prefill_segments(int32_t num_seqs, int32_t num_heads, int32_t max_seqlen);
-/* Workspace size for a call with that many segments (0 when num_segments <= 1). */
-size_t hymeta_gla_prefill_workspace_bytes(int32_t num_seqs, int32_t num_heads, int32_t num_segments);
+/* Workspace size for a call with that many segments and that state layout (state_heads 0 = num_heads);
+ * 0 when num_segments <= 1 and the state is per query head. */
+size_t hymeta_gla_prefill_workspace_bytes(int32_t num_seqs, int32_t num_heads, int32_t state_heads, int32_t num_segments);
 int hymeta_gla_prefill_varlen(const hymeta_gla_prefill_args* args, hymeta_stream_t stream);
 
 /* ------------------------------------------------------------------------

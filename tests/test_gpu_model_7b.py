@@ -37,7 +37,8 @@ def _checkpoint(g_, cfg):
     return w
 
 
-def test_glaswa_for_causal_lm_prefill_then_decode():
+@pytest.mark.parametrize("state_per_kv_head", [True, False])
+def test_glaswa_for_causal_lm_prefill_then_decode(state_per_kv_head):
     from oracle.model import glaswa_model_ref
     from vllm_hymeta.model_for_7B.configuration_gla_swa import GLAswaConfig
     from vllm_hymeta.model_for_7B.modeling_gla_swa import GLAswaForCausalLM
@@ -47,11 +48,12 @@ def test_glaswa_for_causal_lm_prefill_then_decode():
     cfg = GLAswaConfig(vocab_size=512, hidden_size=512, num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=2,
                        intermediate_size=1024, sliding_window=48, max_position_embeddings=1024)
     ckpt = _checkpoint(g_, cfg)
-    model = GLAswaForCausalLM(cfg, max_num_seqs=4, device=dev)
+    model = GLAswaForCausalLM(cfg, max_num_seqs=4, device=dev, state_per_kv_head=state_per_kv_head)
     loaded = model.load_weights(ckpt.items())
     assert "model.layers.0.attn.qkv_proj.weight" in loaded and "model.layers.1.mlp.gate_up_proj.weight" in loaded
     assert not any(".layers.4." in n for n in loaded)
-    assert model.model.cache_shape == (2, 4, 4, D, D)
+    # one GLA state per key/value head (2), or per query head (4) as the reference caches them
+    assert model.model.cache_shape == (2, 4, 2 if state_per_kv_head else 4, D, D)
 
     lens = [70, 41]
     ids = [torch.randint(0, cfg.vocab_size, (L + 1,), generator=g_) for L in lens]     # prompt + the decode step's token

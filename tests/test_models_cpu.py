@@ -41,7 +41,10 @@ def test_7b_checkpoint_loads_per_rank(tp, monkeypatch):
         loaded = model.load_weights(ckpt.items())
         assert len(loaded) == 39
         m = model.model
-        assert m.cache_shape == (2, 3, 4 // tp, D, D) and m.gla_cache.cache[0].shape == m.cache_shape
+        # one GLA state per key/value head of the rank (the reference's per-query-head shape on request)
+        assert m.cache_shape == (2, 3, 2 // tp, D, D) and m.gla_cache.cache[0].shape == m.cache_shape
+        per_head = mod.GLAswaModel(cfg, max_num_seqs=3, device="cpu", state_per_kv_head=False)
+        assert per_head.cache_shape == (2, 3, 4 // tp, D, D)
         assert len(m.layers) == 4 and len(model.kv_cache) == 2
         H, Hkv = 4 // tp, 2 // tp
         for i, layer in enumerate(m.layers):

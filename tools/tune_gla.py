@@ -26,15 +26,16 @@ def bench(fn, iters=40):
 
 def main():
     dev = torch.device("cuda")
+    SH = HKV if os.environ.get("STATE", "kv_head") == "kv_head" else H     # heads in the state tensor
     for B in [int(x) for x in os.environ.get("BATCHES", "1,8,64,256").split(",")]:
-        nstate = max(1, min(16, int(2e9 // (B * H * D * D * 2)) + 1))   # cycle states: defeat the Infinity Cache
-        states = [(torch.randn(B, H, D, D, device=dev) * 0.1).to(torch.bfloat16) for _ in range(nstate)]
+        nstate = max(1, min(16, int(2e9 // (B * SH * D * D * 2)) + 1))   # cycle states: defeat the Infinity Cache
+        states = [(torch.randn(B, SH, D, D, device=dev) * 0.1).to(torch.bfloat16) for _ in range(nstate)]
         q = torch.randn(B, H, D, device=dev).to(torch.bfloat16)
         k, v, gk = (torch.randn(B, HKV, D, device=dev).to(torch.bfloat16) for _ in range(3))
         w = torch.ones(D, dtype=torch.bfloat16, device=dev)
         slot = torch.arange(B, dtype=torch.int32, device=dev)
         out = torch.empty(B, H, D, dtype=torch.bfloat16, device=dev)
-        nbytes = B * (2 * H * D * D * 2 + H * D * 2 * 2 + 3 * HKV * D * 2)
+        nbytes = B * (2 * SH * D * D * 2 + H * D * 2 * 2 + 3 * HKV * D * 2)
         for name, kw in (("plain", {}), ("fused gate+norm", dict(gate_mode=_C.GATE_7B, out_norm_weight=w))):
             i = [0]
 
@@ -43,7 +44,7 @@ def main():
                 i[0] += 1
                 hip_ops.gla_decode(q, k, v, gk, st, slot, out=out, **kw)
             us = bench(fn)
-            print(f"B={B:4d} {name:16s} {us:8.1f} us  {nbytes / us / 1e3:8.1f} GB/s", flush=True)
+            print(f"state heads {SH:2d} B={B:4d} {name:16s} {us:8.1f} us  {nbytes / us / 1e3:8.1f} GB/s", flush=True)
 
 
 if __name__ == "__main__":

@@ -192,9 +192,214 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   }
 }
 
+
+// One state per key/value head.  The REP query heads of a group see the same k, v and decay, so
+// their states are equal for ever once they start equal; the group's state is streamed once and
+// contracted with all REP queries.  Rows, lanes and summation order are those of the kernel above,
+// so out is bit-identical to REP per-query-head units.
+template <int REP, int NSPLIT, bool STATE_F32>
+__global__ __launch_bounds__(256) void gla_decode_group_kernel(hymeta_gla_decode_args a, GateParams gp) {
+  constexpr int D = kHeadDim;
+  constexpr int COLS = D / NSPLIT;
+  constexpr int CG = COLS / 8;
+  constexpr int RPP = 256 / CG;
+  constexpr int NPASS = D / RPP;
+
+  __shared__ float s_q[REP][D];
+  __shared__ float s_k[D];
+  __shared__ float s_dec[D];
+  __shared__ float s_red[4][REP][COLS];
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / a.num_kv_heads;
+  const int kvh = blockIdx.x % a.num_kv_heads;
+  const int split = blockIdx.y;
+  const int slot = a.slot_idx[b];
+  if (slot < 0) return;  // padded sequence: state and output untouched
+  const int h0 = kvh * REP;
+
+  if (tid < D) {
+    const uint16_t* kp = reinterpret_cast<const uint16_t*>(a.k) + b * a.k_stride_b + kvh * a.k_stride_h;
+    float g_raw = 0.f;
+    if (a.g != nullptr) {
+      const int64_t goff = b * a.g_stride_b + kvh * a.g_stride_h + tid;
+      g_raw = a.g_dtype == HYMETA_F32 ? reinterpret_cast<const float*>(a.g)[goff]
+                                      : bf2f(reinterpret_cast<const uint16_t*>(a.g)[goff]);
+    }
+    const float k_raw = bf2f(kp[tid]);
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+      const uint16_t* qp = reinterpret_cast<const uint16_t*>(a.q) + b * a.q_stride_b + (h0 + r) * a.q_stride_h;
+      float qs, kb, g;
+      apply_gate(gp, bf2f(qp[tid]), k_raw, g_raw, 0.f, qs, kb, g);
+      s_q[r][tid] = qs;
+      if (r == 0) {
+        s_k[tid] = kb;
+        s_dec[tid] = __expf(g);
+      }
+    }
+  }
+
+  const int cg = tid % CG;
+  const int r0 = tid / CG;
+  const int col0 = split * COLS + cg * 8;
+
+  float vf[8];
+  {
+    const uint16_t* vp = reinterpret_cast<const uint16_t*>(a.v) + b * a.v_stride_b + kvh * a.v_stride_h + col0;
+    u32x4 raw = ld16(vp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      vf[2 * i] = lo_bf(raw[i]);
+      vf[2 * i + 1] = hi_bf(raw[i]);
+    }
+  }
+
+  const int64_t sbase = static_cast<int64_t>(slot) * a.state_stride_slot + static_cast<int64_t>(kvh) * a.state_stride_h;
+  float acc[REP][8];
+#pragma unroll
+  for (int r = 0; r < REP; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[r][c] = 0.f;
+
+  // every load of the lane's rows is in flight before the first is used
+  u32x4 raw[NPASS][STATE_F32 ? 2 : 1];
+  char* sp = reinterpret_cast<char*>(a.state) + (sbase + col0) * (STATE_F32 ? 4 : 2);
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
+    const char* p = sp + static_cast<int64_t>(r0 + RPP * i) * D * (STATE_F32 ? 4 : 2);
+    raw[i][0] = ld16(p);
+    if constexpr (STATE_F32) raw[i][1] = ld16(p + 16);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
+    const int row = r0 + RPP * i;
+    const float kr = s_k[row], dr = s_dec[row];
+    float s[8];
+    if constexpr (STATE_F32) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s[c] = __uint_as_float(raw[i][c >> 2][c & 3]);
+    } else {
+      StateIO<uint16_t>::unpack(raw[i][0], s);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float kv = bf16_round(kr * vf[c]);  // outer product is formed in bf16
+      s[c] = fmaf(dr, s[c], kv);
+    }
+    char* p = sp + static_cast<int64_t>(row) * D * (STATE_F32 ? 4 : 2);
+    if constexpr (STATE_F32) {
+      st16(p, u32x4{__float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2]), __float_as_uint(s[3])});
+      st16(p + 16, u32x4{__float_as_uint(s[4]), __float_as_uint(s[5]), __float_as_uint(s[6]), __float_as_uint(s[7])});
+    } else {
+      StateIO<uint16_t>::store8(reinterpret_cast<uint16_t*>(p), s);
+    }
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+      const float qr = s_q[r][row];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[r][c] = fmaf(qr, s[c], acc[r][c]);
+    }
+  }
+
+  // Sum over the lanes of a wave that share a column group.  Each step hands half of the lane's
+  // columns to the partner lane and keeps the other half: the same pairs are added as in a full
+  // butterfly, with half the exchanges per step.
+  const int wave = tid / kWave, lane = tid % kWave;
+  float a4[REP][4], a2[REP][2];
+  int cbase = 0;
+  {
+    const bool hi = (lane & CG) != 0;
+#pragma unroll
+    for (int r = 0; r < REP; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float send = hi ? acc[r][c] : acc[r][c + 4];
+        const float keep = hi ? acc[r][c + 4] : acc[r][c];
+        a4[r][c] = keep + __shfl_xor(send, CG);
+      }
+    cbase += hi ? 4 : 0;
+  }
+  {
+    const bool hi = (lane & (2 * CG)) != 0;
+#pragma unroll
+    for (int r = 0; r < REP; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float send = hi ? a4[r][c] : a4[r][c + 2];
+        const float keep = hi ? a4[r][c + 2] : a4[r][c];
+        a2[r][c] = keep + __shfl_xor(send, 2 * CG);
+      }
+    cbase += hi ? 2 : 0;
+  }
+  if constexpr (CG == 8) {
+    const bool hi = (lane & 32) != 0;
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+      const float send = hi ? a2[r][0] : a2[r][1];
+      const float keep = hi ? a2[r][1] : a2[r][0];
+      s_red[wave][r][cg * 8 + cbase + (hi ? 1 : 0)] = keep + __shfl_xor(send, 32);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+      s_red[wave][r][cg * 8 + cbase] = a2[r][0];
+      s_red[wave][r][cg * 8 + cbase + 1] = a2[r][1];
+    }
+  }
+  __syncthreads();
+
+  if (a.out_norm_weight == nullptr || NSPLIT != 1) {
+    for (int idx = tid; idx < REP * COLS; idx += 256) {
+      const int r = idx / COLS, c = idx % COLS;
+      const float o = s_red[0][r][c] + s_red[1][r][c] + s_red[2][r][c] + s_red[3][r][c];
+      reinterpret_cast<uint16_t*>(a.out)[b * a.out_stride_b + (h0 + r) * a.out_stride_h + split * COLS + c] = f2bf(o);
+    }
+    return;
+  }
+  if constexpr (NSPLIT == 1) {
+    // Per-head RMS norm over the 128 output channels (g_norm), applied to the bf16-rounded
+    // output the way the unfused layer sees it; a wave takes heads wave, wave + 4.
+    const float w0 = bf2f(reinterpret_cast<const uint16_t*>(a.out_norm_weight)[lane]);
+    const float w1 = bf2f(reinterpret_cast<const uint16_t*>(a.out_norm_weight)[lane + kWave]);
+    for (int r = wave; r < REP; r += 4) {
+      const float o0 = bf16_round(s_red[0][r][lane] + s_red[1][r][lane] + s_red[2][r][lane] + s_red[3][r][lane]);
+      const float o1 = bf16_round(s_red[0][r][lane + kWave] + s_red[1][r][lane + kWave] + s_red[2][r][lane + kWave] +
+                                  s_red[3][r][lane + kWave]);
+      float ss0 = o0 * o0, ss1 = o1 * o1;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        ss0 += __shfl_xor(ss0, off);
+        ss1 += __shfl_xor(ss1, off);
+      }
+      const float rs = rsqrtf((ss0 + ss1) * (1.f / D) + a.out_norm_eps);
+      uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + b * a.out_stride_b + (h0 + r) * a.out_stride_h;
+      op[lane] = f2bf(bf16_round(o0 * rs) * w0);
+      op[lane + kWave] = f2bf(bf16_round(o1 * rs) * w1);
+    }
+  }
+}
+
 }  // namespace hymeta
 
 using namespace hymeta;
+
+namespace {
+
+template <int REP>
+void launch_group(const hymeta_gla_decode_args& a, const GateParams& gp, bool split2, bool f32, hipStream_t s) {
+  dim3 block(256), grid(static_cast<unsigned>(a.batch) * a.num_kv_heads, split2 ? 2 : 1);
+  if (split2) {
+    if (f32) hipLaunchKernelGGL((gla_decode_group_kernel<REP, 2, true>), grid, block, 0, s, a, gp);
+    else hipLaunchKernelGGL((gla_decode_group_kernel<REP, 2, false>), grid, block, 0, s, a, gp);
+  } else {
+    if (f32) hipLaunchKernelGGL((gla_decode_group_kernel<REP, 1, true>), grid, block, 0, s, a, gp);
+    else hipLaunchKernelGGL((gla_decode_group_kernel<REP, 1, false>), grid, block, 0, s, a, gp);
+  }
+}
+
+}  // namespace
 
 extern "C" int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stream_t stream) {
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
@@ -219,9 +424,30 @@ extern "C" int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stre
   gp.normalizer = a.gate_normalizer > 0.f ? a.gate_normalizer : 16.f;
   gp.clamp = a.gate_clamp > 0.f ? a.gate_clamp : 0.95f;
 
+  const int state_heads = a.state_heads == 0 ? a.num_heads : a.state_heads;
+  if (state_heads != a.num_heads && state_heads != a.num_kv_heads) return HYMETA_ERR_INVALID_ARG;
+  const int rep = a.num_heads / a.num_kv_heads;
+  const bool grouped = state_heads != a.num_heads;
+  // a state shared by a group needs a gate that is the same for every query head of the group
+  if (grouped && a.gate_mode == HYMETA_GATE_70B_LOWER_BOUND) return HYMETA_ERR_INVALID_ARG;
+  if (grouped && rep > 8) return HYMETA_ERR_UNSUPPORTED;
+
   hipStream_t s = begin_launches(stream);
-  const int64_t units = static_cast<int64_t>(a.batch) * a.num_heads;
   const bool f32 = a.state_dtype == HYMETA_F32;
+  if (grouped) {
+    const bool split2 = static_cast<int64_t>(a.batch) * a.num_kv_heads < 512 && a.out_norm_weight == nullptr;
+    switch (rep) {
+      case 2: launch_group<2>(a, gp, split2, f32, s); break;
+      case 3: launch_group<3>(a, gp, split2, f32, s); break;
+      case 4: launch_group<4>(a, gp, split2, f32, s); break;
+      case 5: launch_group<5>(a, gp, split2, f32, s); break;
+      case 6: launch_group<6>(a, gp, split2, f32, s); break;
+      case 7: launch_group<7>(a, gp, split2, f32, s); break;
+      default: launch_group<8>(a, gp, split2, f32, s); break;
+    }
+    return launch_status();
+  }
+  const int64_t units = static_cast<int64_t>(a.batch) * a.num_heads;
   // Few (sequence, head) units: split the state columns over two workgroups so
   // more CUs stream.  The fused norm needs all 128 columns in one workgroup.
   const bool split2 = units < 1024 && a.out_norm_weight == nullptr;

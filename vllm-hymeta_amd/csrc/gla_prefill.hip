@@ -102,6 +102,8 @@ struct Smem {
 
 struct Seg {
   int seq, h, kvh, slot;
+  int sh;         // head index in the state tensors (h, or the kv-head when a group shares its state)
+  bool writer;    // this head stores the final state
   int tb;         // first token of the run
   int t_end;      // end of the sequence
   int nchunks;    // chunks in the run
@@ -457,6 +459,9 @@ __global__ __launch_bounds__(kThreads) void gla_prefill_kernel(hymeta_gla_prefil
     const int j = rest % nseg;
     sg.seq = rest / nseg;
     sg.kvh = sg.h / (H / a.num_kv_heads);
+    const int heads_per_state = H / a.state_heads;
+    sg.sh = sg.h / heads_per_state;
+    sg.writer = sg.h % heads_per_state == 0;
     const int t_begin = a.cu_seqlens[sg.seq];
     sg.t_end = a.cu_seqlens[sg.seq + 1];
     sg.slot = a.slot_idx[sg.seq];
@@ -471,6 +476,10 @@ __global__ __launch_bounds__(kThreads) void gla_prefill_kernel(hymeta_gla_prefil
     sg.tb = t_begin + c0 * CH;
     sg.ws_state = nullptr;
     sg.ws_dec = nullptr;
+    if (nseg == 1 && heads_per_state > 1) {
+      // sibling heads read state[slot] at their own pace: the final state is staged, a later launch commits it
+      sg.ws_state = workspace + (static_cast<int64_t>(sg.seq) * a.state_heads + sg.sh) * (D * D);
+    }
     if (nseg > 1) {
       const int64_t unit = (static_cast<int64_t>(sg.seq) * H + sg.h) * nseg + j;
       sg.ws_state = workspace + unit * (D * D);
@@ -501,9 +510,9 @@ __global__ __launch_bounds__(kThreads) void gla_prefill_kernel(hymeta_gla_prefil
       const char* src = nullptr;
       if (!first) {
         src = reinterpret_cast<const char*>(a.state) +
-              (static_cast<int64_t>(sg.slot) * a.state_stride_slot + static_cast<int64_t>(sg.h) * a.state_stride_h) * (state_f32 ? 4 : 2);
+              (static_cast<int64_t>(sg.slot) * a.state_stride_slot + static_cast<int64_t>(sg.sh) * a.state_stride_h) * (state_f32 ? 4 : 2);
       } else if (a.meta_state != nullptr) {
-        src = reinterpret_cast<const char*>(a.meta_state) + static_cast<int64_t>(sg.h) * a.meta_state_stride_h * (state_f32 ? 4 : 2);
+        src = reinterpret_cast<const char*>(a.meta_state) + static_cast<int64_t>(sg.sh) * a.meta_state_stride_h * (state_f32 ? 4 : 2);
       }
 #pragma unroll
       for (int tp = 0; tp < 8; ++tp) {
@@ -534,16 +543,18 @@ __global__ __launch_bounds__(kThreads) void gla_prefill_kernel(hymeta_gla_prefil
       __syncthreads();
     }
 
-    if (MODE == kStateOnly) {
+    if (MODE == kStateOnly || (nseg == 1 && sg.ws_state != nullptr)) {
+      if (MODE == kStateOnly || sg.writer) {
 #pragma unroll
-      for (int tp = 0; tp < 8; ++tp) {
+        for (int tp = 0; tp < 8; ++tp) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          *reinterpret_cast<float2*>(sg.ws_state + (32 * c + 8 * r + tp) * D + col) = float2{s_acc[tp][0][r], s_acc[tp][1][r]};
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float2*>(sg.ws_state + (32 * c + 8 * r + tp) * D + col) = float2{s_acc[tp][0][r], s_acc[tp][1][r]};
+        }
       }
-    } else if (sg.last) {
+    } else if (sg.last && sg.writer) {
       char* dst = reinterpret_cast<char*>(a.state) +
-                  (static_cast<int64_t>(sg.slot) * a.state_stride_slot + static_cast<int64_t>(sg.h) * a.state_stride_h) * (state_f32 ? 4 : 2);
+                  (static_cast<int64_t>(sg.slot) * a.state_stride_slot + static_cast<int64_t>(sg.sh) * a.state_stride_h) * (state_f32 ? 4 : 2);
 #pragma unroll
       for (int tp = 0; tp < 8; ++tp) {
 #pragma unroll
@@ -600,6 +611,7 @@ __global__ __launch_bounds__(256) void gla_prefill_scan_kernel(hymeta_gla_prefil
   const int j_last = (nch_seq - 1) / seg_chunks;
   const int idx = (blockIdx.y * 256 + threadIdx.x) * 4;   // element of the [D][D] block
   const int ch = idx / D;
+  const int sh = h / (H / a.state_heads);
   const int64_t unit0 = (static_cast<int64_t>(seq) * H + h) * nseg;
   float* ws = workspace + unit0 * (D * D) + idx;
   const float* wd = workspace + static_cast<int64_t>(a.num_seqs) * H * nseg * (D * D) + unit0 * D + ch;
@@ -609,9 +621,9 @@ __global__ __launch_bounds__(256) void gla_prefill_scan_kernel(hymeta_gla_prefil
   const char* src = nullptr;
   if (!first) {
     src = reinterpret_cast<const char*>(a.state) +
-          (static_cast<int64_t>(slot) * a.state_stride_slot + static_cast<int64_t>(h) * a.state_stride_h) * (STATE_F32 ? 4 : 2);
+          (static_cast<int64_t>(slot) * a.state_stride_slot + static_cast<int64_t>(sh) * a.state_stride_h) * (STATE_F32 ? 4 : 2);
   } else if (a.meta_state != nullptr) {
-    src = reinterpret_cast<const char*>(a.meta_state) + static_cast<int64_t>(h) * a.meta_state_stride_h * (STATE_F32 ? 4 : 2);
+    src = reinterpret_cast<const char*>(a.meta_state) + static_cast<int64_t>(sh) * a.meta_state_stride_h * (STATE_F32 ? 4 : 2);
   }
   if (src != nullptr) {
     if constexpr (STATE_F32) {
@@ -645,6 +657,23 @@ __global__ __launch_bounds__(256) void gla_prefill_scan_kernel(hymeta_gla_prefil
   }
 }
 
+// Staged final states (fp32, one per sequence and state head) into state[slot].
+template <bool STATE_F32>
+__global__ __launch_bounds__(256) void gla_prefill_commit_kernel(hymeta_gla_prefill_args a, const float* staged) {
+  const int SH = a.state_heads;
+  const int sh = blockIdx.x % SH, seq = blockIdx.x / SH;
+  const int slot = a.slot_idx[seq];
+  if (slot < 0 || a.cu_seqlens[seq + 1] <= a.cu_seqlens[seq]) return;
+  const int idx = (blockIdx.y * 256 + threadIdx.x) * 4;
+  const f32x4 x = *reinterpret_cast<const f32x4*>(staged + (static_cast<int64_t>(seq) * SH + sh) * (D * D) + idx);
+  const int64_t off = static_cast<int64_t>(slot) * a.state_stride_slot + static_cast<int64_t>(sh) * a.state_stride_h + idx;
+  if constexpr (STATE_F32) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.state) + off) = x;
+  } else {
+    *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.state) + off) = u32x2{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
+  }
+}
+
 }  // namespace hymeta
 
 using namespace hymeta;
@@ -662,9 +691,12 @@ extern "C" int hymeta_gla_prefill_segments(int32_t num_seqs, int32_t num_heads, 
   return nseg < 1 ? 1 : nseg;
 }
 
-extern "C" size_t hymeta_gla_prefill_workspace_bytes(int32_t num_seqs, int32_t num_heads, int32_t num_segments) {
-  if (num_segments <= 1 || num_seqs <= 0 || num_heads <= 0) return 0;
-  return static_cast<size_t>(num_seqs) * num_heads * num_segments * (D * D + D) * sizeof(float);
+extern "C" size_t hymeta_gla_prefill_workspace_bytes(int32_t num_seqs, int32_t num_heads, int32_t state_heads,
+                                                     int32_t num_segments) {
+  if (num_seqs <= 0 || num_heads <= 0) return 0;
+  if (num_segments > 1) return static_cast<size_t>(num_seqs) * num_heads * num_segments * (D * D + D) * sizeof(float);
+  if (state_heads > 0 && state_heads < num_heads) return static_cast<size_t>(num_seqs) * state_heads * (D * D) * sizeof(float);
+  return 0;
 }
 
 namespace {
@@ -700,7 +732,7 @@ void launch_main(const hymeta_gla_prefill_args& a, const GateParams& gp, float* 
 
 extern "C" int hymeta_gla_prefill_varlen(const hymeta_gla_prefill_args* args, hymeta_stream_t stream) {
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
-  const hymeta_gla_prefill_args& a = *args;
+  hymeta_gla_prefill_args a = *args;
   if (a.num_seqs < 0 || a.total_tokens < 0 || a.num_heads <= 0 || a.num_kv_heads <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.num_seqs == 0 || a.total_tokens == 0) return HYMETA_OK;
   if (!a.q || !a.k || !a.v || !a.out || !a.state || !a.slot_idx || !a.cu_seqlens) return HYMETA_ERR_INVALID_ARG;
@@ -711,6 +743,11 @@ extern "C" int hymeta_gla_prefill_varlen(const hymeta_gla_prefill_args* args, hy
   if (a.gate_mode < HYMETA_GATE_NONE || a.gate_mode > HYMETA_GATE_70B_LOWER_BOUND) return HYMETA_ERR_UNSUPPORTED;
   if ((a.gate_mode == HYMETA_GATE_NONE || a.gate_mode == HYMETA_GATE_7B) && !a.g) return HYMETA_ERR_INVALID_ARG;
   if (a.gate_mode == HYMETA_GATE_70B_LOWER_BOUND && !a.lower_bound) return HYMETA_ERR_INVALID_ARG;
+  if (a.state_heads == 0) a.state_heads = a.num_heads;
+  if (a.state_heads != a.num_heads && a.state_heads != a.num_kv_heads) return HYMETA_ERR_INVALID_ARG;
+  const bool grouped = a.state_heads != a.num_heads;
+  // a state shared by a group needs a gate that is the same for every query head of the group
+  if (grouped && a.gate_mode == HYMETA_GATE_70B_LOWER_BOUND) return HYMETA_ERR_INVALID_ARG;
   const int64_t strides[] = {a.q_stride_t, a.q_stride_h, a.k_stride_t, a.k_stride_h, a.v_stride_t, a.v_stride_h,
                              a.out_stride_t, a.out_stride_h, a.state_stride_slot, a.state_stride_h,
                              a.meta_state_stride_h, a.g ? a.g_stride_t : 0, a.g ? a.g_stride_h : 0};
@@ -728,9 +765,13 @@ extern "C" int hymeta_gla_prefill_varlen(const hymeta_gla_prefill_args* args, hy
   const int chunks = (a.max_seqlen + CH - 1) / CH;
   if (nseg == 0) nseg = a.workspace != nullptr ? hymeta_gla_prefill_segments(a.num_seqs, a.num_heads, a.max_seqlen) : 1;
   if (nseg > chunks) nseg = chunks;
-  if (nseg > 1) {
+  if (nseg < 1) nseg = 1;
+  // the library's own choice stays within the workspace it was given
+  if (a.num_segments == 0 && nseg > 1 &&
+      a.workspace_bytes < hymeta_gla_prefill_workspace_bytes(a.num_seqs, a.num_heads, a.state_heads, nseg)) nseg = 1;
+  if (nseg > 1 || grouped) {
     if (a.workspace == nullptr) return HYMETA_ERR_INVALID_ARG;
-    if (a.workspace_bytes < hymeta_gla_prefill_workspace_bytes(a.num_seqs, a.num_heads, nseg)) return HYMETA_ERR_WORKSPACE;
+    if (a.workspace_bytes < hymeta_gla_prefill_workspace_bytes(a.num_seqs, a.num_heads, a.state_heads, nseg)) return HYMETA_ERR_WORKSPACE;
   }
   const int seg_chunks = (chunks + nseg - 1) / nseg;
 
@@ -749,5 +790,10 @@ extern "C" int hymeta_gla_prefill_varlen(const hymeta_gla_prefill_args* args, hy
     else hipLaunchKernelGGL((gla_prefill_scan_kernel<false>), grid, block, 0, s, a, ws, nseg, seg_chunks);
   }
   launch_main<kFull>(a, gp, ws, nseg, seg_chunks, s);
+  if (nseg == 1 && grouped) {
+    dim3 grid(static_cast<unsigned>(a.num_seqs) * a.state_heads, D * D / (256 * 4)), block(256);
+    if (a.state_dtype == HYMETA_F32) hipLaunchKernelGGL((gla_prefill_commit_kernel<true>), grid, block, 0, s, a, ws);
+    else hipLaunchKernelGGL((gla_prefill_commit_kernel<false>), grid, block, 0, s, a, ws);
+  }
   return launch_status();
 }

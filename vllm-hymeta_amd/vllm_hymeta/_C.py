@@ -41,6 +41,7 @@ class GlaDecodeArgs(C.Structure):
         ("state_stride_slot", _i64), ("state_stride_h", _i64),
         ("g_dtype", _i32), ("state_dtype", _i32), ("gate_mode", _i32),
         ("scale", _f32), ("gate_normalizer", _f32), ("gate_clamp", _f32), ("out_norm_eps", _f32),
+        ("state_heads", _i32),
     ]
 
 
@@ -61,6 +62,7 @@ class GlaPrefillArgs(C.Structure):
         ("g_dtype", _i32), ("state_dtype", _i32), ("gate_mode", _i32),
         ("scale", _f32), ("gate_normalizer", _f32), ("gate_clamp", _f32), ("out_norm_eps", _f32),
         ("workspace", _ptr), ("workspace_bytes", _sz), ("num_segments", _i32),
+        ("state_heads", _i32),
     ]
 
 
@@ -210,7 +212,7 @@ _SIGNATURES = {
     "hymeta_gla_decode": (C.c_int, [C.POINTER(GlaDecodeArgs), _ptr]),
     "hymeta_gla_prefill_varlen": (C.c_int, [C.POINTER(GlaPrefillArgs), _ptr]),
     "hymeta_gla_prefill_segments": (C.c_int, [_i32, _i32, _i32]),
-    "hymeta_gla_prefill_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "hymeta_gla_prefill_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "hymeta_reshape_and_cache": (C.c_int, [C.POINTER(ReshapeAndCacheArgs), _ptr]),
     "hymeta_meta_swa_paged_decode_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "hymeta_meta_swa_paged_decode_splits": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),

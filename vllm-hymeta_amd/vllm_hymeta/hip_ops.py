@@ -64,7 +64,9 @@ def gla_decode(
     out_norm_weight: Optional[torch.Tensor] = None,
     out_norm_eps: float = 1e-6,
 ) -> torch.Tensor:
-    """q [B,H,D]; k, v, g [B,Hkv,D]; state [slots,H,D,D] updated in place; slot_idx [B] int32.
+    """q [B,H,D]; k, v, g [B,Hkv,D]; state [slots,H,D,D] (one state per query head, the reference's
+    layout) or [slots,Hkv,D,D] (one per key/value head; any gate but the 70B lower-bound one), updated
+    in place; slot_idx [B] int32.
 
     Returns out [B,H,D] bf16 (rows of skipped sequences, slot -1, are left as they were).
     """
@@ -75,7 +77,10 @@ def gla_decode(
              "q, k, v must be bfloat16")
     _require(k.shape == (B, Hkv, D) and v.shape == (B, Hkv, D), "k, v must be [B, Hkv, D]")
     _require(g is None or g.shape == (B, Hkv, D), "g must be [B, Hkv, D]")
-    _require(state.dim() == 4 and state.shape[1:] == (H, D, D), "state must be [slots, H, D, D]")
+    _require(state.dim() == 4 and state.shape[2:] == (D, D) and state.shape[1] in (H, Hkv),
+             "state must be [slots, H, D, D] or [slots, Hkv, D, D]")
+    _require(state.shape[1] == H or gate_mode != _C.GATE_70B_LOWER_BOUND,
+             "the lower-bound gate depends on the query head: the state must be per query head")
     _require(state.stride(3) == 1 and state.stride(2) == D, "state (Dk, Dv) blocks must be contiguous")
     _require(state.dtype in _DT, "state must be bfloat16 or float32")
     _require(slot_idx.dtype == torch.int32 and slot_idx.shape == (B,) and slot_idx.is_contiguous(),
@@ -107,6 +112,7 @@ def gla_decode(
     a.out_stride_b, a.out_stride_h = out.stride(0), out.stride(1)
     a.state_stride_slot, a.state_stride_h = state.stride(0), state.stride(1)
     a.state_dtype = _DT[state.dtype]
+    a.state_heads = state.shape[1]
     a.gate_mode = gate_mode
     a.scale = float(scale) if scale is not None else 0.0
     a.gate_normalizer, a.gate_clamp, a.out_norm_eps = gate_normalizer, gate_clamp, out_norm_eps
@@ -138,7 +144,8 @@ def gla_prefill_varlen(
     out_norm_eps: float = 1e-6,
     num_segments: int = 0,
 ) -> torch.Tensor:
-    """q [T,H,D]; k, v, g [T,Hkv,D]; cu_seqlens int32 [nseq+1]; state updated in place.
+    """q [T,H,D]; k, v, g [T,Hkv,D]; cu_seqlens int32 [nseq+1]; state [slots,H,D,D] or [slots,Hkv,D,D]
+    (see gla_decode) updated in place.
     ``num_segments``: 0 lets the library decide whether to cut long sequences into parallel runs,
     1 forces a single run per (sequence, head), >1 forces that many."""
     _dev(q, k, v, g, state, slot_idx, cu_seqlens, context_lens, meta_state, lower_bound, out_norm_weight)
@@ -149,7 +156,11 @@ def gla_prefill_varlen(
              "q, k, v must be bfloat16")
     _require(k.shape == (T, Hkv, D) and v.shape == (T, Hkv, D), "k, v must be [T, Hkv, D]")
     _require(g is None or g.shape == (T, Hkv, D), "g must be [T, Hkv, D]")
-    _require(state.dim() == 4 and state.shape[1:] == (H, D, D), "state must be [slots, H, D, D]")
+    _require(state.dim() == 4 and state.shape[2:] == (D, D) and state.shape[1] in (H, Hkv),
+             "state must be [slots, H, D, D] or [slots, Hkv, D, D]")
+    SH = state.shape[1]
+    _require(SH == H or gate_mode != _C.GATE_70B_LOWER_BOUND,
+             "the lower-bound gate depends on the query head: the state must be per query head")
     _require(state.stride(3) == 1 and state.stride(2) == D, "state (Dk, Dv) blocks must be contiguous")
     _require(state.dtype in _DT, "state must be bfloat16 or float32")
     for name, t, n in (("slot_idx", slot_idx, nseq), ("cu_seqlens", cu_seqlens, nseq + 1),
@@ -161,9 +172,9 @@ def gla_prefill_varlen(
         if t is not None:
             _inner_contig(t, name)
     if meta_state is not None:
-        _require(meta_state.shape == (H, D, D) and meta_state.dtype == state.dtype
+        _require(meta_state.shape == (SH, D, D) and meta_state.dtype == state.dtype
                  and meta_state.stride(2) == 1 and meta_state.stride(1) == D,
-                 "meta_state must be [H, D, D] in the state dtype with contiguous blocks")
+                 "meta_state must be [state heads, D, D] in the state dtype with contiguous blocks")
     if out is None:
         out = torch.empty(T, H, D, dtype=torch.bfloat16, device=q.device)
     _require(out.shape == (T, H, D) and out.dtype == torch.bfloat16 and out.stride(-1) == 1,
@@ -186,6 +197,7 @@ def gla_prefill_varlen(
     if meta_state is not None:
         a.meta_state_stride_h = meta_state.stride(0)
     a.state_dtype = _DT[state.dtype]
+    a.state_heads = SH
     a.gate_mode = gate_mode
     a.scale = float(scale) if scale is not None else 0.0
     a.gate_normalizer, a.gate_clamp, a.out_norm_eps = gate_normalizer, gate_clamp, out_norm_eps
@@ -195,8 +207,8 @@ def gla_prefill_varlen(
         nseg = int(lib.hymeta_gla_prefill_segments(nseq, H, int(max_seqlen)))
     nseg = max(1, min(nseg, (int(max_seqlen) + 31) // 32))
     a.num_segments = nseg
-    if nseg > 1:
-        nbytes = int(lib.hymeta_gla_prefill_workspace_bytes(nseq, H, nseg))
+    nbytes = int(lib.hymeta_gla_prefill_workspace_bytes(nseq, H, SH, nseg))
+    if nbytes:
         ws = _workspace(q.device, nbytes, "gla_prefill")
         a.workspace, a.workspace_bytes = _p(ws), nbytes
     _C.check(lib.hymeta_gla_prefill_varlen(C.byref(a), _stream(q)), "hymeta_gla_prefill_varlen")

@@ -44,9 +44,16 @@ def _forward_context_metadata():
 
 
 class GLAswaModel(torch.nn.Module):
-    def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda"):
+    def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda",
+                 state_per_kv_head: bool = True):
         """``quant``: ``{"bits", "group_size", "zero_offset"}`` of a GPTQ checkpoint (ignored for bf16 /
-        W8A8 tensors, which identify themselves by dtype)."""
+        W8A8 tensors, which identify themselves by dtype).
+
+        ``state_per_kv_head``: keep one GLA state per key/value head instead of one per query head.  The
+        reference expands k, v and the gate to the query heads (``model_for_7B/gla_attention.py:246-282``)
+        and caches ``[layers, slots, H, D, D]`` (``modeling_gla_swa.py:391-414``); the 7 query heads of
+        a group then hold 7 identical states.  Keeping one cuts the state traffic of a decode step and
+        the cache size by that factor with bit-identical outputs; ``False`` restores the reference's shape."""
         super().__init__()
         self.config = config
         self.device = torch.device(device)
@@ -56,7 +63,8 @@ class GLAswaModel(torch.nn.Module):
         self.quant.update(quant or {})
         self.shard = shard_heads(config.num_attention_heads, config.num_key_value_heads, self.tp_size, self.tp_rank)
         self.gla_layers = [i for i in range(config.num_hidden_layers) if i not in config.attn_layers]
-        self.cache_shape = (len(self.gla_layers), max_num_seqs, self.shard.num_heads, config.head_dim, config.head_dim)
+        state_heads = self.shard.num_kv_heads if state_per_kv_head else self.shard.num_heads
+        self.cache_shape = (len(self.gla_layers), max_num_seqs, state_heads, config.head_dim, config.head_dim)
         self.gla_cache = GLACacheManager(dtype=torch.bfloat16, cache_shape=self.cache_shape, device=self.device)
         max_pos = min(config.max_position_embeddings, getattr(config, "max_model_len", config.max_position_embeddings))
         self.register_buffer("cos_sin_cache", rope_cos_sin_cache(config.head_dim, max_pos, config.rope_theta, device=self.device),
@@ -105,11 +113,13 @@ class GLAswaForCausalLM(torch.nn.Module):
         "gate_up_proj": ["gate_proj", "up_proj"],
     }
 
-    def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda"):
+    def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda",
+                 state_per_kv_head: bool = True):
         super().__init__()
         self.config = config
         self.CONCAT_FFN = True
-        self.model = GLAswaModel(config, max_num_seqs=max_num_seqs, quant=quant, tp_group=tp_group, device=device)
+        self.model = GLAswaModel(config, max_num_seqs=max_num_seqs, quant=quant, tp_group=tp_group, device=device,
+                                 state_per_kv_head=state_per_kv_head)
         self.lm_head: Optional[torch.Tensor] = None             # [vocab, hidden] fp32 (the reference's lm_head.float())
         self.kv_cache = [torch.tensor([]) for _ in config.attn_layers]
 
