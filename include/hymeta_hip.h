@@ -153,11 +153,11 @@ int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stream_t stream
  *   num_segments == 0, workspace == NULL   : single run
  *   num_segments  > 1                      : as given (clamped to the chunk count)
  *
- * With one state per key/value head (state_heads == num_kv_heads < num_heads)
- * the query heads of a group run as separate workgroups that all read the
- * group's initial state, so a single-run call stages the final states in the
- * workspace and a second launch commits them to state[slot]: the workspace is
- * then required for every segment count (size: the function below).
+ * With one state per key/value head (state_heads == num_kv_heads < num_heads,
+ * at most 8 query heads per group) a workgroup walks one (sequence, kv-head)
+ * and serves every query head of the group: the key side of a chunk (gate,
+ * decay scan, state update) is computed once instead of once per query head.
+ * Segment counts and the workspace are then sized over state_heads.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_gla_prefill_args {
   const void* q;            /* bf16 [total_tokens, num_heads,    head_dim] */
@@ -198,10 +198,11 @@ typedef struct hymeta_gla_prefill_args {
   int32_t state_heads;      /* as in hymeta_gla_decode_args; state and meta_state hold that many heads */
 } hymeta_gla_prefill_args;
 
-/* Segment count the library would choose for this shape (1 = single run). */
+/* Segment count the library would choose for this shape (1 = single run); num_heads = heads that run as
+ * separate workgroups: the query heads, or state_heads when a group shares its state. */
 int hymeta_gla_prefill_segments(int32_t num_seqs, int32_t num_heads, int32_t max_seqlen);
 /* Workspace size for a call with that many segments and that state layout (state_heads 0 = num_heads);
- * 0 when num_segments <= 1 and the state is per query head. */
+ * 0 when num_segments <= 1. */
 size_t hymeta_gla_prefill_workspace_bytes(int32_t num_seqs, int32_t num_heads, int32_t state_heads, int32_t num_segments);
 int hymeta_gla_prefill_varlen(const hymeta_gla_prefill_args* args, hymeta_stream_t stream);
 

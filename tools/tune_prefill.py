@@ -79,7 +79,8 @@ def gla(lens, H, Hkv, nseg=0):
     k = torch.randn(T, Hkv, D, device=dev).to(torch.bfloat16)
     v = torch.randn(T, Hkv, D, device=dev).to(torch.bfloat16)
     gk = torch.randn(T, Hkv, D, device=dev).to(torch.bfloat16)
-    st = torch.zeros(len(lens), H, D, D, dtype=torch.bfloat16, device=dev)
+    SH = Hkv if os.environ.get("STATE", "kv_head") == "kv_head" else H      # heads in the state tensor
+    st = torch.zeros(len(lens), SH, D, D, dtype=torch.bfloat16, device=dev)
     slot = torch.arange(len(lens), dtype=torch.int32, device=dev)
     cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
     ctx = torch.zeros(len(lens), dtype=torch.int32, device=dev)
@@ -87,7 +88,7 @@ def gla(lens, H, Hkv, nseg=0):
     us = bench(lambda: hip_ops.gla_prefill_varlen(q, k, v, gk, st, slot, cu, max(lens), context_lens=ctx, out=out,
                                                   gate_mode=_C.GATE_7B, num_segments=nseg))
     nbytes = T * (H * D * 2 * 2 + 3 * Hkv * D * 2) + len(lens) * H * D * D * 2
-    print(f"gla_prefill lens={lens[0]}x{len(lens)} H={H} Hkv={Hkv} nseg={nseg}: {us:9.1f} us  {nbytes / us / 1e3:8.1f} GB/s  "
+    print(f"gla_prefill lens={lens[0]}x{len(lens)} H={H} Hkv={Hkv} state heads {SH} nseg={nseg}: {us:9.1f} us  {nbytes / us / 1e3:8.1f} GB/s  "
           f"{T / us:7.2f} tok/us", flush=True)
 
 
@@ -114,7 +115,7 @@ if __name__ == "__main__":
         swa_paged(8192, 32768, 28, 4, 0, 4096)
         swa_paged(8192, 32768, 28, 4, 0, 4096, bs=16)
     if "gla" in which:
-        for nseg in (1, 0, 9, 18, 27, 36, 64):
+        for nseg in (1, 0, 9, 18, 27, 36, 64, 128):
             gla([32768], 28, 4, nseg)
         for nseg in (1, 0, 9, 18):
             gla([8192], 28, 4, nseg)

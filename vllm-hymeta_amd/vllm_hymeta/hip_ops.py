@@ -204,7 +204,7 @@ def gla_prefill_varlen(
     lib = _C.load()
     nseg = int(num_segments)
     if nseg == 0:
-        nseg = int(lib.hymeta_gla_prefill_segments(nseq, H, int(max_seqlen)))
+        nseg = int(lib.hymeta_gla_prefill_segments(nseq, SH, int(max_seqlen)))   # SH: heads that run as workgroups
     nseg = max(1, min(nseg, (int(max_seqlen) + 31) // 32))
     a.num_segments = nseg
     nbytes = int(lib.hymeta_gla_prefill_workspace_bytes(nseq, H, SH, nseg))
