@@ -195,3 +195,63 @@ def test_paged_decode_fused_kv_write_equals_write_then_decode(M, window_left, sp
     assert torch.equal(k_a.cpu().view(torch.int16), k_b.cpu().view(torch.int16))
     assert torch.equal(v_a.cpu().view(torch.int16), v_b.cpu().view(torch.int16))
     assert torch.equal(out_a.cpu().view(torch.int16), out_b.cpu().view(torch.int16))
+
+
+@pytest.mark.parametrize("H,Hkv,bs,M,window_left,seq_lens,splits", [
+    (28, 4, 16, 0, W, [1, W - 1, W, W + 1, 3 * W, 5], 1),        # 7B geometry, one pass
+    (28, 4, 256, 128, 4095, [5000, 4096, 4097, 17], 3),          # splits meet inside the kernel
+    (14, 2, 64, 64, 127, [700, 130, 1], 5),                      # two kv-heads: four waves per kv-head
+    (8, 2, 16, 0, -1, [77, 300, 31], 2),
+])
+def test_paged_decode_all_kv_heads_per_workgroup(H, Hkv, bs, M, window_left, seq_lens, splits, monkeypatch):
+    """The workgroup shape used when the sequences alone fill the chip (all kv-heads of a sequence in one
+    workgroup, splits merged by the workgroup that arrives last), forced here at small batch; two calls
+    in a row: the arrival counters must be back at zero after the first."""
+    from oracle import meta_swa_paged_decode_ref
+    from vllm_hymeta import hip_ops
+
+    monkeypatch.setenv("HYMETA_PAGED_SHAPE", "all")
+    B = len(seq_lens)
+    kc, vc, bt = _paged_problem(51, seq_lens, Hkv, bs)
+    g_ = gen(52)
+    k2 = randn_bf16(g_, M, Hkv, D) if M else None
+    v2 = randn_bf16(g_, M, Hkv, D) if M else None
+    lens = torch.tensor(seq_lens, dtype=torch.int32)
+    for call in range(2):
+        q = randn_bf16(g_, B, H, D)
+        ref = meta_swa_paged_decode_ref(q, kc, vc, seq_lens, bt, k2, v2, window_left)
+        out = hip_ops.meta_swa_paged_decode(
+            q.cuda(), kc.cuda(), vc.cuda(), lens.cuda(), bt.cuda(),
+            None if k2 is None else k2.cuda(), None if v2 is None else v2.cuda(),
+            window_left=window_left, num_splits=splits)
+        torch.cuda.synchronize()
+        assert_bf16_close(out.cpu(), ref, f"paged decode, all kv-heads per workgroup, call {call}")
+
+
+@pytest.mark.parametrize("splits", [1, 3])
+def test_paged_decode_all_kv_heads_fused_kv_write(splits, monkeypatch):
+    """Fused KV write in the all-kv-heads shape: same cache bytes and output bits as write-then-decode."""
+    from vllm_hymeta import hip_ops
+
+    monkeypatch.setenv("HYMETA_PAGED_SHAPE", "all")
+    H, Hkv, bs = 28, 4, 16
+    seq_lens = [1, 16, 17, 130, 257, 64]
+    kc, vc, bt = _paged_problem(61, seq_lens, Hkv, bs)
+    g_ = gen(62)
+    B = len(seq_lens)
+    q = randn_bf16(g_, B, H, D).cuda()
+    nk, nv = randn_bf16(g_, B, Hkv, D).cuda(), randn_bf16(g_, B, Hkv, D).cuda()
+    slots = torch.tensor([bt[i, (L - 1) // bs].item() * bs + (L - 1) % bs for i, L in enumerate(seq_lens)],
+                         dtype=torch.int64)
+    slots[3] = -1
+    lens = torch.tensor(seq_lens, dtype=torch.int32).cuda()
+    k_a, v_a = kc.cuda(), vc.cuda()
+    hip_ops.reshape_and_cache(nk, nv, k_a, v_a, slots.cuda())
+    out_a = hip_ops.meta_swa_paged_decode(q, k_a, v_a, lens, bt.cuda(), window_left=100, num_splits=splits)
+    k_b, v_b = kc.cuda(), vc.cuda()
+    out_b = hip_ops.meta_swa_paged_decode(q, k_b, v_b, lens, bt.cuda(), window_left=100, num_splits=splits,
+                                          new_key=nk, new_value=nv, slot_mapping=slots.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(k_a.cpu().view(torch.int16), k_b.cpu().view(torch.int16))
+    assert torch.equal(v_a.cpu().view(torch.int16), v_b.cpu().view(torch.int16))
+    assert torch.equal(out_a.cpu().view(torch.int16), out_b.cpu().view(torch.int16))

@@ -15,10 +15,18 @@
 //     stored with the channel index contiguous.  Each lane loads 8 key rows x
 //     16 bytes and transposes the 8x8 block of 16-bit values in registers
 //     (32 v_perm_b32), which yields the B fragments of 8 MFMAs at once.
-// A workgroup (4 waves) owns one (sequence, kv-head, split); its waves take
-// alternate 32-key tiles and merge their online-softmax states through LDS.
-// With more than one split the un-normalised partial results go to a
-// workspace and a second kernel merges them.
+// Two workgroup shapes:
+//   HKV == 1  a workgroup (4 waves) owns one (sequence, kv-head, split); its waves take alternate
+//             32-key tiles and merge their online-softmax states through LDS.  With more than one
+//             split the un-normalised partial results go to a workspace and a second kernel
+//             merges them.
+//   HKV  > 1  a workgroup (8 waves) owns one (sequence, split) with ALL its kv-heads: wave =
+//             (kv-head, tile parity).  One kv-head's rows are 256 B at a 1-KiB pitch in the cache;
+//             the waves of a workgroup move through the tiles together, so the workgroup as a whole
+//             reads whole contiguous token rows, which HBM serves at the plain streaming rate
+//             (measured with tools/membw: 6.2 TB/s against 5.6 TB/s for one kv-head per workgroup).
+//             With more than one split the partials meet in the workspace and the workgroup that
+//             arrives last for a sequence merges them (no second launch).
 #include <cstdint>
 #include <cstdlib>
 
@@ -30,6 +38,7 @@ namespace {
 
 constexpr int kTile = 32;          // keys per tile (two 16-key MFMA sub-tiles)
 constexpr int kMaxGroup = 16;      // q-heads per kv-head handled by one workgroup
+constexpr int kMaxTicketSeqs = 16384;   // sequences per call whose splits can meet inside the split kernel
 constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
@@ -61,14 +70,30 @@ __device__ __forceinline__ SplitGeom split_geom(int L, int window_left, int meta
   return g;
 }
 
+// One arrival counter per sequence for the in-kernel merge of the splits.  Zero when the module is
+// loaded; the workgroup that merges a sequence puts its counter back to zero, so every call finds
+// them zero.  Calls that overlap on one GPU (two streams) would share them: such callers serialise
+// their paged-decode calls.
+__device__ int g_split_tickets[kMaxTicketSeqs];
+
+// The workgroup-per-sequence shape pays when the sequences alone fill most of the chip: 64 sequences x 4
+// kv-heads run 100-102 us as 256 (sequence, kv-head) workgroups and 105-108 us as 64 x 4 key splits of
+// all heads (the splits' meeting costs what the access pattern gains); 192 sequences run 269 us against
+// 281 us, 512 sequences 732 us against 761 us.
+inline bool all_heads_shape(int batch, int num_kv_heads) {
+  return (num_kv_heads == 2 || num_kv_heads == 4) && batch >= 192;
+}
+
 }  // namespace
 
-// grid.x = batch * num_kv_heads * head_groups, grid.y = num_splits, NW waves per workgroup.
-template <int NW>
+// HKV == 1: grid.x = batch * num_kv_heads * head_groups; HKV > 1: grid.x = batch.  grid.y = num_splits,
+// NW waves per workgroup.
+template <int NW, int HKV>
 __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_paged_decode_args a,
                                                                  int num_splits, int head_groups,
-                                                                 float scale_log2) {
+                                                                 float scale_log2, int fused_merge) {
   constexpr int D = kHeadDim;
+  constexpr int WPH = NW / HKV;    // waves that share one kv-head's tiles
   __shared__ float s_o[NW][kMaxGroup][D];  // per-wave partial outputs
   __shared__ float s_m[NW][kMaxGroup];
   __shared__ float s_l[NW][kMaxGroup];
@@ -80,9 +105,11 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
   const int n = lane & 15;   // MFMA row/column index carried by the lane
 
   int bid = blockIdx.x;
-  const int hg = bid % head_groups; bid /= head_groups;
-  const int kvh = bid % a.num_kv_heads;
-  const int b = bid / a.num_kv_heads;
+  const int hg = HKV > 1 ? 0 : bid % head_groups;
+  if (HKV == 1) bid /= head_groups;
+  const int kvh = HKV > 1 ? wave % HKV : bid % a.num_kv_heads;
+  const int b = HKV > 1 ? bid : bid / a.num_kv_heads;
+  const int wp = HKV > 1 ? wave / HKV : wave;   // this wave's place among the waves of its kv-head
   const int split = blockIdx.y;
   const int group = a.num_heads / a.num_kv_heads;
   const int head0 = kvh * group + hg * kMaxGroup;        // first q-head of this workgroup
@@ -271,28 +298,28 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
   };
 
   // Two register sets: the next tile of this wave is in flight while the current one is consumed.
-  if (geo.lo + wave < geo.hi) {
+  if (geo.lo + wp < geo.hi) {
     TileRegs ra, rb;
-    issue(geo.lo + wave, ra);
-    for (int tile = geo.lo + wave; tile < geo.hi; tile += 2 * NW) {
-      issue(tile + NW, rb);
+    issue(geo.lo + wp, ra);
+    for (int tile = geo.lo + wp; tile < geo.hi; tile += 2 * WPH) {
+      issue(tile + WPH, rb);
       __builtin_amdgcn_sched_barrier(0);
       consume(tile, ra);
-      issue(tile + 2 * NW, ra);
+      issue(tile + 2 * WPH, ra);
       __builtin_amdgcn_sched_barrier(0);
-      consume(tile + NW, rb);
+      consume(tile + WPH, rb);
     }
   }
 
-  if (patch && tid < 32) {   // the new row into the cache (nothing in this launch reads it back)
-    const int chunk = tid & 15;
-    const bool is_v = tid >= 16;
+  if (patch && wp == 0 && lane < 32) {   // the new row into the cache (nothing in this launch reads it back)
+    const int chunk = lane & 15;
+    const bool is_v = lane >= 16;
     uint16_t* dst = const_cast<uint16_t*>(is_v ? vc : kc) + (new_slot / a.block_size) * a.cache_stride_block +
                     (new_slot % a.block_size) * a.cache_stride_pos;
     st16(dst + 8 * chunk, ld16g((is_v ? nv : nk) + 8 * chunk));
   }
 
-  // ---- merge the four waves ----
+  // ---- merge the waves of each kv-head ----
   l_run += __shfl_xor(l_run, 16);
   l_run += __shfl_xor(l_run, 32);
   if (lane < kMaxGroup) {
@@ -306,45 +333,83 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
   }
   __syncthreads();
 
-  if (tid >= 256) return;
-  const int hh = tid >> 4;          // head within the group
-  const int d0 = (tid & 15) * 8;    // 8 channels per thread
-  if (hh >= nheads) return;
-  float mw[NW], m_tot = -INFINITY;
+  float* wo = reinterpret_cast<float*>(a.workspace);
+  float* wml = wo + static_cast<int64_t>(a.batch) * a.num_heads * num_splits * D;
+  // item = (kv-head of the workgroup, head within the group, 8 channels)
+  for (int item = tid; item < HKV * 256; item += NW * 64) {
+    const int kk = item >> 8;
+    const int hh = (item >> 4) & 15;
+    const int d0 = (item & 15) * 8;
+    if (hh >= nheads) continue;
+    float mw[WPH], m_tot = -INFINITY;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    mw[w] = s_m[w][hh];
-    m_tot = fmaxf(m_tot, mw[w]);
-  }
-  float acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  float l_tot = 0.f;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    const float f = mw[w] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw[w] - m_tot);
-    l_tot += f * s_l[w][hh];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] += f * s_o[w][hh][d0 + i];
-  }
-  const int head = head0 + hh;
-  if (num_splits == 1) {
-    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-    u32x4 w;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(acc[2 * i] * inv, acc[2 * i + 1] * inv);
-    st16(reinterpret_cast<uint16_t*>(a.out) + b * a.out_stride_b + static_cast<int64_t>(head) * a.out_stride_h + d0, w);
-  } else {
-    float* wo = reinterpret_cast<float*>(a.workspace);
-    const int64_t unit = (static_cast<int64_t>(b) * a.num_heads + head) * num_splits + split;
-    float* po = wo + unit * D + d0;
-    *reinterpret_cast<f32x4*>(po) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-    *reinterpret_cast<f32x4*>(po + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
-    if ((tid & 15) == 0) {
-      float* ml = wo + static_cast<int64_t>(a.batch) * a.num_heads * num_splits * D + unit * 2;
-      ml[0] = m_tot;
-      ml[1] = l_tot;
+    for (int w = 0; w < WPH; ++w) {
+      mw[w] = s_m[HKV > 1 ? kk + HKV * w : w][hh];
+      m_tot = fmaxf(m_tot, mw[w]);
     }
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    float l_tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPH; ++w) {
+      const int ws = HKV > 1 ? kk + HKV * w : w;
+      const float f = mw[w] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw[w] - m_tot);
+      l_tot += f * s_l[ws][hh];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += f * s_o[ws][hh][d0 + i];
+    }
+    const int head = HKV > 1 ? kk * group + hh : head0 + hh;
+    if (num_splits == 1) {
+      const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+      u32x4 w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(acc[2 * i] * inv, acc[2 * i + 1] * inv);
+      st16(reinterpret_cast<uint16_t*>(a.out) + b * a.out_stride_b + static_cast<int64_t>(head) * a.out_stride_h + d0, w);
+    } else {
+      const int64_t unit = (static_cast<int64_t>(b) * a.num_heads + head) * num_splits + split;
+      float* po = wo + unit * D + d0;
+      *reinterpret_cast<f32x4*>(po) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<f32x4*>(po + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+      if ((item & 15) == 0) {
+        wml[unit * 2] = m_tot;
+        wml[unit * 2 + 1] = l_tot;
+      }
+    }
+  }
+
+  if (HKV > 1 && num_splits > 1 && fused_merge) {
+    // The workgroup that arrives last for this sequence merges the splits of all its heads.
+    if (!last_arriver(&g_split_tickets[b], num_splits, reinterpret_cast<int*>(&s_l[0][0]))) return;
+    for (int item = tid; item < a.num_heads * 16; item += NW * 64) {
+      const int head = item >> 4;
+      const int d0 = (item & 15) * 8;
+      const int64_t unit0 = (static_cast<int64_t>(b) * a.num_heads + head) * num_splits;
+      float m_tot = -INFINITY;
+      for (int sp = 0; sp < num_splits; ++sp) m_tot = fmaxf(m_tot, wml[(unit0 + sp) * 2]);
+      float acc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+      float l_tot = 0.f;
+      for (int sp = 0; sp < num_splits; ++sp) {
+        const float ms = wml[(unit0 + sp) * 2];
+        const float f = ms == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms - m_tot);
+        l_tot += f * wml[(unit0 + sp) * 2 + 1];
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(wo + (unit0 + sp) * D + d0);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(wo + (unit0 + sp) * D + d0 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i] += f * x0[i];
+          acc[4 + i] += f * x1[i];
+        }
+      }
+      const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+      u32x4 w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(acc[2 * i] * inv, acc[2 * i + 1] * inv);
+      st16(reinterpret_cast<uint16_t*>(a.out) + b * a.out_stride_b + static_cast<int64_t>(head) * a.out_stride_h + d0, w);
+    }
+    if (tid == 0) g_split_tickets[b] = 0;   // every call finds the counters zero
   }
 }
 
@@ -387,6 +452,8 @@ extern "C" int hymeta_meta_swa_paged_decode_splits(int32_t batch, int32_t num_kv
   int64_t keys = max_seqlen_k > 0 ? max_seqlen_k : 0;
   if (window_left >= 0 && keys > static_cast<int64_t>(window_left) + 1) keys = static_cast<int64_t>(window_left) + 1;
   const int64_t tiles = (num_meta > 0 ? num_meta / kTile : 0) + (keys + kTile - 1) / kTile + 1;
+  // With a workgroup per sequence on every CU, 2 or 4 kv-heads travel in one workgroup and nothing is split.
+  if (all_heads_shape(batch, num_kv_heads)) return 1;
   const int64_t units = static_cast<int64_t>(batch) * num_kv_heads;
   // One workgroup per CU already streams at the rate this access pattern allows (measured:
   // 256 workgroups = 5.2 TB/s, more splits only add merge traffic), so split just enough to
@@ -455,13 +522,25 @@ extern "C" int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args
       a.new_key = nullptr;
     }
   }
-  dim3 grid(static_cast<unsigned>(a.batch) * a.num_kv_heads * head_groups, static_cast<unsigned>(splits));
-  const char* nw_env = getenv("HYMETA_PAGED_NW");
-  const int nw = nw_env ? atoi(nw_env) : 4;
-  if (nw == 8) hipLaunchKernelGGL((paged_decode_split_kernel<8>), grid, dim3(512), 0, s, a, splits, head_groups, scale * kLog2e);
-  else hipLaunchKernelGGL((paged_decode_split_kernel<4>), grid, dim3(256), 0, s, a, splits, head_groups, scale * kLog2e);
+  // HYMETA_PAGED_SHAPE=all|head forces a shape (A/B timing, tests of the in-kernel merge of splits)
+  const char* shape_env = getenv("HYMETA_PAGED_SHAPE");
+  bool all_heads = all_heads_shape(a.batch, a.num_kv_heads);
+  if (shape_env != nullptr) all_heads = shape_env[0] == 'a' && (a.num_kv_heads == 2 || a.num_kv_heads == 4);
+  all_heads = all_heads && head_groups == 1;
+  bool fused_merge = false;
+  if (all_heads) {
+    fused_merge = a.batch <= kMaxTicketSeqs;
+    dim3 grid(static_cast<unsigned>(a.batch), static_cast<unsigned>(splits));
+    if (a.num_kv_heads == 4)
+      hipLaunchKernelGGL((paged_decode_split_kernel<8, 4>), grid, dim3(512), 0, s, a, splits, 1, scale * kLog2e, fused_merge ? 1 : 0);
+    else
+      hipLaunchKernelGGL((paged_decode_split_kernel<8, 2>), grid, dim3(512), 0, s, a, splits, 1, scale * kLog2e, fused_merge ? 1 : 0);
+  } else {
+    dim3 grid(static_cast<unsigned>(a.batch) * a.num_kv_heads * head_groups, static_cast<unsigned>(splits));
+    hipLaunchKernelGGL((paged_decode_split_kernel<4, 1>), grid, dim3(256), 0, s, a, splits, head_groups, scale * kLog2e, 0);
+  }
   if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
-  if (splits > 1) {
+  if (splits > 1 && !fused_merge) {
     hipLaunchKernelGGL(paged_decode_merge_kernel, dim3(static_cast<unsigned>(a.batch) * a.num_heads), dim3(128), 0, s, a, splits);
   }
   return launch_status();
