@@ -199,14 +199,13 @@ def test_paged_decode_fused_kv_write_equals_write_then_decode(M, window_left, sp
 
 @pytest.mark.parametrize("H,Hkv,bs,M,window_left,seq_lens,splits", [
     (28, 4, 16, 0, W, [1, W - 1, W, W + 1, 3 * W, 5], 1),        # 7B geometry, one pass
-    (28, 4, 256, 128, 4095, [5000, 4096, 4097, 17], 3),          # splits meet inside the kernel
+    (28, 4, 256, 128, 4095, [5000, 4096, 4097, 17], 3),          # key splits + merge kernel
     (14, 2, 64, 64, 127, [700, 130, 1], 5),                      # two kv-heads: four waves per kv-head
     (8, 2, 16, 0, -1, [77, 300, 31], 2),
 ])
 def test_paged_decode_all_kv_heads_per_workgroup(H, Hkv, bs, M, window_left, seq_lens, splits, monkeypatch):
     """The workgroup shape used when the sequences alone fill the chip (all kv-heads of a sequence in one
-    workgroup, splits merged by the workgroup that arrives last), forced here at small batch; two calls
-    in a row: the arrival counters must be back at zero after the first."""
+    workgroup), forced here at small batch; two calls in a row."""
     from oracle import meta_swa_paged_decode_ref
     from vllm_hymeta import hip_ops
 

@@ -17,16 +17,16 @@
 //     (32 v_perm_b32), which yields the B fragments of 8 MFMAs at once.
 // Two workgroup shapes:
 //   HKV == 1  a workgroup (4 waves) owns one (sequence, kv-head, split); its waves take alternate
-//             32-key tiles and merge their online-softmax states through LDS.  With more than one
-//             split the un-normalised partial results go to a workspace and a second kernel
-//             merges them.
+//             32-key tiles and merge their online-softmax states through LDS.
 //   HKV  > 1  a workgroup (8 waves) owns one (sequence, split) with ALL its kv-heads: wave =
 //             (kv-head, tile parity).  One kv-head's rows are 256 B at a 1-KiB pitch in the cache;
 //             the waves of a workgroup move through the tiles together, so the workgroup as a whole
 //             reads whole contiguous token rows, which HBM serves at the plain streaming rate
 //             (measured with tools/membw: 6.2 TB/s against 5.6 TB/s for one kv-head per workgroup).
-//             With more than one split the partials meet in the workspace and the workgroup that
-//             arrives last for a sequence merges them (no second launch).
+// With more than one split the un-normalised partial results go to a workspace and a second kernel
+// merges them (letting the workgroup that arrives last merge inside the split kernel was measured
+// slower: the agent-scope release / acquire around the ticket costs more than the second launch,
+// 23.9 against 19.9 us at 8 sequences, 30.8 against 27.9 us at 16).
 #include <cstdint>
 #include <cstdlib>
 
@@ -38,7 +38,6 @@ namespace {
 
 constexpr int kTile = 32;          // keys per tile (two 16-key MFMA sub-tiles)
 constexpr int kMaxGroup = 16;      // q-heads per kv-head handled by one workgroup
-constexpr int kMaxTicketSeqs = 16384;   // sequences per call whose splits can meet inside the split kernel
 constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
@@ -70,12 +69,6 @@ __device__ __forceinline__ SplitGeom split_geom(int L, int window_left, int meta
   return g;
 }
 
-// One arrival counter per sequence for the in-kernel merge of the splits.  Zero when the module is
-// loaded; the workgroup that merges a sequence puts its counter back to zero, so every call finds
-// them zero.  Calls that overlap on one GPU (two streams) would share them: such callers serialise
-// their paged-decode calls.
-__device__ int g_split_tickets[kMaxTicketSeqs];
-
 // The workgroup-per-sequence shape pays when the sequences alone fill most of the chip: 64 sequences x 4
 // kv-heads run 100-102 us as 256 (sequence, kv-head) workgroups and 105-108 us as 64 x 4 key splits of
 // all heads (the splits' meeting costs what the access pattern gains); 192 sequences run 269 us against
@@ -91,7 +84,7 @@ inline bool all_heads_shape(int batch, int num_kv_heads) {
 template <int NW, int HKV>
 __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_paged_decode_args a,
                                                                  int num_splits, int head_groups,
-                                                                 float scale_log2, int fused_merge) {
+                                                                 float scale_log2) {
   constexpr int D = kHeadDim;
   constexpr int WPH = NW / HKV;    // waves that share one kv-head's tiles
   __shared__ float s_o[NW][kMaxGroup][D];  // per-wave partial outputs
@@ -377,40 +370,6 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
       }
     }
   }
-
-  if (HKV > 1 && num_splits > 1 && fused_merge) {
-    // The workgroup that arrives last for this sequence merges the splits of all its heads.
-    if (!last_arriver(&g_split_tickets[b], num_splits, reinterpret_cast<int*>(&s_l[0][0]))) return;
-    for (int item = tid; item < a.num_heads * 16; item += NW * 64) {
-      const int head = item >> 4;
-      const int d0 = (item & 15) * 8;
-      const int64_t unit0 = (static_cast<int64_t>(b) * a.num_heads + head) * num_splits;
-      float m_tot = -INFINITY;
-      for (int sp = 0; sp < num_splits; ++sp) m_tot = fmaxf(m_tot, wml[(unit0 + sp) * 2]);
-      float acc[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-      float l_tot = 0.f;
-      for (int sp = 0; sp < num_splits; ++sp) {
-        const float ms = wml[(unit0 + sp) * 2];
-        const float f = ms == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms - m_tot);
-        l_tot += f * wml[(unit0 + sp) * 2 + 1];
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(wo + (unit0 + sp) * D + d0);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(wo + (unit0 + sp) * D + d0 + 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[i] += f * x0[i];
-          acc[4 + i] += f * x1[i];
-        }
-      }
-      const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-      u32x4 w;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(acc[2 * i] * inv, acc[2 * i + 1] * inv);
-      st16(reinterpret_cast<uint16_t*>(a.out) + b * a.out_stride_b + static_cast<int64_t>(head) * a.out_stride_h + d0, w);
-    }
-    if (tid == 0) g_split_tickets[b] = 0;   // every call finds the counters zero
-  }
 }
 
 // grid.x = batch * num_heads, 128 threads: one channel per thread.
@@ -527,20 +486,18 @@ extern "C" int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args
   bool all_heads = all_heads_shape(a.batch, a.num_kv_heads);
   if (shape_env != nullptr) all_heads = shape_env[0] == 'a' && (a.num_kv_heads == 2 || a.num_kv_heads == 4);
   all_heads = all_heads && head_groups == 1;
-  bool fused_merge = false;
   if (all_heads) {
-    fused_merge = a.batch <= kMaxTicketSeqs;
     dim3 grid(static_cast<unsigned>(a.batch), static_cast<unsigned>(splits));
     if (a.num_kv_heads == 4)
-      hipLaunchKernelGGL((paged_decode_split_kernel<8, 4>), grid, dim3(512), 0, s, a, splits, 1, scale * kLog2e, fused_merge ? 1 : 0);
+      hipLaunchKernelGGL((paged_decode_split_kernel<8, 4>), grid, dim3(512), 0, s, a, splits, 1, scale * kLog2e);
     else
-      hipLaunchKernelGGL((paged_decode_split_kernel<8, 2>), grid, dim3(512), 0, s, a, splits, 1, scale * kLog2e, fused_merge ? 1 : 0);
+      hipLaunchKernelGGL((paged_decode_split_kernel<8, 2>), grid, dim3(512), 0, s, a, splits, 1, scale * kLog2e);
   } else {
     dim3 grid(static_cast<unsigned>(a.batch) * a.num_kv_heads * head_groups, static_cast<unsigned>(splits));
-    hipLaunchKernelGGL((paged_decode_split_kernel<4, 1>), grid, dim3(256), 0, s, a, splits, head_groups, scale * kLog2e, 0);
+    hipLaunchKernelGGL((paged_decode_split_kernel<4, 1>), grid, dim3(256), 0, s, a, splits, head_groups, scale * kLog2e);
   }
   if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
-  if (splits > 1 && !fused_merge) {
+  if (splits > 1) {
     hipLaunchKernelGGL(paged_decode_merge_kernel, dim3(static_cast<unsigned>(a.batch) * a.num_heads), dim3(128), 0, s, a, splits);
   }
   return launch_status();
