@@ -229,15 +229,25 @@ def shard70b_side_measurement(dev, B=64, ctx=32768, chunk=2048):
             attn(layer)
 
     def timed(fn, iters=10):
+        """ms per call, replayed from a HIP graph of ``iters`` calls (as a serving loop replays its decode
+        step), so that kernels shorter than a Python launch are timed on the GPU's clock."""
         fn()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(iters):
+                    fn()
+        graph.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            fn()
+        for _ in range(3):
+            graph.replay()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters
+        return e0.elapsed_time(e1) / (3 * iters)
 
     t_step = timed(step, 5)
     t_win, t_full, t_gla = timed(lambda: attn(0)), timed(lambda: attn(3)), timed(lambda: gla(1))
