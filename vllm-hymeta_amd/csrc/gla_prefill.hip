@@ -650,15 +650,25 @@ __device__ __forceinline__ void load_vf(const KTiles& t, int wave, int lane, bf1
 }
 
 // Outputs of one query head for one chunk (the query half of consume_chunk).
-__device__ __forceinline__ void consume_q(const KTiles& kt, const QTiles& qt, float (&o)[CH][LDF], const f32x4 (&s_acc)[8][2],
+// k~ fragments of a chunk (A-operand of the A^T blocks): the same for every query head of the group.
+__device__ __forceinline__ void load_kfr(const KTiles& t, int lane, bf16x8 (&kfr)[2][4]) {
+  const int c = lane >> 4, n = lane & 15;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kfr[0][ks] = as_frag(ld16(&t.kr[n][32 * ks + 8 * c]));
+    kfr[1][ks] = as_frag(ld16(&t.kr[16 + n][32 * ks + 8 * c]));
+  }
+}
+
+__device__ __forceinline__ void consume_q(const bf16x8 (&kfr)[2][4], const QTiles& qt, float (&o)[CH][LDF], const f32x4 (&s_acc)[8][2],
                                           const bf16x8 (&vf)[2], int wave, int lane) {
   const int c = lane >> 4, n = lane & 15;
   f32x4 at00 = {0, 0, 0, 0}, at01 = {0, 0, 0, 0}, at11 = {0, 0, 0, 0};
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int off = 32 * ks + 8 * c;
-    const bf16x8 k0 = as_frag(ld16(&kt.kr[n][off]));
-    const bf16x8 k1 = as_frag(ld16(&kt.kr[16 + n][off]));
+    const bf16x8 k0 = kfr[0][ks];
+    const bf16x8 k1 = kfr[1][ks];
     const bf16x8 q0 = as_frag(ld16(&qt.qc[n][off]));
     const bf16x8 q1 = as_frag(ld16(&qt.qc[16 + n][off]));
     const bf16x8 qh = as_frag(ld16(&qt.qh1[n][off]));
@@ -845,6 +855,7 @@ __global__ __launch_bounds__(kThreads) void gla_prefill_group_kernel(hymeta_gla_
     __syncthreads();   // tiles of unit 0 are ready
     int ci = 0, r = 0;
     int cim = 0, rm = 0;    // (chunk, head) of unit u - 1
+    bf16x8 vf[2], kfr[2][4];   // fragments of the chunk's key side, loaded at its first unit
     for (int u = 0; u <= U; ++u) {
       if (MODE == kFull && u >= 1) {
         Seg so = sg;
@@ -854,9 +865,11 @@ __global__ __launch_bounds__(kThreads) void gla_prefill_group_kernel(hymeta_gla_
       }
       if (u < U) {
         const KTiles& kt = sm.k[ci & 1];
-        bf16x8 vf[2];
-        load_vf(kt, wave, lane, vf);
-        if (MODE == kFull) consume_q(kt, sm.q[u & 1], sm.o[u & 1], s_acc, vf, wave, lane);
+        if (r == 0) {
+          load_vf(kt, wave, lane, vf);
+          if (MODE == kFull) load_kfr(kt, lane, kfr);
+        }
+        if (MODE == kFull) consume_q(kfr, sm.q[u & 1], sm.o[u & 1], s_acc, vf, wave, lane);
         if (r == urep - 1) update_state(kt, s_acc, vf, lane);
         if (++r == urep) { r = 0; ++ci; }
       }
