@@ -22,6 +22,9 @@ def _expand(state_kv, rep):
     (5, 8, 2, torch.float32, "plain"),          # fp32 state, 4 query heads per group
     (5, 7, 1, torch.bfloat16, "70b_clamp"),     # first-layer 70B gate on a TP=4 shard
     (160, 28, 4, torch.bfloat16, "plain"),      # many units: whole rows per workgroup, no norm
+    (4, 8, 4, torch.bfloat16, "7b_norm"),       # 2 query heads per group
+    (3, 16, 2, torch.float32, "7b_norm"),       # 8 query heads per group, fp32 state with the fused norm
+    (3, 6, 2, torch.bfloat16, "plain"),         # 3 query heads per group
 ])
 def test_gla_decode_group_state_equals_per_head_state(B, H, Hkv, state_dtype, mode):
     from vllm_hymeta import _C, hip_ops
@@ -74,32 +77,48 @@ def test_gla_group_state_rejects_the_lower_bound_gate():
                                    gate_mode=_C.GATE_70B_LOWER_BOUND, lower_bound=lb)
 
 
-@pytest.mark.parametrize("lens,H,Hkv,nseg,state_dtype", [
-    ([33, 64, 5], 28, 4, 1, torch.bfloat16),     # single runs: final states staged, then committed
-    ([257, 40], 7, 1, 1, torch.float32),
-    ([600, 90], 4, 2, 3, torch.bfloat16),        # segmented runs
+@pytest.mark.parametrize("lens,H,Hkv,nseg,state_dtype,mode", [
+    ([33, 64, 5], 28, 4, 1, torch.bfloat16, "plain"),      # single runs
+    ([257, 40], 7, 1, 1, torch.float32, "plain"),
+    ([600, 90], 4, 2, 3, torch.bfloat16, "plain"),         # segmented runs
+    ([300, 31, 64], 28, 4, 1, torch.bfloat16, "7b_norm"),  # fused 7B gate and per-head norm
+    ([700], 14, 2, 4, torch.bfloat16, "7b_norm"),
+    ([130, 257], 7, 1, 2, torch.bfloat16, "70b_clamp"),    # first-layer 70B gate, first chunks start from the meta state
 ])
-def test_gla_prefill_group_state_equals_per_head_state(lens, H, Hkv, nseg, state_dtype):
-    from vllm_hymeta import hip_ops
+def test_gla_prefill_group_state_equals_per_head_state(lens, H, Hkv, nseg, state_dtype, mode):
+    from vllm_hymeta import _C, hip_ops
 
     rep = H // Hkv
     T, nseq = sum(lens), len(lens)
     g_ = gen(22)
     q, k, v = randn_bf16(g_, T, H, D), randn_bf16(g_, T, Hkv, D), randn_bf16(g_, T, Hkv, D)
-    g = (torch.nn.functional.logsigmoid(torch.randn(T, Hkv, D, generator=g_)) / 16).to(torch.bfloat16)
+    kw_group, kw_head = {}, {}
+    if mode == "plain":
+        g = (torch.nn.functional.logsigmoid(torch.randn(T, Hkv, D, generator=g_)) / 16).to(torch.bfloat16).cuda()
+    elif mode == "7b_norm":
+        g = randn_bf16(g_, T, Hkv, D, scale=2.0).cuda()
+        kw_group = dict(gate_mode=_C.GATE_7B, out_norm_weight=(1 + 0.1 * torch.randn(D, generator=g_)).to(torch.bfloat16).cuda())
+        kw_head = kw_group
+    else:
+        g = None
+        meta = (torch.randn(Hkv, D, D, generator=g_) * 0.1).to(state_dtype)
+        kw_group = dict(gate_mode=_C.GATE_70B_CLAMP, meta_state=meta.cuda())
+        kw_head = dict(gate_mode=_C.GATE_70B_CLAMP, meta_state=_expand(meta[None], rep)[0].cuda())
     cu = torch.tensor(np.cumsum([0] + lens), dtype=torch.int32).cuda()
     slots = nseq + 2
     state_kv = (torch.randn(slots, Hkv, D, D, generator=g_) * 0.1).to(state_dtype)
     slot = torch.randperm(slots, generator=g_)[:nseq].to(torch.int32).cuda()
-    # sequence 0 resumes from its state, the others start from zero
+    # sequence 0 resumes from its state, the others start from zero (or the meta state)
     ctx = torch.tensor([17] + [0] * (nseq - 1), dtype=torch.int32).cuda()
     s_group, s_head = state_kv.cuda(), _expand(state_kv, rep).cuda()
-    args = (q.cuda(), k.cuda(), v.cuda(), g.cuda())
-    o_group = hip_ops.gla_prefill_varlen(*args, s_group, slot, cu, max(lens), context_lens=ctx, num_segments=nseg)
-    o_head = hip_ops.gla_prefill_varlen(*args, s_head, slot, cu, max(lens), context_lens=ctx, num_segments=nseg)
+    args = (q.cuda(), k.cuda(), v.cuda(), g)
+    o_group = hip_ops.gla_prefill_varlen(*args, s_group, slot, cu, max(lens), context_lens=ctx, num_segments=nseg, **kw_group)
+    o_head = hip_ops.gla_prefill_varlen(*args, s_head, slot, cu, max(lens), context_lens=ctx, num_segments=nseg, **kw_head)
     torch.cuda.synchronize()
     assert torch.equal(o_group, o_head)
     assert torch.equal(_expand(s_group, rep), s_head)
+    if mode != "plain":
+        return
     # and a decode step continues from either layout alike
     B = nseq
     qd, kd, vd = randn_bf16(g_, B, H, D).cuda(), randn_bf16(g_, B, Hkv, D).cuda(), randn_bf16(g_, B, Hkv, D).cuda()
