@@ -295,8 +295,9 @@ def shard70b_side_measurement(dev, B=64, ctx=32768, chunk=2048):
 def model_decode_side_measurement(dev, w, B, s, quant):
     """One decode token for every sequence through the WHOLE 28-layer stack (random-init Hymeta-7B
     geometry): block norms, qkv / gate / output projections and the gated MLP around the same
-    attention kernels, caches and metadata as the timed hot path.  ``quant`` = "bf16" (library GEMMs)
-    or "gptq4" (GPTQ 4-bit, group 128, the fused dequant-GEMM).  Replayed from one HIP graph, as the
+    attention kernels, caches and metadata as the timed hot path.  ``quant`` = "bf16" (library GEMMs),
+    "w8a8" (int8 weights, per-token int8 activations, the int8-MFMA GEMM) or "gptq4" (GPTQ 4-bit, group 128,
+    the fused dequant-GEMM).  Replayed from one HIP graph, as the
     serving engine replays its decode step.  Outside the timed region; reported beside the value."""
     from vllm_hymeta import _C, hip_ops
     from vllm_hymeta.linear import HymetaLinear
@@ -311,6 +312,10 @@ def model_decode_side_measurement(dev, w, B, s, quant):
         if quant == "bf16":
             wt = (torch.randn(out_f, in_f, device=dev, dtype=torch.float32) * in_f ** -0.5).to(torch.bfloat16)
             return HymetaLinear.from_weight(wt, b)
+        if quant == "w8a8":   # int8 per-channel weights, dynamic per-token int8 activations (hf_model/quant_w8a8.py:121-124)
+            qw8 = torch.randint(-127, 128, (out_f, in_f), dtype=torch.int8, device=dev)
+            ws = (torch.rand(out_f, device=dev) * (2.0 / 127) * in_f ** -0.5).float()
+            return HymetaLinear.from_w8a8(qw8, ws, bias=b)
         qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // 8, out_f), dtype=torch.int32, device=dev)
         qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // group, out_f // 8), dtype=torch.int32, device=dev)
         sc = (torch.rand(in_f // group, out_f, device=dev) * (0.25 * in_f ** -0.5)).to(torch.float16)
@@ -378,7 +383,7 @@ def model_decode_side_measurement(dev, w, B, s, quant):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    wbytes = (N_GLA + N_SWA) * (qkv_n * hidden + hidden * H * D + 3 * inter * hidden) * (2.0 if quant == "bf16" else 0.5)
+    wbytes = (N_GLA + N_SWA) * (qkv_n * hidden + hidden * H * D + 3 * inter * hidden) * {"bf16": 2.0, "w8a8": 1.0, "gptq4": 0.5}[quant]
     return {"ms_per_step": round(ms, 4), "tokens_per_s": round(B / (ms * 1e-3), 1),
             "linear_weight_bytes": int(wbytes), "layers": N_GLA + N_SWA, "sequences": B}
 
@@ -540,7 +545,7 @@ def main():
     if world == 1 and not args.no_prefill:
         line["prefill"] = prefill_side_measurement(dev, args.prefill_ctx)
     if world == 1 and not args.no_model:
-        line["model_decode"] = {q: model_decode_side_measurement(dev, w, B, total - 1, q) for q in ("bf16", "gptq4")}
+        line["model_decode"] = {q: model_decode_side_measurement(dev, w, B, total - 1, q) for q in ("bf16", "w8a8", "gptq4")}
     if world == 1 and not args.no_model:
         del w
         torch.cuda.empty_cache()
