@@ -762,22 +762,60 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(hymeta_w8a8_gemm_args a,
   const int split = blockIdx.z;
   const int ks_lo = split * steps_per_split;
   const int ks_hi = min(a.K / 64, ks_lo + steps_per_split);
-  for (int ks = ks_lo + wave; ks < ks_hi; ks += 4) {
-    const int k0 = 64 * ks + 16 * c;
-    i32x4 bfrag[4];
+  // At 33..64 rows a k-step is 16 MFMAs against two microseconds of load latency, and a launch holds two
+  // or three waves per SIMD: each wave keeps a ring of four k-steps' fragments in flight.  Loads are
+  // unconditional (a step past the slice re-reads its last step, a row past M re-reads row M - 1 and is
+  // zeroed) so that the compiler can count them.
+  struct Frags {
+    i32x4 b[4];
+    i32x4 a[MT];
+  };
+  const int8_t* wrow[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {   // n-tile i: output channels 64 nb + 16 i + n
-      const int8_t* wp = a.qweight + static_cast<int64_t>(nb * kColsPerBlock + 16 * i + n) * a.K + k0;
-      bfrag[i] = __builtin_bit_cast(i32x4, ld16(wp));
-    }
+  for (int i = 0; i < 4; ++i)   // n-tile i: output channels 64 nb + 16 i + n
+    wrow[i] = a.qweight + static_cast<int64_t>(nb * kColsPerBlock + 16 * i + n) * a.K + 16 * c;
+  const int8_t* xrow[MT];
+  bool xlive[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = m0 + 16 * mt + n;
+    xlive[mt] = row < a.M;
+    xrow[mt] = a.xq + static_cast<int64_t>(min(row, a.M - 1)) * a.K + 16 * c;
+  }
+  auto load = [&](int ks, Frags& f) {
+    const int k0 = 64 * min(ks, ks_hi - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.b[i] = __builtin_bit_cast(i32x4, ld16g(wrow[i] + k0));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) f.a[mt] = __builtin_bit_cast(i32x4, ld16g(xrow[mt] + k0));
+  };
+  auto mma = [&](const Frags& f) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int row = m0 + 16 * mt + n;
-      i32x4 afrag = {0, 0, 0, 0};
-      if (row < a.M) afrag = __builtin_bit_cast(i32x4, ld16(a.xq + static_cast<int64_t>(row) * a.K + k0));
+      const i32x4 afrag = xlive[mt] ? f.a[mt] : i32x4{0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        acc[mt][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag, bfrag[i], acc[mt][i], 0, 0, 0);
+        acc[mt][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag, f.b[i], acc[mt][i], 0, 0, 0);
+    }
+  };
+  if constexpr (MT < 4) {
+    // up to 32 rows the plain loop already streams the weights (4.5-4.8 TB/s on the widest matrix) and
+    // the ring measured slower (fewer waves resident)
+    for (int ks = ks_lo + wave; ks < ks_hi; ks += 4) {
+      Frags f;
+      load(ks, f);
+      mma(f);
+    }
+  } else if (ks_lo + wave < ks_hi) {
+    Frags f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load(ks_lo + wave + 4 * u, f[u]);
+    for (int ks = ks_lo + wave; ks < ks_hi; ks += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (ks + 4 * u < ks_hi) mma(f[u]);
+        load(ks + 16 + 4 * u, f[u]);
+      }
     }
   }
   // acc[mt][i][r] = C[row 16 mt + 4c + r][col 16 i + n]
