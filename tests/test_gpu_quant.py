@@ -126,16 +126,16 @@ def test_gptq_linear_large_m_uses_expanded_weights():
         assert_bf16_close(out.cpu(), ref, f"gptq linear M={M}", rel=8e-3)
 
 
-@pytest.mark.parametrize("M,K,N", [(300, 512, 256), (1024, 3584, 4608)])
+@pytest.mark.parametrize("M,K,N", [(300, 512, 256), (1024, 3584, 4608), (40, 3584, 4608), (72, 2048, 256)])
 def test_w8a8_linear_prefill_regime_matches_fused_kernel_exactly(M, K, N):
-    """Above the row threshold the linear runs quantise -> library int8 GEMM -> scale; the int32 sums
-    are exact on both paths, so the outputs agree bit for bit with the fused kernel's and with the
-    oracle within the bf16 tolerance."""
+    """Above the row threshold (lower for wide matrices than for deep narrow ones) the linear runs
+    quantise -> library int8 GEMM -> scale; the int32 sums are exact on both paths, so the outputs
+    agree bit for bit with the fused kernel's and with the oracle within the bf16 tolerance."""
     from oracle.quant import w8a8_gemm_ref
     from vllm_hymeta import hip_ops
-    from vllm_hymeta.linear import HymetaLinear, W8A8_LIBRARY_ROWS
+    from vllm_hymeta.linear import HymetaLinear, w8a8_use_library
 
-    assert M > W8A8_LIBRARY_ROWS
+    assert w8a8_use_library(M, K, N) and not w8a8_use_library(32, K, N) and not w8a8_use_library(64, 2048, 256)
     g_ = gen(21)
     x = randn_bf16(g_, M, K)
     wq = torch.randint(-127, 128, (N, K), generator=g_, dtype=torch.int8)
