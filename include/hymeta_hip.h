@@ -496,7 +496,15 @@ int hymeta_add_rmsnorm(const hymeta_add_rmsnorm_args* args, hymeta_stream_t stre
  * hymeta_gptq_gemm_workspace_bytes(M, N, 0), is a bound that holds for every K.  Without a
  * workspace the library runs unsplit.  split_k > 1 forces that many slices and needs
  * hymeta_gptq_gemm_workspace_bytes(M, N, split_k) bytes.
+ *
+ * Workspace contract of the three split-K GEMMs (hymeta_gptq_gemm, hymeta_bf16_gemm,
+ * hymeta_w8a8_gemm): the first HYMETA_GEMM_TICKET_BYTES bytes are the ticket counters.  Zero them
+ * ONCE when the workspace is allocated (hipMemset); every call leaves them zero, so no call spends
+ * a memset on them.  The rest is scratch with no content carried between calls.  One workspace can
+ * serve all three entry points, one call at a time (calls that share a workspace must be ordered
+ * on one stream).
  * ---------------------------------------------------------------------- */
+#define HYMETA_GEMM_TICKET_BYTES 16384
 typedef struct hymeta_gptq_gemm_args {
   const void* x;          /* bf16 [M, K] */
   const int32_t* qweight;
@@ -544,7 +552,7 @@ typedef struct hymeta_bf16_gemm_args {
   const void* weight;     /* bf16 [N, K] */
   const void* bias;       /* bf16 [N] or NULL */
   void* out;              /* bf16 [M, N] */
-  void* workspace;        /* [ticket counters][fp32 slabs], or NULL */
+  void* workspace;        /* [ticket counters, see hymeta_gptq_gemm][fp32 slabs], or NULL */
   size_t workspace_bytes;
   int32_t M, K, N;
   int32_t split_k;

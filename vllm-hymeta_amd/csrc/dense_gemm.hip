@@ -151,7 +151,7 @@ extern "C" int hymeta_bf16_gemm_split_k(int32_t M, int32_t K, int32_t N) {
 
 extern "C" size_t hymeta_bf16_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
   if (M <= 0 || N <= 0) return 0;
-  const size_t counters = (static_cast<size_t>(N / kCols) * sizeof(int) + 255) / 256 * 256;
+  const size_t counters = kTicketBytes;   // zero at first use, left zero by every call
   if (split_k <= 0) {   // a bound for whatever the library chooses: tiles x slices <= 256 + tiles
     const size_t tiles = N / kCols > 0 ? N / kCols : 1;
     return counters + (256 + tiles) * kCols * static_cast<size_t>(M) * sizeof(float);
@@ -174,17 +174,16 @@ extern "C" int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream
   const int ksteps = a.K / 32;
   int splits = a.split_k > 0 ? a.split_k : (a.workspace != nullptr ? hymeta_bf16_gemm_split_k(a.M, a.K, a.N) : 1);
   if (splits > ksteps) splits = ksteps;
+  if (a.N / kCols > kMaxTickets) splits = 1;
   const int sps = (ksteps + splits - 1) / splits;
   splits = (ksteps + sps - 1) / sps;
-  const size_t counter_bytes = (static_cast<size_t>(a.N / kCols) * sizeof(int) + 255) / 256 * 256;
+  const size_t counter_bytes = kTicketBytes;
   if (splits > 1 && (a.workspace == nullptr ||
                      a.workspace_bytes < counter_bytes + static_cast<size_t>(splits) * a.M * a.N * sizeof(float)))
     return HYMETA_ERR_WORKSPACE;
   hipStream_t s = begin_launches(stream);
   int* counters = static_cast<int*>(a.workspace);
   float* slabs = reinterpret_cast<float*>(static_cast<char*>(a.workspace) + counter_bytes);
-  if (splits > 1 && hipMemsetAsync(counters, 0, static_cast<size_t>(a.N / kCols) * sizeof(int), s) != hipSuccess)
-    return HYMETA_ERR_LAUNCH;
   const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
   const dim3 grid(a.N / kCols, splits), block(256);
   const size_t lds = static_cast<size_t>(4) * 16 * mt * kCols * sizeof(float);

@@ -19,6 +19,7 @@
 // where sum_k x comes from one extra MFMA against an all-ones B fragment.
 #include <type_traits>
 
+#include <cstdlib>
 #include "common.h"
 
 namespace hymeta {
@@ -912,11 +913,9 @@ extern "C" int hymeta_gptq_gemm_split_k(int32_t M, int32_t K, int32_t N, int32_t
   return static_cast<int>(want);
 }
 
-static size_t gptq_counter_bytes(int M, int N) {
-  return (static_cast<size_t>(gptq_tiles(M, N)) * sizeof(int) + 255) / 256 * 256;
-}
+static size_t gptq_counter_bytes(int, int) { return kTicketBytes; }
 
-// workspace = [ticket counters, zeroed per call][fp32 slabs]
+// workspace = [ticket counters: zero at first use, left zero by every call][fp32 slabs]
 extern "C" size_t hymeta_gptq_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
   if (M <= 0 || N <= 0 || split_k == 1) return 0;
   // split_k <= 0 (the library chooses): never more (tile, slice) pairs than kMaxPairs, whatever K is
@@ -958,6 +957,7 @@ extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream
   const bool autosplit = a.split_k <= 0;
   int splits = autosplit ? hymeta_gptq_gemm_split_k(a.M, a.K, a.N, a.group_size) : a.split_k;
   if (autosplit && a.workspace == nullptr) splits = 1;
+  if (gptq_tiles(a.M, a.N) > kMaxTickets) splits = 1;
   if (splits > units) splits = units;
   const size_t counter_bytes = gptq_counter_bytes(a.M, a.N);
   if (a.workspace != nullptr && a.workspace_bytes < hymeta_gptq_gemm_workspace_bytes(a.M, a.N, autosplit ? 0 : splits))
@@ -986,8 +986,7 @@ extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream
   hipStream_t s = begin_launches(stream);
   int* counters = reinterpret_cast<int*>(a.workspace);
   float* slabs = a.workspace == nullptr ? nullptr : reinterpret_cast<float*>(reinterpret_cast<char*>(a.workspace) + counter_bytes);
-  if (tickets && hipMemsetAsync(counters, 0, static_cast<size_t>(gptq_tiles(a.M, a.N)) * sizeof(int), s) != hipSuccess)
-    return HYMETA_ERR_LAUNCH;
+  (void)tickets;
   if (wide) {
     dim3 grid(plan.tiles_n * ((a.M + 63) / 64), splits), block(kWideThreads);
     if (plan.mode == 1) grid = dim3(plan.wgs);
@@ -1055,8 +1054,8 @@ extern "C" int hymeta_w8a8_gemm_split_k(int32_t M, int32_t K, int32_t N) {
 
 extern "C" size_t hymeta_w8a8_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
   if (M <= 0 || N <= 0 || split_k <= 1) return 0;
-  // [int32 slabs [split_k][M][N]][ticket counters]
-  return static_cast<size_t>(split_k) * M * N * sizeof(int) + gptq_counter_bytes(M, N);
+  // [ticket counters: zero at first use, left zero by every call][int32 slabs [split_k][M][N]]
+  return kTicketBytes + static_cast<size_t>(split_k) * M * N * sizeof(int);
 }
 
 extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream) {
@@ -1074,16 +1073,14 @@ extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream
   const int ksteps = a.K / 64;
   int splits = a.split_k > 0 ? a.split_k : (a.workspace != nullptr ? hymeta_w8a8_gemm_split_k(a.M, a.K, a.N) : 1);
   if (splits > ksteps) splits = ksteps;
+  if (gptq_tiles(a.M, a.N) > kMaxTickets) splits = 1;
   if (splits > 1 && (a.workspace == nullptr || a.workspace_bytes < hymeta_w8a8_gemm_workspace_bytes(a.M, a.N, splits)))
     return HYMETA_ERR_WORKSPACE;
-  const int requested = splits;
   const int sps = (ksteps + splits - 1) / splits;
   splits = (ksteps + sps - 1) / sps;
   hipStream_t s = begin_launches(stream);
-  int* slabs = static_cast<int*>(a.workspace);
-  int* counters = reinterpret_cast<int*>(static_cast<char*>(a.workspace) + static_cast<size_t>(requested) * a.M * a.N * sizeof(int));
-  if (splits > 1 && hipMemsetAsync(counters, 0, static_cast<size_t>(gptq_tiles(a.M, a.N)) * sizeof(int), s) != hipSuccess)
-    return HYMETA_ERR_LAUNCH;
+  int* counters = static_cast<int*>(a.workspace);
+  int* slabs = reinterpret_cast<int*>(static_cast<char*>(a.workspace) + kTicketBytes);
   hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
   if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
   const int mt = mt_for(a.M);

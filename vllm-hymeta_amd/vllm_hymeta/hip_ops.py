@@ -258,11 +258,12 @@ _workspaces = {}
 
 
 def _workspace(device: torch.device, nbytes: int, tag: str = "paged_decode") -> torch.Tensor:
-    """Grow-only per-device, per-op scratch (split-KV partials, prefill segment states); reuse is
-    ordered by the stream the ops run on."""
+    """Grow-only per-device, per-op scratch (split-KV partials, prefill segment states, split-K slabs);
+    reuse is ordered by the stream the ops run on.  Born zero-filled: the split-K GEMMs keep their
+    ticket counters at the front of theirs and leave them zero after every call."""
     ws = _workspaces.get((device, tag))
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[(device, tag)] = ws
     return ws
 
