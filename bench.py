@@ -341,11 +341,16 @@ def model_decode_side_measurement(dev, w, B, s, quant):
     x0 = (torch.randn(B, hidden, generator=g) * 0.5).to(torch.bfloat16).to(dev)
 
     def step():
-        x = x0
+        # the residual stream travels beside the blocks' outputs, as in the model classes: the sum
+        # happens inside the next block's fused add + norm
+        x, res = x0, None
         i_gla = i_swa = 0
         for lay in layers:
-            res = x.clone()
-            h = hip_ops.add_rmsnorm(x, lay["n1"], 1e-6)
+            if res is None:
+                res = x.clone()
+                h = hip_ops.add_rmsnorm(x, lay["n1"], 1e-6)
+            else:
+                h = hip_ops.add_rmsnorm(x, lay["n1"], 1e-6, residual=res)
             qkv = lay["qkv"](h)
             q, k, v = split_qkv(qkv, B)
             if lay["gla"]:
@@ -363,8 +368,8 @@ def model_decode_side_measurement(dev, w, B, s, quant):
                 i_swa += 1
             a_out = lay["o"](att.view(B, H * D))
             n2 = hip_ops.add_rmsnorm(a_out, lay["n2"], 1e-6, residual=res)
-            x = res + lay["down"](hip_ops.silu_and_mul(lay["gate_up"](n2)))
-        return x
+            x = lay["down"](hip_ops.silu_and_mul(lay["gate_up"](n2)))
+        return hip_ops.add_rmsnorm(x, layers[0]["n1"], 1e-6, residual=res)     # the model's final norm
 
     for _ in range(2):
         step()

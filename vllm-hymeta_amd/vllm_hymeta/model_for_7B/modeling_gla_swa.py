@@ -94,17 +94,20 @@ class GLAswaModel(torch.nn.Module):
         hidden_states = self.get_input_embeddings(input_ids) if inputs_embeds is None else inputs_embeds
 
         gla_index = swa_index = 0
+        residual = None      # the residual stream travels beside the blocks' outputs (fused add + norm)
         for i, layer in enumerate(self.layers):
             if i in self.config.attn_layers:
                 kv = kv_caches[swa_index] if kv_caches is not None else torch.empty(0, device=hidden_states.device)
                 swa_index += 1
-                hidden_states, _ = layer(hidden_states, positions=positions, kv_cache=kv, attn_metadata=attn_metadata)
+                hidden_states, residual = layer(hidden_states, carry_residual=True, residual=residual, positions=positions,
+                                                kv_cache=kv, attn_metadata=attn_metadata)
             else:
                 p = params.at_layer_idx(gla_index)
                 gla_index += 1
-                hidden_states, _ = layer(hidden_states, gla_cache=p.gla_cache, state_indices_tensor=p.state_indices_tensor,
-                                         attn_metadata=attn_metadata)
-        return self.norm(hidden_states)
+                hidden_states, residual = layer(hidden_states, carry_residual=True, residual=residual,
+                                                gla_cache=p.gla_cache, state_indices_tensor=p.state_indices_tensor,
+                                                attn_metadata=attn_metadata)
+        return self.norm(hidden_states, residual)[0] if residual is not None else self.norm(hidden_states)
 
 
 class GLAswaForCausalLM(torch.nn.Module):

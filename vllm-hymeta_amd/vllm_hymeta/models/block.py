@@ -51,15 +51,26 @@ class DecoderBlock(torch.nn.Module):
         super().__init__()
         self.attn_norm, self.attn, self.mlp_norm, self.mlp = attn_norm, attn, mlp_norm, mlp
 
-    def forward(self, hidden_states: torch.Tensor, attn_fn=None, **attn_kwargs) -> Tuple[torch.Tensor, None]:
+    def forward(self, hidden_states: torch.Tensor, attn_fn=None, carry_residual: bool = False,
+                residual: Optional[torch.Tensor] = None, **attn_kwargs) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """``attn_fn``: call this on the normed input instead of ``self.attn(normed, **attn_kwargs)``
-        (the 70B model's one-off pass of the meta tokens uses the layer's ``prepare_meta_state``)."""
-        # the block's input becomes the residual stream; it is updated in place by mlp_norm, so
-        # take a private copy when the caller keeps using its tensor
-        residual = hidden_states.clone()
-        normed = self.attn_norm(hidden_states)
+        (the 70B model's one-off pass of the meta tokens uses the layer's ``prepare_meta_state``).
+
+        ``carry_residual``: return ``(mlp output, residual stream)`` instead of their sum, and take the pair
+        of the block before (``residual`` None for the first block).  The sum then happens inside the next
+        block's fused add + norm (or the model's final norm) instead of in two launches of its own per
+        block; the values are the same (the sum is rounded to bf16 either way)."""
+        if carry_residual and residual is not None:
+            normed, residual = self.attn_norm(hidden_states, residual)    # residual += hidden_states, in place
+        else:
+            # the block's input becomes the residual stream; it is updated in place by mlp_norm, so
+            # take a private copy when the caller keeps using its tensor
+            residual = hidden_states.clone()
+            normed = self.attn_norm(hidden_states)
         attn_out = attn_fn(normed) if attn_fn is not None else self.attn(normed, **attn_kwargs)
         normed, residual = self.mlp_norm(attn_out, residual)
+        if carry_residual:
+            return self.mlp(normed), residual
         return residual + self.mlp(normed), None
 
 

@@ -132,14 +132,16 @@ class HymetaModel(torch.nn.Module):
         kwargs.setdefault("finished_requests_ids", [])
         params = HymetaCacheParams(*self.hymeta_cache.current_run_tensors(**kwargs))
         hidden_states = self.get_input_embeddings(input_ids) if inputs_embeds is None else inputs_embeds
+        residual = None      # the residual stream travels beside the blocks' outputs (fused add + norm)
         for i, layer in enumerate(self.layers):
             c = params.at_layer_idx(i)
             kv = kv_caches[i] if kv_caches is not None else torch.empty(0, device=hidden_states.device)
-            hidden_states, _ = layer(hidden_states, positions=positions, kv_cache=kv, hymeta_cache=c.hymeta_cache,
-                                     meta_linear_cache=c.meta_linear_cache, meta_fattn_cache=c.meta_fattn_cache,
-                                     state_indices_tensor=c.state_indices_tensor, attn_metadata=attn_metadata,
-                                     lower_bound=self._lower_bound(i))
-        return self.norm(hidden_states)
+            hidden_states, residual = layer(hidden_states, carry_residual=True, residual=residual, positions=positions,
+                                            kv_cache=kv, hymeta_cache=c.hymeta_cache,
+                                            meta_linear_cache=c.meta_linear_cache, meta_fattn_cache=c.meta_fattn_cache,
+                                            state_indices_tensor=c.state_indices_tensor, attn_metadata=attn_metadata,
+                                            lower_bound=self._lower_bound(i))
+        return self.norm(hidden_states, residual)[0] if residual is not None else self.norm(hidden_states)
 
 
 class HymetaForCausalLM(torch.nn.Module):
