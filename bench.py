@@ -354,7 +354,7 @@ def model_decode_side_measurement(dev, w, B, s, quant):
             qkv = lay["qkv"](h)
             q, k, v = split_qkv(qkv, B)
             if lay["gla"]:
-                gk = torch.nn.functional.linear(torch.nn.functional.linear(h, lay["gk0"]), lay["gk1"], lay["gk1_b"])
+                gk = hip_ops.lowrank_gate(h, lay["gk0"], lay["gk1"], lay["gk1_b"])
                 att = hip_ops.gla_decode(q, k, v, gk.view(B, HKV, D), w["state"][i_gla], w["slot_idx"],
                                          gate_mode=_C.GATE_7B, out_norm_weight=w["g_norm"], out_norm_eps=1e-6)
                 i_gla += 1

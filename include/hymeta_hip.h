@@ -469,6 +469,31 @@ typedef struct hymeta_add_rmsnorm_args {
 
 int hymeta_add_rmsnorm(const hymeta_add_rmsnorm_args* args, hymeta_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * The rank-16 gate projection of the 7B GLA layer in one launch.
+ * Replaces the two un-quantised linears of gk_proj
+ * (vllm_hymeta/model_for_7B/gla_attention.py:157-176: hidden -> 16 without bias,
+ * 16 -> num_kv_heads * head_dim with bias; hf_7B_model/gla_attention.py:108-112)
+ * for decode-sized batches, where each of the two library GEMMs is a launch of its own:
+ *   t   = bf16( x w0^T )            [num_tokens, 16], fp32 sums
+ *   out = bf16( t w1^T + bias )     [num_tokens, out_features], fp32 sums
+ * rank must be 16, hidden a multiple of 8.
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_lowrank_gate_args {
+  const void* x;         /* bf16 [num_tokens, hidden] */
+  const void* w0;        /* bf16 [rank, hidden], contiguous */
+  const void* w1;        /* bf16 [out_features, rank], contiguous */
+  const void* bias;      /* bf16 [out_features] or NULL */
+  void* out;             /* bf16 [num_tokens, out_features] */
+  int32_t num_tokens;
+  int32_t hidden;
+  int32_t rank;          /* 16 */
+  int32_t out_features;
+  int64_t x_stride_t, out_stride_t;
+} hymeta_lowrank_gate_args;
+
+int hymeta_lowrank_gate(const hymeta_lowrank_gate_args* args, hymeta_stream_t stream);
+
 
 /* ------------------------------------------------------------------------
  * Fused dequant-GEMM for GPTQ checkpoints: out = x W (+ bias), W dequantised on

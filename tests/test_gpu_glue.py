@@ -106,3 +106,28 @@ def test_add_rmsnorm_rejects_bad_layout():
     w = torch.ones(130, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(Exception):
         hip_ops.add_rmsnorm(x, w)
+
+
+@pytest.mark.parametrize("T,hidden,N,with_bias", [(1, 3584, 512, True), (64, 3584, 512, True), (5, 512, 256, False), (37, 1024, 128, True)])
+def test_lowrank_gate_equals_the_two_linears(T, hidden, N, with_bias):
+    """The rank-16 gate projection in one launch against its two linears (fp32 sums of bf16 products,
+    the intermediate and the result rounded to bf16, as ``model_for_7B/gla_attention.py:157-176`` computes them)."""
+    from vllm_hymeta import hip_ops
+
+    g_ = gen(71)
+    x = randn_bf16(g_, T, hidden)
+    w0 = randn_bf16(g_, 16, hidden, scale=hidden ** -0.5)
+    w1 = randn_bf16(g_, N, 16, scale=0.25)
+    b = randn_bf16(g_, N, scale=0.1) if with_bias else None
+    t = (x.double() @ w0.double().t()).to(torch.bfloat16)
+    ref = t.double() @ w1.double().t() + (b.double() if b is not None else 0.0)
+    out = hip_ops.lowrank_gate(x.cuda(), w0.cuda(), w1.cuda(), None if b is None else b.cuda())
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), ref, f"lowrank gate T={T}")
+    # rows of a wider buffer as input and output
+    buf = randn_bf16(g_, T, hidden + 64).cuda()
+    wide = torch.zeros(T, N + 32, dtype=torch.bfloat16, device="cuda")
+    hip_ops.lowrank_gate(buf[:, :hidden], w0.cuda(), w1.cuda(), None if b is None else b.cuda(), out=wide[:, :N])
+    again = hip_ops.lowrank_gate(buf[:, :hidden].contiguous(), w0.cuda(), w1.cuda(), None if b is None else b.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(wide[:, :N], again) and (wide[:, N:] == 0).all()

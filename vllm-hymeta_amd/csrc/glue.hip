@@ -195,6 +195,90 @@ extern "C" int hymeta_hybrid_combine(const hymeta_combine_args* args, hymeta_str
   return launch_status();
 }
 
+namespace hymeta {
+
+// One token per workgroup: 16 dot products over the hidden size (w0 is 16 rows, read by every
+// workgroup and served by the L2), summed over the workgroup, rounded to bf16 as the first linear's
+// output is, then the 16 -> out_features expansion with bias.
+__global__ __launch_bounds__(256) void lowrank_gate_kernel(hymeta_lowrank_gate_args a) {
+  constexpr int R = 16;
+  __shared__ float s_part[4][R];
+  __shared__ float s_t[R];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint16_t* x = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(blockIdx.x) * a.x_stride_t;
+  const uint16_t* w0 = reinterpret_cast<const uint16_t*>(a.w0);
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  for (int ch = tid; ch < a.hidden / 8; ch += 256) {
+    const u32x4 xv = ld16(x + 8 * ch);
+    float xf[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xf[2 * i] = lo_bf(xv[i]);
+      xf[2 * i + 1] = hi_bf(xv[i]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const u32x4 wv = ld16(w0 + static_cast<int64_t>(r) * a.hidden + 8 * ch);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[r] = fmaf(xf[2 * i], lo_bf(wv[i]), acc[r]);
+        acc[r] = fmaf(xf[2 * i + 1], hi_bf(wv[i]), acc[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) acc[r] += __shfl_xor(acc[r], off);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) s_part[wave][r] = acc[r];
+  }
+  __syncthreads();
+  if (tid < R) s_t[tid] = bf16_round(s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid]);
+  __syncthreads();
+  float t[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) t[r] = s_t[r];
+  const uint16_t* w1 = reinterpret_cast<const uint16_t*>(a.w1);
+  uint16_t* out = reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(blockIdx.x) * a.out_stride_t;
+  for (int o = tid; o < a.out_features; o += 256) {
+    const u32x4 wa = ld16(w1 + static_cast<int64_t>(o) * R), wb = ld16(w1 + static_cast<int64_t>(o) * R + 8);
+    float y = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      y = fmaf(t[2 * i], lo_bf(wa[i]), y);
+      y = fmaf(t[2 * i + 1], hi_bf(wa[i]), y);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      y = fmaf(t[8 + 2 * i], lo_bf(wb[i]), y);
+      y = fmaf(t[8 + 2 * i + 1], hi_bf(wb[i]), y);
+    }
+    if (a.bias != nullptr) y += bf2f(reinterpret_cast<const uint16_t*>(a.bias)[o]);
+    out[o] = f2bf(y);
+  }
+}
+
+}  // namespace hymeta
+
+extern "C" int hymeta_lowrank_gate(const hymeta_lowrank_gate_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_lowrank_gate_args& a = *args;
+  if (a.num_tokens < 0 || a.hidden <= 0 || a.out_features <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.num_tokens == 0) return HYMETA_OK;
+  if (!a.x || !a.w0 || !a.w1 || !a.out) return HYMETA_ERR_INVALID_ARG;
+  if (a.rank != 16 || a.hidden % 8 != 0 || a.x_stride_t % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.w0) | reinterpret_cast<uintptr_t>(a.w1)) % 16 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  hipStream_t s = hymeta::begin_launches(stream);
+  hipLaunchKernelGGL(hymeta::lowrank_gate_kernel, dim3(a.num_tokens), dim3(256), 0, s, a);
+  return hymeta::launch_status();
+}
+
 extern "C" int hymeta_add_rmsnorm(const hymeta_add_rmsnorm_args* args, hymeta_stream_t stream) {
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
   const hymeta_add_rmsnorm_args& a = *args;

@@ -149,6 +149,14 @@ class AddRmsNormArgs(C.Structure):
     ]
 
 
+class LowrankGateArgs(C.Structure):
+    _fields_ = [
+        ("x", _ptr), ("w0", _ptr), ("w1", _ptr), ("bias", _ptr), ("out", _ptr),
+        ("num_tokens", _i32), ("hidden", _i32), ("rank", _i32), ("out_features", _i32),
+        ("x_stride_t", _i64), ("out_stride_t", _i64),
+    ]
+
+
 class GptqGemmArgs(C.Structure):
     _fields_ = [
         ("x", _ptr), ("qweight", _ptr), ("qzeros", _ptr), ("scales", _ptr), ("bias", _ptr), ("out", _ptr),
@@ -224,6 +232,7 @@ _SIGNATURES = {
     "hymeta_rms_sumsq2": (C.c_int, [C.POINTER(CombineArgs), _ptr]),
     "hymeta_hybrid_combine": (C.c_int, [C.POINTER(CombineArgs), _ptr]),
     "hymeta_add_rmsnorm": (C.c_int, [C.POINTER(AddRmsNormArgs), _ptr]),
+    "hymeta_lowrank_gate": (C.c_int, [C.POINTER(LowrankGateArgs), _ptr]),
     "hymeta_gptq_gemm_split_k": (C.c_int, [_i32, _i32, _i32, _i32]),
     "hymeta_gptq_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "hymeta_gptq_gemm": (C.c_int, [C.POINTER(GptqGemmArgs), _ptr]),
@@ -251,6 +260,7 @@ STRUCTS = {
     "hymeta_rope_args": RopeArgs,
     "hymeta_combine_args": CombineArgs,
     "hymeta_add_rmsnorm_args": AddRmsNormArgs,
+    "hymeta_lowrank_gate_args": LowrankGateArgs,
     "hymeta_gptq_gemm_args": GptqGemmArgs,
     "hymeta_w8a8_gemm_args": W8A8GemmArgs,
     "hymeta_moe_route_args": MoeRouteArgs,

@@ -563,6 +563,31 @@ def add_rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, residu
     return out
 
 
+LOWRANK_GATE_ROWS = 256     # above this the two library GEMMs are ahead (w0 is re-read per token here)
+
+
+def lowrank_gate(x: torch.Tensor, w0: torch.Tensor, w1: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16( bf16(x w0^T) w1^T + bias ): the rank-16 gate projection of the 7B GLA layer in one launch.
+    x [T, hidden]; w0 [16, hidden]; w1 [N, 16]; bias [N] -> [T, N]."""
+    _dev(x, w0, w1, bias, out)
+    T, hidden = x.shape
+    N = w1.shape[0]
+    _require(x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [T, hidden]")
+    _require(w0.dtype == torch.bfloat16 and w0.is_contiguous() and w0.shape == (16, hidden), "w0 must be contiguous bf16 [16, hidden]")
+    _require(w1.dtype == torch.bfloat16 and w1.is_contiguous() and w1.shape == (N, 16), "w1 must be contiguous bf16 [N, 16]")
+    _require(bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N),
+             "bias must be contiguous bf16 [N]")
+    if out is None:
+        out = torch.empty(T, N, dtype=torch.bfloat16, device=x.device)
+    _require(out.shape == (T, N) and out.dtype == torch.bfloat16 and out.stride(1) == 1, "out must be row-contiguous bf16 [T, N]")
+    a = _C.LowrankGateArgs(x=x.data_ptr(), w0=w0.data_ptr(), w1=w1.data_ptr(), bias=_p(bias), out=out.data_ptr(),
+                           num_tokens=T, hidden=hidden, rank=16, out_features=N,
+                           x_stride_t=x.stride(0), out_stride_t=out.stride(0))
+    _C.check(_C.load().hymeta_lowrank_gate(C.byref(a), _stream(x)), "hymeta_lowrank_gate")
+    return out
+
+
 # ---------------------------------------------------------------------------
 # Quantised linears
 # ---------------------------------------------------------------------------

@@ -46,7 +46,12 @@ class GatedLinearAttention(torch.nn.Module):
         q = qkv[:, : H * D].view(T, H, D)
         k = qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
         v = qkv[:, (H + Hkv) * D:].view(T, Hkv, D)
-        gk = self.gk_proj1(self.gk_proj0(hidden_states)).view(T, Hkv, D)
+        p0, p1 = self.gk_proj0, self.gk_proj1
+        if (T <= hip_ops.LOWRANK_GATE_ROWS and p0.kind == "bf16" and p1.kind == "bf16" and p0.bias is None
+                and p0.weight.shape[0] == 16 and p0.weight.is_contiguous() and p1.weight.is_contiguous()):
+            gk = hip_ops.lowrank_gate(hidden_states, p0.weight, p1.weight, p1.bias).view(T, Hkv, D)   # one launch
+        else:
+            gk = p1(p0(hidden_states)).view(T, Hkv, D)
         out = torch.empty(T, H, D, dtype=hidden_states.dtype, device=hidden_states.device)
         n_pre = getattr(attn_metadata, "num_prefills", 0)
         t_pre = getattr(attn_metadata, "num_prefill_tokens", 0)
