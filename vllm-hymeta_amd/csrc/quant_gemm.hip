@@ -19,7 +19,6 @@
 // where sum_k x comes from one extra MFMA against an all-ones B fragment.
 #include <type_traits>
 
-#include <cstdlib>
 #include "common.h"
 
 namespace hymeta {
@@ -982,11 +981,9 @@ extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream
       }
     }
   }
-  const bool tickets = plan.mode == 1 ? plan.left_slices > 1 : splits > 1;
   hipStream_t s = begin_launches(stream);
   int* counters = reinterpret_cast<int*>(a.workspace);
   float* slabs = a.workspace == nullptr ? nullptr : reinterpret_cast<float*>(reinterpret_cast<char*>(a.workspace) + counter_bytes);
-  (void)tickets;
   if (wide) {
     dim3 grid(plan.tiles_n * ((a.M + 63) / 64), splits), block(kWideThreads);
     if (plan.mode == 1) grid = dim3(plan.wgs);
