@@ -315,3 +315,15 @@ def test_7b_decoder_block_gla_with_dense_mlp():
     assert second is None
     assert torch.equal(xd.cpu(), x), "the block must not modify its input"
     assert_bf16_close(out.cpu(), ref, "7B decoder block", rel=1e-2)
+
+    # the residual stream carried beside the block's output (what the model classes do): same values,
+    # and a second block fed with the pair equals a second block fed with the sum
+    md = _md(dev, prefill_lens=[T], context_lens=[0])
+    slot = torch.tensor([1], dtype=torch.int32, device=dev)
+    delta, stream = block(xd, carry_residual=True, gla_cache=cache.zero_(), state_indices_tensor=slot, attn_metadata=md)
+    assert torch.equal((stream + delta), out) and torch.equal(xd.cpu(), x)
+    out2, _ = block(out, gla_cache=cache.zero_(), state_indices_tensor=slot, attn_metadata=md)
+    delta2, stream2 = block(delta, carry_residual=True, residual=stream, gla_cache=cache.zero_(), state_indices_tensor=slot,
+                            attn_metadata=md)
+    torch.cuda.synchronize()
+    assert torch.equal(stream2 + delta2, out2)
