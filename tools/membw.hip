@@ -4,6 +4,11 @@
 #include <cstdint>
 #include <vector>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifdef NONTEMPORAL   // build with -DNONTEMPORAL: every load carries the non-temporal hint
+#define LD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define LD(ptr) (*(ptr))
+#endif
 
 // plain streaming: grid-stride, 16 B per lane, UNROLL loads in flight per lane
 template <int UNROLL>
@@ -14,7 +19,7 @@ __global__ __launch_bounds__(256) void stream_read(const u32x4* __restrict__ p, 
   for (; i + (UNROLL - 1) * blockDim.x < n16; i += stride) {
     u32x4 v[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) v[u] = p[i + u * blockDim.x];
+    for (int u = 0; u < UNROLL; ++u) v[u] = LD(&p[i + u * blockDim.x]);
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) acc ^= v[u];
   }
@@ -34,7 +39,7 @@ __global__ __launch_bounds__(256) void strided_rows(const char* __restrict__ bas
     u32x4 v[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u)
-      v[u] = *reinterpret_cast<const u32x4*>(p + (r + u * 16 + row_in) * 1024 + lane16 * 16);
+      v[u] = LD(reinterpret_cast<const u32x4*>(p + (r + u * 16 + row_in) * 1024 + lane16 * 16));
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) acc ^= v[u];
   }
@@ -60,25 +65,25 @@ __global__ __launch_bounds__(256) void tile_rows(const char* __restrict__ base, 
     u32x4 v[16];
     if (MODE == 0) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const u32x4*>(p + (r + 4 * j + c) * 1024 + n * 16);
+      for (int j = 0; j < 8; ++j) v[j] = LD(reinterpret_cast<const u32x4*>(p + (r + 4 * j + c) * 1024 + n * 16));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[8 + j] = *reinterpret_cast<const u32x4*>(p2 + (r + 4 * j + c) * 1024 + n * 16);
+      for (int j = 0; j < 8; ++j) v[8 + j] = LD(reinterpret_cast<const u32x4*>(p2 + (r + 4 * j + c) * 1024 + n * 16));
     } else if (MODE == 1) {
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) v[4 * s + ks] = *reinterpret_cast<const u32x4*>(p + (r + 16 * s + n) * 1024 + ks * 64 + c * 16);
+        for (int ks = 0; ks < 4; ++ks) v[4 * s + ks] = LD(reinterpret_cast<const u32x4*>(p + (r + 16 * s + n) * 1024 + ks * 64 + c * 16));
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) v[8 + 4 * s + ks] = *reinterpret_cast<const u32x4*>(p2 + (r + 16 * s + n) * 1024 + ks * 64 + c * 16);
+        for (int ks = 0; ks < 4; ++ks) v[8 + 4 * s + ks] = LD(reinterpret_cast<const u32x4*>(p2 + (r + 16 * s + n) * 1024 + ks * 64 + c * 16));
     } else {
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) v[4 * s + ks] = *reinterpret_cast<const u32x4*>(p + (r + 16 * s + n) * 1024 + ks * 64 + c * 16);
+        for (int ks = 0; ks < 4; ++ks) v[4 * s + ks] = LD(reinterpret_cast<const u32x4*>(p + (r + 16 * s + n) * 1024 + ks * 64 + c * 16));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[8 + j] = *reinterpret_cast<const u32x4*>(p2 + (r + 4 * j + c) * 1024 + n * 16);
+      for (int j = 0; j < 8; ++j) v[8 + j] = LD(reinterpret_cast<const u32x4*>(p2 + (r + 4 * j + c) * 1024 + n * 16));
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc ^= v[u];
@@ -100,9 +105,9 @@ __global__ __launch_bounds__(512) void tile_rows_allheads(const char* __restrict
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) v[4 * s + ks] = *reinterpret_cast<const u32x4*>(p + (r + 16 * s + n) * 1024 + ks * 64 + c * 16);
+      for (int ks = 0; ks < 4; ++ks) v[4 * s + ks] = LD(reinterpret_cast<const u32x4*>(p + (r + 16 * s + n) * 1024 + ks * 64 + c * 16));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[8 + j] = *reinterpret_cast<const u32x4*>(p2 + (r + 4 * j + c) * 1024 + n * 16);
+    for (int j = 0; j < 8; ++j) v[8 + j] = LD(reinterpret_cast<const u32x4*>(p2 + (r + 4 * j + c) * 1024 + n * 16));
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc ^= v[u];
   }

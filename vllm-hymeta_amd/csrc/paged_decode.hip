@@ -192,12 +192,12 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
     for (int s = 0; s < 2; ++s) {
       const uint16_t* kp = krow[s] + static_cast<int64_t>(n) * row_stride + 8 * c;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) r.k[s][ks] = ld16g(kp + 32 * ks);
+      for (int ks = 0; ks < 4; ++ks) r.k[s][ks] = ld16nt(kp + 32 * ks);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint16_t* vp = vrow[j >> 2] + static_cast<int64_t>(4 * c + (j & 3)) * row_stride + 8 * n;
-      r.v[j] = ld16g(vp);
+      r.v[j] = ld16nt(vp);
     }
   };
 
