@@ -69,12 +69,12 @@ __device__ __forceinline__ SplitGeom split_geom(int L, int window_left, int meta
   return g;
 }
 
-// The workgroup-per-sequence shape pays when the sequences alone fill most of the chip: 64 sequences x 4
-// kv-heads run 100-102 us as 256 (sequence, kv-head) workgroups and 105-108 us as 64 x 4 key splits of
-// all heads (the splits' meeting costs what the access pattern gains); 192 sequences run 269 us against
-// 281 us, 512 sequences 732 us against 761 us.
+// The workgroup-per-sequence shape pays from 64 sequences up (KV rows read with the non-temporal hint):
+// 64 sequences run 95.5 us as 64 x 4 key splits of all kv-heads + merge against 99.4 us as 256 (sequence,
+// kv-head) workgroups, 128 sequences 181 against 198 us, 256 sequences 322-338 against 357-383 us; below
+// 64 sequences the per-kv-head workgroups are ahead (16 sequences: 32 against 39 us).
 inline bool all_heads_shape(int batch, int num_kv_heads) {
-  return (num_kv_heads == 2 || num_kv_heads == 4) && batch >= 192;
+  return (num_kv_heads == 2 || num_kv_heads == 4) && batch >= 64;
 }
 
 }  // namespace
@@ -187,6 +187,12 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_split_kernel(hymeta_page
         krow[s] = kc + off;
         vrow[s] = vc + off;
       }
+    }
+    if (tile_raw > tile_last) {
+      // past this wave's last tile the loads stay (the compiler counts them) but fetch one hot row:
+      // with the non-temporal hint a re-read of the last tile would come from HBM again
+      krow[0] = krow[1] = vrow[0] = vrow[1] = qrow;
+      row_stride = 0;
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -411,8 +417,14 @@ extern "C" int hymeta_meta_swa_paged_decode_splits(int32_t batch, int32_t num_kv
   int64_t keys = max_seqlen_k > 0 ? max_seqlen_k : 0;
   if (window_left >= 0 && keys > static_cast<int64_t>(window_left) + 1) keys = static_cast<int64_t>(window_left) + 1;
   const int64_t tiles = (num_meta > 0 ? num_meta / kTile : 0) + (keys + kTile - 1) / kTile + 1;
-  // With a workgroup per sequence on every CU, 2 or 4 kv-heads travel in one workgroup and nothing is split.
-  if (all_heads_shape(batch, num_kv_heads)) return 1;
+  if (all_heads_shape(batch, num_kv_heads)) {
+    // one round of workgroups: as many key splits as keep (sequences x splits) within the compute units
+    // (measured best: 64 -> 4, 96 and 128 -> 2, 192 and more -> 1), at least 2 tiles per wave
+    int64_t want = 256 / batch;
+    const int64_t cap = tiles / (2 * (8 / num_kv_heads));
+    if (want > cap) want = cap;
+    return want < 1 ? 1 : static_cast<int>(want);
+  }
   const int64_t units = static_cast<int64_t>(batch) * num_kv_heads;
   // One workgroup per CU already streams at the rate this access pattern allows (measured:
   // 256 workgroups = 5.2 TB/s, more splits only add merge traffic), so split just enough to
