@@ -69,12 +69,11 @@ __device__ __forceinline__ SplitGeom split_geom(int L, int window_left, int meta
   return g;
 }
 
-// The workgroup-per-sequence shape pays from 64 sequences up (KV rows read with the non-temporal hint):
-// 64 sequences run 95.5 us as 64 x 4 key splits of all kv-heads + merge against 99.4 us as 256 (sequence,
-// kv-head) workgroups, 128 sequences 181 against 198 us, 256 sequences 322-338 against 357-383 us; below
-// 64 sequences the per-kv-head workgroups are ahead (16 sequences: 32 against 39 us).
+// The workgroup-per-sequence shape pays from about 48 sequences up (7B geometry, 4097 keys, us per launch
+// incl. the merge of key splits; per-kv-head workgroups / all kv-heads per workgroup, best split count each):
+// 16: 31 / 35, 32: 53 / 52, 48: 82 / 72, 64: 100 / 91, 128: 196 / 175, 256: 388 / 336.
 inline bool all_heads_shape(int batch, int num_kv_heads) {
-  return (num_kv_heads == 2 || num_kv_heads == 4) && batch >= 64;
+  return (num_kv_heads == 2 || num_kv_heads == 4) && batch >= 48;
 }
 
 }  // namespace
@@ -419,7 +418,7 @@ extern "C" int hymeta_meta_swa_paged_decode_splits(int32_t batch, int32_t num_kv
   const int64_t tiles = (num_meta > 0 ? num_meta / kTile : 0) + (keys + kTile - 1) / kTile + 1;
   if (all_heads_shape(batch, num_kv_heads)) {
     // one round of workgroups: as many key splits as keep (sequences x splits) within the compute units
-    // (measured best: 64 -> 4, 96 and 128 -> 2, 192 and more -> 1), at least 2 tiles per wave
+    // (measured best: 48 -> 5, 64 -> 4, 128 -> 2, 192 and more -> 1), at least 2 tiles per wave
     int64_t want = 256 / batch;
     const int64_t cap = tiles / (2 * (8 / num_kv_heads));
     if (want > cap) want = cap;
