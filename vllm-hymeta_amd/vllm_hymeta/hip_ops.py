@@ -255,6 +255,7 @@ def reshape_and_cache(
 # Paged decode attention (sliding window + meta keys)
 # ---------------------------------------------------------------------------
 _workspaces = {}
+_retired = []
 
 
 def _workspace(device: torch.device, nbytes: int, tag: str = "paged_decode") -> torch.Tensor:
@@ -263,6 +264,8 @@ def _workspace(device: torch.device, nbytes: int, tag: str = "paged_decode") -> 
     ticket counters at the front of theirs and leave them zero after every call."""
     ws = _workspaces.get((device, tag))
     if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _retired.append(ws)     # a captured HIP graph may still hold its address: never hand it back
         ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[(device, tag)] = ws
     return ws
