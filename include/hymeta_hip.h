@@ -65,6 +65,10 @@ enum hymeta_gate_mode {
 
 const char* hymeta_strerror(int code);
 int hymeta_abi_version(void);
+/* Host helper with no counterpart in the reference: *id = the identifier of the graph capture `stream` is
+ * recording into (unique per capture), 0 when the stream is not capturing.  The Python front end uses it to
+ * give every captured graph its own clearing of the split-K ticket counters (see hymeta_gptq_gemm). */
+int hymeta_stream_capture_id(hymeta_stream_t stream, uint64_t* id);
 
 /* ------------------------------------------------------------------------
  * GLA single-token decode step with slot-indexed in-place state.

@@ -33,6 +33,39 @@ def test_rope_neox_in_place_with_meta_offset():
     assert torch.equal(dev.cpu()[:, (H + Hkv) * D:], qkv[:, (H + Hkv) * D:])
 
 
+def test_rope_last_position_with_meta_offset_stays_inside_the_table():
+    """The 70B model ropes real token p at p + num_meta_tokens, so its table holds max_pos + M rows: the last
+    position of a full-length sequence reads the last row.  A position past the table is clamped to that row
+    (never read out of bounds)."""
+    from oracle.layers import rope_cos_sin_cache_ref, rope_neox_ref
+    from vllm_hymeta import hip_ops
+
+    H, Hkv, M, max_pos = 7, 1, 128, 512
+    g_ = gen(3)
+    cache = rope_cos_sin_cache_ref(D, max_pos + M, 1e6)
+    pos = torch.tensor([max_pos - 1, 0, max_pos + 5], dtype=torch.int64)       # last row, first row, beyond the table
+    q, k = randn_bf16(g_, 3, H, D), randn_bf16(g_, 3, Hkv, D)
+    q_ref, k_ref = rope_neox_ref(torch.tensor([max_pos - 1 + M, M, max_pos + M - 1]), q, k, cache)
+    # the table sits at the very end of its allocation
+    buf = torch.zeros((max_pos + M) * D, dtype=torch.bfloat16, device="cuda")
+    buf.copy_(cache.reshape(-1))
+    qd, kd = q.cuda(), k.cuda()
+    hip_ops.rope_neox_(pos.cuda(), qd, kd, buf.view(max_pos + M, D), position_offset=M)
+    torch.cuda.synchronize()
+    assert_bf16_close(qd.cpu(), q_ref, "rope q at the table's last row", rel=2e-3)
+    assert_bf16_close(kd.cpu(), k_ref, "rope k at the table's last row", rel=2e-3)
+
+
+def test_70b_model_rope_table_covers_the_meta_offset():
+    from types import SimpleNamespace
+    from vllm_hymeta.models.modeling_hymeta import HymetaModel
+
+    cfg = SimpleNamespace(num_attention_heads=4, num_key_value_heads=2, head_dim=D, hidden_size=4 * D, num_hidden_layers=1,
+                          use_lower_bound=False, num_meta_tokens=128, max_position_embeddings=300, rope_theta=1e6)
+    m = HymetaModel(cfg, max_num_seqs=2, device="cuda")
+    assert m.cos_sin_cache.shape == (300 + 128, D)
+
+
 @pytest.mark.parametrize("tp", [1, 4])
 def test_hybrid_combine(tp):
     from oracle.layers import hybrid_combine_ref, rms_norm_tp_ref

@@ -162,3 +162,23 @@ def test_stack_experts_layout():
                 assert torch.equal(w13[e, :per], experts[e]["gate_proj"][rank * per:(rank + 1) * per])
                 assert torch.equal(w13[e, per:], experts[e]["up_proj"][rank * per:(rank + 1) * per])
                 assert torch.equal(w2[e], experts[e]["down_proj"][:, rank * per:(rank + 1) * per])
+
+
+def test_make_linear_casts_checkpoint_floats_to_bf16():
+    """gptqmodel / llmcompressor checkpoints keep biases, scales and the layers they leave un-quantised in the
+    checkpoint's float type (often fp16): the linear must end up with bf16 bias and weight (the kernels' types),
+    fp16 scales are taken as they are."""
+    g = torch.Generator().manual_seed(5)
+    t = _gptq(g, 64, 32)
+    t["scales"] = t["scales"].to(torch.float16)
+    t["bias"] = torch.randn(32, generator=g).to(torch.float16)
+    lin = loader.make_linear(t, 4, 32)
+    assert lin.kind == "gptq" and lin.bias.dtype == torch.bfloat16 and lin.scales.dtype == torch.float16
+    assert torch.equal(lin.bias, t["bias"].to(torch.bfloat16))
+    dense = {"weight": torch.randn(32, 64, generator=g).to(torch.float16), "bias": torch.randn(32, generator=g).to(torch.float16)}
+    lin = loader.make_linear(dense)
+    assert lin.kind == "bf16" and lin.weight.dtype == torch.bfloat16 and lin.bias.dtype == torch.bfloat16
+    w8 = {"weight": torch.randint(-128, 128, (32, 64), generator=g).to(torch.int8),
+          "weight_scale": torch.rand(32, 1, generator=g).to(torch.float16), "bias": torch.randn(32, generator=g).to(torch.float16)}
+    lin = loader.make_linear(w8)
+    assert lin.kind == "w8a8" and lin.qweight.dtype == torch.int8 and lin.w_scale.dtype == torch.float32 and lin.bias.dtype == torch.bfloat16

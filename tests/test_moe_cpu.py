@@ -57,7 +57,7 @@ def _worker(rank, world, port, ret):
         logits = randn_bf16(g_, T, E)
         whole = moe_ref(x, logits, w13, w2)
         share = moe_ref(x, logits, w13, w2, local_experts=expert_range(E, world, rank))
-        total = all_reduce_sum(share.float())
+        total = all_reduce_sum(share.float(), dist.group.WORLD)
         assert torch.equal(total.to(torch.bfloat16), whole)      # top-1: the shares have disjoint support
         ret[rank] = "ok"
     finally:

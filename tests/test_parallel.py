@@ -74,7 +74,12 @@ def _worker(rank, world, port, ret):
 
         # this rank's heads: attention needs no communication
         s = shard_heads(H, Hkv, world, rank)
-        assert tp_rank_and_size() == (rank, world)
+        tp = dist.group.WORLD
+        assert tp_rank_and_size(tp) == (rank, world)
+        # without a group nothing is reduced, even though a process group exists (replicas, DP, PP)
+        assert tp_rank_and_size() == (0, 1)
+        probe = torch.full((2,), float(rank + 1))
+        assert torch.equal(all_reduce_sum(probe.clone()), probe) and torch.equal(all_reduce_variance(probe.clone()), probe)
         hs = slice(s.head_start, s.head_start + s.num_heads)
         ks = slice(s.kv_head_start, s.kv_head_start + s.num_kv_heads)
         lrep = s.num_heads // s.num_kv_heads
@@ -86,14 +91,14 @@ def _worker(rank, world, port, ret):
         a_loc = o_attn[:, cols]
         # variance all-reduce: per-rank mean of squares -> mean over the full hidden size
         stats = torch.stack([a_loc.float().pow(2).mean(-1), loc.float().pow(2).mean(-1)], dim=-1)
-        stats = all_reduce_variance(stats)
+        stats = all_reduce_variance(stats, tp)
         ref_var = torch.stack([o_attn.float().pow(2).mean(-1), full.float().pow(2).mean(-1)], dim=-1)
         torch.testing.assert_close(stats, ref_var, rtol=1e-6, atol=1e-7)
         n1 = rms_norm_tp_ref(a_loc, w1[cols], stats[:, 0:1], 1e-6)
         n2 = rms_norm_tp_ref(loc, w2[cols], stats[:, 1:2], 1e-6)
         y_loc = ((n1.float() + n2.float()) / 2).to(torch.bfloat16)
         # row-parallel out projection: partial products summed over ranks
-        y = all_reduce_sum(y_loc.float() @ w_out[:, cols].t())
+        y = all_reduce_sum(y_loc.float() @ w_out[:, cols].t(), tp)
         torch.testing.assert_close(y, y_full, rtol=2e-2, atol=2e-2)
         ret[rank] = "ok"
     finally:

@@ -13,3 +13,15 @@ extern "C" const char* hymeta_strerror(int code) {
     default: return "unknown hymeta status";
   }
 }
+
+extern "C" int hymeta_stream_capture_id(hymeta_stream_t stream, uint64_t* id) {
+  if (id == nullptr) return HYMETA_ERR_INVALID_ARG;
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long cid = 0;
+  if (hipStreamGetCaptureInfo(static_cast<hipStream_t>(stream), &status, &cid) != hipSuccess) {
+    (void)hipGetLastError();
+    return HYMETA_ERR_LAUNCH;
+  }
+  *id = status == hipStreamCaptureStatusActive ? static_cast<uint64_t>(cid) : 0;
+  return HYMETA_OK;
+}

@@ -9,7 +9,9 @@ __global__ __launch_bounds__(256) void rope_neox_kernel(hymeta_rope_args a) {
   const int t = blockIdx.x;
   const int half = a.rot_dim / 2;
   const int chunks = half / 8;                 // 16-byte chunks per half head
-  const int64_t pos = a.positions[t] + a.position_offset;
+  // positions outside the table are the caller's error; they are clamped to its last row rather than read past it
+  int64_t pos = a.positions[t] + a.position_offset;
+  pos = pos < 0 ? 0 : (pos >= a.max_position ? a.max_position - 1 : pos);
   const uint16_t* cs = reinterpret_cast<const uint16_t*>(a.cos_sin_cache) + pos * a.rot_dim;
   const int total_heads = a.num_heads + (a.k != nullptr ? a.num_kv_heads : 0);
   for (int w = threadIdx.x; w < total_heads * chunks; w += blockDim.x) {

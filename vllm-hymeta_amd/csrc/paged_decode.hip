@@ -439,6 +439,19 @@ extern "C" int hymeta_meta_swa_paged_decode_splits(int32_t batch, int32_t num_kv
   return static_cast<int>(want);
 }
 
+namespace {
+
+// HYMETA_PAGED_SHAPE=all|head forces a workgroup shape (A/B timing, tests of both shapes); read once per process.
+int forced_shape() {
+  static const int shape = [] {
+    const char* e = getenv("HYMETA_PAGED_SHAPE");
+    return e == nullptr ? 0 : (e[0] == 'a' ? 1 : 2);
+  }();
+  return shape;
+}
+
+}  // namespace
+
 extern "C" int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args, hymeta_stream_t stream) {
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
   hymeta_paged_decode_args a = *args;
@@ -495,10 +508,8 @@ extern "C" int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args
       a.new_key = nullptr;
     }
   }
-  // HYMETA_PAGED_SHAPE=all|head forces a shape (A/B timing, tests of the in-kernel merge of splits)
-  const char* shape_env = getenv("HYMETA_PAGED_SHAPE");
   bool all_heads = all_heads_shape(a.batch, a.num_kv_heads);
-  if (shape_env != nullptr) all_heads = shape_env[0] == 'a' && (a.num_kv_heads == 2 || a.num_kv_heads == 4);
+  if (forced_shape() != 0) all_heads = forced_shape() == 1 && (a.num_kv_heads == 2 || a.num_kv_heads == 4);
   all_heads = all_heads && head_groups == 1;
   if (all_heads) {
     dim3 grid(static_cast<unsigned>(a.batch), static_cast<unsigned>(splits));

@@ -24,6 +24,7 @@ GATE_70B_CLAMP = 2
 GATE_70B_LOWER_BOUND = 3
 
 ABI_VERSION = 1
+GEMM_TICKET_BYTES = 16384
 
 _i32, _i64, _f32, _ptr, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -217,6 +218,7 @@ class MoeCombineArgs(C.Structure):
 _SIGNATURES = {
     "hymeta_strerror": (C.c_char_p, [C.c_int]),
     "hymeta_abi_version": (C.c_int, []),
+    "hymeta_stream_capture_id": (C.c_int, [_ptr, C.POINTER(C.c_uint64)]),
     "hymeta_gla_decode": (C.c_int, [C.POINTER(GlaDecodeArgs), _ptr]),
     "hymeta_gla_prefill_varlen": (C.c_int, [C.POINTER(GlaPrefillArgs), _ptr]),
     "hymeta_gla_prefill_segments": (C.c_int, [_i32, _i32, _i32]),

@@ -256,19 +256,64 @@ def reshape_and_cache(
 # ---------------------------------------------------------------------------
 _workspaces = {}
 _retired = []
+_TICKETED = ("gptq_gemm", "bf16_gemm", "w8a8_gemm")     # workspaces that start with split-K ticket counters
+
+
+class _Workspace:
+    __slots__ = ("buf", "eager_clean", "captures")
+
+    def __init__(self, buf, eager_clean):
+        self.buf, self.eager_clean, self.captures = buf, eager_clean, set()
+
+
+def _capture_id(stream) -> int:
+    cid = C.c_uint64(0)
+    _C.check(_C.load().hymeta_stream_capture_id(C.c_void_p(stream.cuda_stream), C.byref(cid)), "hymeta_stream_capture_id")
+    return int(cid.value)
 
 
 def _workspace(device: torch.device, nbytes: int, tag: str = "paged_decode") -> torch.Tensor:
-    """Grow-only per-device, per-op scratch (split-KV partials, prefill segment states, split-K slabs);
-    reuse is ordered by the stream the ops run on.  Born zero-filled: the split-K GEMMs keep their
-    ticket counters at the front of theirs and leave them zero after every call."""
-    ws = _workspaces.get((device, tag))
-    if ws is None or ws.numel() < nbytes:
+    """Grow-only scratch per (device, stream, op): split-KV partials, prefill segment states, split-K
+    slabs.  Calls on one stream are ordered, so they share; calls of one op on two streams (a shared
+    expert beside the routed ones) each get their own, ticket counters included.
+
+    The split-K GEMMs keep ticket counters at the front of theirs, which must be zero when a call starts
+    and which every completed call leaves zero.  Eagerly that is one zero fill when the buffer is made.
+    Under graph capture a fill recorded once would only run when that graph is replayed, so every
+    capture (told apart by its capture id) records its own clearing kernel in front of its first use of a
+    ticketed workspace: each replay then starts from zero tickets whatever ran before it, and a buffer
+    made during a capture is cleared eagerly before its first eager use."""
+    stream = torch.cuda.current_stream(device)
+    key = (device, stream.cuda_stream, tag)
+    cid = _capture_id(stream) if torch.cuda.is_current_stream_capturing() else 0
+    ticketed = tag in _TICKETED
+    ws = _workspaces.get(key)
+    if ws is None or ws.buf.numel() < nbytes:
         if ws is not None:
-            _retired.append(ws)     # a captured HIP graph may still hold its address: never hand it back
-        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _workspaces[(device, tag)] = ws
-    return ws
+            _retired.append(ws.buf)     # a captured HIP graph may still hold its address: never hand it back
+        size = max(nbytes, 1 << 20)
+        if cid == 0:
+            ws = _Workspace(torch.zeros(size, dtype=torch.uint8, device=device) if ticketed
+                            else torch.empty(size, dtype=torch.uint8, device=device), True)
+        else:
+            ws = _Workspace(torch.empty(size, dtype=torch.uint8, device=device), False)
+        _workspaces[key] = ws
+    if ticketed:
+        if cid != 0 and cid not in ws.captures:
+            ws.buf[: _C.GEMM_TICKET_BYTES].zero_()      # a fill kernel node of this graph (no memset node)
+            ws.captures.add(cid)
+        elif cid == 0 and not ws.eager_clean:
+            ws.buf[: _C.GEMM_TICKET_BYTES].zero_()
+            ws.eager_clean = True
+    return ws.buf
+
+
+def reset_workspace_tickets(device: Optional[torch.device] = None) -> None:
+    """Zero the ticket counters of every split-K workspace (of ``device``): the recovery step after a launch
+    that failed or was aborted midway, which may leave tickets drawn."""
+    for (dev, _, tag), ws in _workspaces.items():
+        if tag in _TICKETED and (device is None or dev == torch.device(device)):
+            ws.buf[: _C.GEMM_TICKET_BYTES].zero_()
 
 
 def paged_decode_splits(batch: int, num_kv_heads: int, max_seqlen_k: int, window_left: int,
@@ -297,6 +342,7 @@ def meta_swa_paged_decode(
 ) -> torch.Tensor:
     """q [B,H,D]; caches [nblk,bs,Hkv,D]; cache_seqlens int32 [B]; block_tables int32 [B,maxblk];
     meta_key/meta_value [M,Hkv,D] or None.  Returns out [B,H,D] bf16.
+
     With ``new_key`` / ``new_value`` [B,Hkv,D] and ``slot_mapping`` int64 [B] the call first writes the
     decoded tokens' K/V rows into the cache (the fused form of ``reshape_and_cache`` + decode)."""
     _dev(q, key_cache, value_cache, cache_seqlens, block_tables, meta_key, meta_value, out, workspace,
@@ -681,6 +727,7 @@ def bf16_gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor
         _require(bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N, "bias must be bf16 [N]")
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _require(out.shape == (M, N) and out.dtype == torch.bfloat16 and out.stride(1) == 1, "out must be bf16 [M, N]")
     a = _C.Bf16GemmArgs()
     a.x, a.weight, a.bias, a.out = _p(x), _p(weight), _p(bias), _p(out)
     a.M, a.K, a.N = M, K, N
@@ -710,6 +757,7 @@ def w8a8_gemm(x: torch.Tensor, qweight: torch.Tensor, w_scale: torch.Tensor,
         _require(bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N, "bias must be bf16 [N]")
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _require(out.shape == (M, N) and out.dtype == torch.bfloat16 and out.stride(1) == 1, "out must be bf16 [M, N]")
     xq = torch.empty(M, K, dtype=torch.int8, device=x.device)
     xs = torch.empty(M, dtype=torch.float32, device=x.device)
     a = _C.W8A8GemmArgs()

@@ -264,12 +264,17 @@ def make_linear(t: Dict[str, torch.Tensor], bits: int = 4, group_size: int = 128
     def mv(x):
         return None if x is None else x.contiguous().to(device) if device is not None else x.contiguous()
 
+    def bf16(x):
+        # gptqmodel / llmcompressor checkpoints store biases (and the layers they leave un-quantised) in the
+        # checkpoint's float type, often fp16; the kernels take bf16 activations, weights and biases
+        return None if x is None else x.to(torch.bfloat16) if x.is_floating_point() else x
+
     kind = linear_kind(t)
-    bias = mv(t.get("bias"))
+    bias = mv(bf16(t.get("bias")))
     if kind == "gptq":
         check_g_idx(t.get("g_idx"), group_size)
         return HymetaLinear.from_gptq(mv(t["qweight"]), mv(t["qzeros"]), mv(t["scales"]), bits, group_size, bias=bias,
                                       zero_offset=zero_offset)
     if kind == "w8a8":
         return HymetaLinear.from_w8a8(mv(t["weight"]), mv(t["weight_scale"].reshape(-1).float()), bias=bias)
-    return HymetaLinear.from_weight(mv(t["weight"]), bias)
+    return HymetaLinear.from_weight(mv(bf16(t["weight"])), bias)

@@ -161,7 +161,7 @@ class IntraHybridAttention(torch.nn.Module):
 
     def combine(self, out_attn: torch.Tensor, out_linear: torch.Tensor) -> torch.Tensor:
         stats = None
-        if self.tp_group is not None or self.linear_attn.shard.tp_size > 1:
+        if self.linear_attn.shard.tp_size > 1:      # the statistics span the full hidden size: every rank's share
             stats = all_reduce_variance(hip_ops.rms_sumsq2(out_attn, out_linear), self.tp_group)
         return hip_ops.hybrid_combine(out_attn, out_linear, self.norm1_weight, self.norm2_weight,
                                       self.norm_eps, stats=stats)

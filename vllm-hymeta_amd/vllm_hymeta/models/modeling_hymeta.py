@@ -85,7 +85,9 @@ class HymetaModel(torch.nn.Module):
         self.hymeta_cache = HymetaCacheManager(torch.bfloat16, self.cache_shape, self.meta_linear_cache_shape,
                                                self.meta_fattn_cache_shape, device=self.device)
         max_pos = min(config.max_position_embeddings, getattr(config, "max_model_len", config.max_position_embeddings))
-        self.register_buffer("cos_sin_cache", rope_cos_sin_cache(D, max_pos, int(config.rope_theta), device=self.device),
+        # real token p is roped at p + num_meta_tokens (reference :1314-1323): the table holds those rows too
+        self.register_buffer("cos_sin_cache", rope_cos_sin_cache(D, max_pos + self.num_meta_tokens, int(config.rope_theta),
+                                                                 device=self.device),
                              persistent=False)
         self.embeddings: Optional[torch.Tensor] = None
         self.layers = torch.nn.ModuleList()

@@ -44,10 +44,17 @@ def shard_heads(total_heads: int, total_kv_heads: int, tp_size: int, tp_rank: in
     return HeadShard(tp_size, tp_rank, h_local, kv_local, tp_rank * h_local, kv_start)
 
 
+def _active(group: Optional[dist.ProcessGroup]) -> bool:
+    """``group is None`` means "no tensor parallelism" and is a strict no-op, whatever process group
+    the program holds for other purposes (replicas, data or pipeline parallelism): a collective only
+    runs over a group that was passed explicitly (``dist.group.WORLD`` for the whole job)."""
+    return group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
 def all_reduce_sum(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """Sum over the tensor-parallel group, in place (the reduction behind ``RowParallelLinear``:
     ``out_proj`` / ``o_proj`` / ``down_proj``).  No-op for a single rank or without a group."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
     return x
 
@@ -56,13 +63,14 @@ def all_reduce_variance(stats: torch.Tensor, group: Optional[dist.ProcessGroup] 
     """``stats [T, 2]`` = per-rank mean of squares of the two branches over the local columns;
     returns the mean over the full hidden size (sum over ranks / tp), one message for both norms
     where the reference sends two ``[T, 1]`` ones (``modeling_hymeta.py:158-160``)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
         stats /= dist.get_world_size(group)
     return stats
 
 
 def tp_rank_and_size(group: Optional[dist.ProcessGroup] = None) -> Tuple[int, int]:
-    if dist.is_available() and dist.is_initialized():
+    """Rank and size of the tensor-parallel group; ``(0, 1)`` without one (see ``_active``)."""
+    if group is not None and dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
