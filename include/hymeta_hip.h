@@ -41,7 +41,8 @@ enum hymeta_status {
   HYMETA_ERR_INVALID_ARG = -1,  /* null pointer, negative size, bad stride */
   HYMETA_ERR_UNSUPPORTED = -2,  /* shape / dtype / mode the kernels do not cover */
   HYMETA_ERR_WORKSPACE = -3,    /* workspace missing or too small */
-  HYMETA_ERR_LAUNCH = -4        /* hipGetLastError() != hipSuccess after launch */
+  HYMETA_ERR_LAUNCH = -4,       /* hipGetLastError() != hipSuccess after launch */
+  HYMETA_ERR_SCRATCH_LIMIT = -5 /* an allocation-free entry point was asked for more than its fixed scratch holds */
 };
 
 enum hymeta_dtype { HYMETA_BF16 = 0, HYMETA_F32 = 1, HYMETA_F16 = 2 };
@@ -307,6 +308,23 @@ int hymeta_meta_swa_paged_decode_splits(int32_t batch, int32_t num_kv_heads,
                                         int32_t max_seqlen_k, int32_t window_left,
                                         int32_t num_meta);
 int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args, hymeta_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * The same paged decode for callers that cannot allocate or carry a workspace: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
+ * args->workspace / workspace_bytes are ignored; the split-KV partials live in a file-scope device
+ * array of HYMETA_STATIC_SCRATCH_BYTES inside the library (one copy per GPU the library runs on, held
+ * until the process ends).  A call whose partials need more -- batch * num_heads * num_splits *
+ * (head_dim + 2) * 4 bytes with more than one split -- returns HYMETA_ERR_SCRATCH_LIMIT and launches
+ * nothing; unsplit calls need no scratch and always fit.  Everything else (arguments, kernels, split
+ * choice, results bit for bit) is hymeta_meta_swa_paged_decode.  The entry point calls no hipMalloc /
+ * hipFree or other allocating routine; its first call on a device looks the array's address up
+ * (hipGetSymbolAddress), so make that one call outside stream capture.  All calls on one GPU share
+ * the array: calls that overlap on one GPU (two streams) race; order them on one stream.  Nothing in
+ * the array has to start at zero and nothing is carried from call to call.
+ * ---------------------------------------------------------------------- */
+#define HYMETA_STATIC_SCRATCH_BYTES (16u << 20)
+int hymeta_meta_swa_paged_decode_static(const hymeta_paged_decode_args* args, hymeta_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Varlen prefill attention: causal sliding window over the real keys plus

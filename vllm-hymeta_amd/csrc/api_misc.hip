@@ -10,6 +10,7 @@ extern "C" const char* hymeta_strerror(int code) {
     case HYMETA_ERR_UNSUPPORTED: return "unsupported shape, dtype, stride or mode";
     case HYMETA_ERR_WORKSPACE: return "workspace missing or too small";
     case HYMETA_ERR_LAUNCH: return "kernel launch failed";
+    case HYMETA_ERR_SCRATCH_LIMIT: return "problem needs more scratch than the allocation-free entry point holds (HYMETA_STATIC_SCRATCH_BYTES)";
     default: return "unknown hymeta status";
   }
 }

@@ -29,6 +29,7 @@
 // 23.9 against 19.9 us at 8 sequences, 30.8 against 27.9 us at 16).
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 
@@ -450,11 +451,49 @@ int forced_shape() {
   return shape;
 }
 
+// Split-KV partials of hymeta_meta_swa_paged_decode_static: one array per GPU the library runs on, held until
+// the process ends.  Nothing in it has to start at zero (every partial the merge kernel reads was written by the
+// split kernel of the same call).  In host code the name `scratch` is only a handle for hipGetSymbolAddress:
+// the device address is looked up once per device and kept in scratch_ptr[].
+static __device__ __align__(256) unsigned char scratch[HYMETA_STATIC_SCRATCH_BYTES];
+constexpr int kMaxDevices = 64;
+void* scratch_ptr[kMaxDevices] = {};
+std::mutex scratch_mutex;
+
+int static_scratch(void** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return HYMETA_ERR_LAUNCH;
+  if (dev < 0 || dev >= kMaxDevices) return HYMETA_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(scratch_mutex);
+  if (scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || p == nullptr) {
+      (void)hipGetLastError();
+      return HYMETA_ERR_LAUNCH;
+    }
+    scratch_ptr[dev] = p;
+  }
+  *out = scratch_ptr[dev];
+  return HYMETA_OK;
+}
+
+int paged_decode_impl(hymeta_paged_decode_args a, hymeta_stream_t stream, bool use_static_scratch);
+
 }  // namespace
 
 extern "C" int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args, hymeta_stream_t stream) {
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
-  hymeta_paged_decode_args a = *args;
+  return paged_decode_impl(*args, stream, false);
+}
+
+extern "C" int hymeta_meta_swa_paged_decode_static(const hymeta_paged_decode_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  return paged_decode_impl(*args, stream, true);
+}
+
+namespace {
+
+int paged_decode_impl(hymeta_paged_decode_args a, hymeta_stream_t stream, bool use_static_scratch) {
   if (a.batch < 0 || a.num_heads <= 0 || a.num_kv_heads <= 0 || a.block_size <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.batch == 0) return HYMETA_OK;
   if (!a.q || !a.out || !a.key_cache || !a.value_cache || !a.block_tables || !a.cache_seqlens) return HYMETA_ERR_INVALID_ARG;
@@ -476,6 +515,17 @@ extern "C" int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args
   const int max_k = a.max_seqlen_k > 0 ? a.max_seqlen_k : a.max_blocks_per_seq * a.block_size;
   int splits = a.num_splits > 0 ? a.num_splits
                                 : hymeta_meta_swa_paged_decode_splits(a.batch, a.num_kv_heads, max_k, a.window_left, a.num_meta);
+  if (use_static_scratch) {
+    a.workspace = nullptr;
+    a.workspace_bytes = 0;
+    if (splits > 1) {
+      const size_t need = hymeta_meta_swa_paged_decode_workspace_bytes(a.batch, a.num_heads, a.head_dim, splits);
+      if (need > HYMETA_STATIC_SCRATCH_BYTES) return HYMETA_ERR_SCRATCH_LIMIT;
+      const int rc = static_scratch(&a.workspace);
+      if (rc != HYMETA_OK) return rc;
+      a.workspace_bytes = HYMETA_STATIC_SCRATCH_BYTES;
+    }
+  }
   if (splits > 1) {
     const size_t need = hymeta_meta_swa_paged_decode_workspace_bytes(a.batch, a.num_heads, a.head_dim, splits);
     if (a.workspace == nullptr || a.workspace_bytes < need) return HYMETA_ERR_WORKSPACE;
@@ -530,3 +580,5 @@ extern "C" int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args
   }
   return launch_status();
 }
+
+}  // namespace

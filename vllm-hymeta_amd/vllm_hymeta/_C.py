@@ -24,7 +24,9 @@ GATE_70B_CLAMP = 2
 GATE_70B_LOWER_BOUND = 3
 
 ABI_VERSION = 1
+ERR_SCRATCH_LIMIT = -5
 GEMM_TICKET_BYTES = 16384
+STATIC_SCRATCH_BYTES = 16 << 20
 
 _i32, _i64, _f32, _ptr, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -227,6 +229,7 @@ _SIGNATURES = {
     "hymeta_meta_swa_paged_decode_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "hymeta_meta_swa_paged_decode_splits": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "hymeta_meta_swa_paged_decode": (C.c_int, [C.POINTER(PagedDecodeArgs), _ptr]),
+    "hymeta_meta_swa_paged_decode_static": (C.c_int, [C.POINTER(PagedDecodeArgs), _ptr]),
     "hymeta_meta_swa_prefill": (C.c_int, [C.POINTER(SwaPrefillArgs), _ptr]),
     "hymeta_meta_swa_prefill_splits": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "hymeta_meta_swa_prefill_workspace_bytes": (_sz, [_i32, _i32, _i32]),

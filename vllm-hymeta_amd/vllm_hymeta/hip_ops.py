@@ -339,10 +339,12 @@ def meta_swa_paged_decode(
     new_key: Optional[torch.Tensor] = None,
     new_value: Optional[torch.Tensor] = None,
     slot_mapping: Optional[torch.Tensor] = None,
+    static_scratch: bool = False,
 ) -> torch.Tensor:
     """q [B,H,D]; caches [nblk,bs,Hkv,D]; cache_seqlens int32 [B]; block_tables int32 [B,maxblk];
     meta_key/meta_value [M,Hkv,D] or None.  Returns out [B,H,D] bf16.
-
+    ``static_scratch``: run ``hymeta_meta_swa_paged_decode_static`` (split-KV partials in the library's
+    own fixed device array; no workspace is allocated or passed; pass ``out`` to allocate nothing at all).
     With ``new_key`` / ``new_value`` [B,Hkv,D] and ``slot_mapping`` int64 [B] the call first writes the
     decoded tokens' K/V rows into the cache (the fused form of ``reshape_and_cache`` + decode)."""
     _dev(q, key_cache, value_cache, cache_seqlens, block_tables, meta_key, meta_value, out, workspace,
@@ -377,7 +379,7 @@ def meta_swa_paged_decode(
     lib = _C.load()
     if num_splits <= 0:
         num_splits = lib.hymeta_meta_swa_paged_decode_splits(B, Hkv, max_seqlen_k, window_left, M)
-    need = lib.hymeta_meta_swa_paged_decode_workspace_bytes(B, H, D, num_splits)
+    need = 0 if static_scratch else lib.hymeta_meta_swa_paged_decode_workspace_bytes(B, H, D, num_splits)
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = _workspace(q.device, need)
     a = _C.PagedDecodeArgs()
@@ -409,7 +411,10 @@ def meta_swa_paged_decode(
     if meta_key is not None:
         a.meta_stride_t, a.meta_stride_h = meta_key.stride(0), meta_key.stride(1)
     a.scale = float(scale) if scale is not None else 0.0
-    _C.check(lib.hymeta_meta_swa_paged_decode(C.byref(a), _stream(q)), "hymeta_meta_swa_paged_decode")
+    if static_scratch:
+        _C.check(lib.hymeta_meta_swa_paged_decode_static(C.byref(a), _stream(q)), "hymeta_meta_swa_paged_decode_static")
+    else:
+        _C.check(lib.hymeta_meta_swa_paged_decode(C.byref(a), _stream(q)), "hymeta_meta_swa_paged_decode")
     return out
 
 
