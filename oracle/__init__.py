@@ -5,11 +5,18 @@ This package is the parity checker for the HIP kernels.  Only ``tests/``,
 import it; nothing under the product package does, and the product path raises
 if its HIP library is missing rather than falling back to anything here.
 
-Parity status: UNPINNED.  The reference ships no golden vectors, known-answer
-tests or fixtures for this path, and its eager modules cannot be imported in the
-build container (``fla``, ``flash_attn`` and ``vllm`` are absent: an ordinary
-``ModuleNotFoundError``).  Every function below therefore restates the reference
-math from its source text and cites the file:line it follows; the vectors under
+Parity status: PINNED only where the reference's own code could run in the build
+container, UNPINNED for the rest.  The reference ships no golden vectors, known-answer
+tests or fixtures for this path, and its eager layers cannot be imported there
+(``fla``, ``flash_attn`` and ``vllm`` are absent: an ordinary ``ModuleNotFoundError``;
+their kernels are GPU-only).  What does load by file path -- ``hf_7B_model/norms.py``
+(RMSNorm), the module-level RoPE / ``repeat_kv`` functions of
+``hf_7B_model/window_attention.py``, both ``cache.py`` files and the config classes --
+was run on seeded inputs (``tests/golden/make_ref_fixtures.py``,
+``make_config_fixture.py``) and ``tests/test_ref_fixtures.py`` checks ``rms_norm_ref`` /
+``rms_norm_tp_ref``, ``rope_neox_ref``, the GQA head mapping and ``oracle/cache.py``
+against those outputs.  Every other function restates the reference math from its
+source text and cites the file:line it follows; the other vectors under
 ``tests/golden`` are outputs of this restatement, not of the reference.
 """
 

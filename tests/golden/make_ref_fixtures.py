@@ -1,0 +1,139 @@
+"""Outputs of the reference's own importable eager code on seeded inputs -> tests/golden/ref_*.npz.
+
+Runs in the build container only (needs /root/reference; nothing from it travels: the fixtures hold inputs
+and outputs, no source).  What loads by file path without the GPU-only third-party wheels:
+
+* hf_7B_model/norms.py          RMSNorm                                   -> ref_rmsnorm.npz
+* hf_7B_model/window_attention.py  RotaryEmbedding, apply_rotary_pos_emb, repeat_kv (module level; the layer's
+                                forward needs flash_attn and is not called)  -> ref_rope.npz
+* hf_7B_model/cache.py, hf_model/cache.py   Cache.update (rolling window, recurrent / meta state slots)
+                                                                           -> ref_cache.npz
+
+bf16 tensors are stored as their uint16 bit patterns (key suffix ``_bf16``)."""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def load(pkg: str, name: str):
+    """Import REF/pkg/name.py as ``pkg.name`` without running the package's __init__ (which imports fla)."""
+    if pkg not in sys.modules:
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, pkg)]
+        sys.modules[pkg] = m
+    full = f"{pkg}.{name}"
+    if full in sys.modules:
+        return sys.modules[full]
+    spec = importlib.util.spec_from_file_location(full, os.path.join(REF, pkg, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[full] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def put(out, key, t):
+    if t.dtype == torch.bfloat16:
+        out[key + "_bf16"] = t.contiguous().view(torch.int16).numpy().view(np.uint16)
+    else:
+        out[key] = t.contiguous().numpy()
+
+
+def rmsnorm():
+    RMSNorm = load("hf_7B_model", "norms").RMSNorm
+    g = torch.Generator().manual_seed(100)
+    out = {}
+    for tag, rows, hidden in (("head", 12, 128), ("hidden", 3, 3584)):
+        x = (torch.randn(rows, hidden, generator=g) * 1.7).to(torch.bfloat16)
+        w = 1 + 0.2 * torch.randn(hidden, generator=g)
+        m = RMSNorm(hidden, eps=1e-6)
+        with torch.no_grad():
+            m.weight.copy_(w)
+            y_w32 = m(x)                       # fp32 weight: bf16 normalised value promoted to fp32
+            y_f32 = m(x.float())               # fp32 activations
+            mb = RMSNorm(hidden, eps=1e-6).to(torch.bfloat16)
+            mb.weight.copy_(w.to(torch.bfloat16))
+            y_bf = mb(x)                       # module cast to bf16, as a bf16 checkpoint runs it
+        put(out, f"{tag}_x", x)
+        put(out, f"{tag}_w", w)
+        put(out, f"{tag}_y_w32", y_w32)
+        put(out, f"{tag}_y_f32", y_f32)
+        put(out, f"{tag}_y", y_bf)
+    np.savez_compressed(os.path.join(HERE, "ref_rmsnorm.npz"), eps=np.float32(1e-6), **out)
+    return {k: v.shape for k, v in out.items()}
+
+
+def rope():
+    wa = load("hf_7B_model", "window_attention")
+    g = torch.Generator().manual_seed(101)
+    H, Hkv, D, theta = 4, 2, 128, 1e6
+    pos = torch.tensor([[0, 1, 2, 127, 128, 4095, 4096, 32767, 32895, 131071]])
+    T = pos.shape[1]
+    rot = wa.RotaryEmbedding(D, max_position_embeddings=131072, base=theta)
+    out = {"positions": pos[0].numpy(), "theta": np.float64(theta)}
+    for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        q = torch.randn(1, H, T, D, generator=g).to(dt)
+        k = torch.randn(1, Hkv, T, D, generator=g).to(dt)
+        cos, sin = rot(k, pos)
+        qe, ke = wa.apply_rotary_pos_emb(q, k, cos, sin)
+        for name, t in (("q", q), ("k", k), ("cos", cos), ("sin", sin), ("q_out", qe), ("k_out", ke)):
+            put(out, f"{tag}_{name}", t)
+    x = torch.arange(2 * 3 * 5 * 4, dtype=torch.float32).view(2, 3, 5, 4)
+    out["repeat_kv_in"] = x.numpy()
+    out["repeat_kv_out"] = wa.repeat_kv(x, 7).numpy()
+    np.savez_compressed(os.path.join(HERE, "ref_rope.npz"), **out)
+    return {k: getattr(v, "shape", ()) for k, v in out.items()}
+
+
+def cache():
+    g = torch.Generator().manual_seed(102)
+    out = {}
+    Hkv, D, W = 2, 8, 6
+    chunks = [4, 1, 1, 1, 1, 3, 1, 2]       # prefill of 4 (< W), decode steps, a 3-token chunk, ...
+    out["window"] = np.int64(W)
+    out["chunks"] = np.array(chunks)
+    total = sum(chunks)
+    keys = torch.randn(1, Hkv, total, D, generator=g)
+    vals = torch.randn(1, Hkv, total, D, generator=g)
+    out["keys"], out["values"] = keys.numpy(), vals.numpy()
+    for tag, pkg in (("7b", "hf_7B_model"), ("70b", "hf_model")):
+        Cache = load(pkg, "cache").Cache
+        c = Cache()
+        t = 0
+        for i, n in enumerate(chunks):
+            kw = dict(attn_state=(keys[:, :, t:t + n].clone(), vals[:, :, t:t + n].clone()), layer_idx=0, offset=n,
+                      cache_kwargs={"window_size": W})
+            if tag == "70b" and i == 0:
+                kw["meta_state"] = (torch.full((1, Hkv, 3, D), 7.0), torch.full((1, Hkv, 3, D), -7.0))
+            st = c.update(**kw)
+            t += n
+            out[f"{tag}_k_after_{i}"] = st["attn_state"][0].numpy().copy()
+            out[f"{tag}_v_after_{i}"] = st["attn_state"][1].numpy().copy()
+            out[f"{tag}_seen_after_{i}"] = np.int64(c.get_seq_length(0))
+        if tag == "70b":
+            out["70b_meta_k_kept"] = c[0]["meta_state"][0].numpy()
+        # a first chunk longer than the window is cut to its last W tokens
+        c2 = Cache()
+        st = c2.update(attn_state=(keys[:, :, :10].clone(), vals[:, :, :10].clone()), layer_idx=0, offset=10,
+                       cache_kwargs={"window_size": W})
+        out[f"{tag}_k_long_first"] = st["attn_state"][0].numpy().copy()
+        # the recurrent-state slot: replaced, not accumulated
+        c3 = Cache()
+        c3.update(recurrent_state=torch.ones(1, 2, 3), layer_idx=0, offset=5)
+        st = c3.update(recurrent_state=torch.full((1, 2, 3), 2.0), layer_idx=0, offset=1)
+        out[f"{tag}_recurrent_after_2"] = st["recurrent_state"].numpy()
+        out[f"{tag}_recurrent_seen"] = np.int64(c3.get_seq_length(0))
+    np.savez_compressed(os.path.join(HERE, "ref_cache.npz"), **out)
+    return len(out)
+
+
+if __name__ == "__main__":
+    print("rmsnorm", rmsnorm())
+    print("rope", rope())
+    print("cache", cache())

@@ -1,0 +1,103 @@
+"""The oracle against outputs of the reference's OWN code (tests/golden/ref_*.npz, made by
+tests/golden/make_ref_fixtures.py in the build container from the reference files that import without the
+GPU-only wheels): RMSNorm, RoPE, repeat_kv and the eager rolling-window cache."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    out = {}
+    for k in z.files:
+        if k.endswith("_bf16"):
+            out[k[:-5]] = torch.from_numpy(z[k].view(np.int16).copy()).view(torch.bfloat16)
+        else:
+            out[k] = torch.from_numpy(np.asarray(z[k]).copy()) if z[k].shape else z[k].item()
+    return out
+
+
+@pytest.mark.parametrize("tag", ["head", "hidden"])
+def test_rms_norm_ref_equals_reference_rmsnorm(tag):
+    """hf_7B_model/norms.py:13-18 -- bit for bit in all three dtype mixes."""
+    from oracle.layers import rms_norm_ref, rms_norm_tp_ref
+
+    f = load("ref_rmsnorm.npz")
+    x, w, eps = f[f"{tag}_x"], f[f"{tag}_w"], float(f["eps"])
+    assert torch.equal(rms_norm_ref(x, w.to(torch.bfloat16), eps), f[f"{tag}_y"])             # bf16 module
+    assert torch.equal(rms_norm_tp_ref(x, w, eps), f[f"{tag}_y_w32"])                            # fp32 weight on bf16 x
+    assert torch.equal(rms_norm_ref(x.float(), w, eps), f[f"{tag}_y_f32"])                       # fp32 activations
+
+
+def test_rope_neox_ref_equals_reference_rotary():
+    """hf_7B_model/window_attention.py:23-79: fp32 activations against an fp32 table, bf16 activations against
+    the table rounded to bf16 (what the eager model does with bf16 weights, and what vLLM's table holds)."""
+    from oracle.layers import rope_cos_sin_cache_ref, rope_neox_ref
+
+    f = load("ref_rope.npz")
+    pos = f["positions"].long()
+    D = f["f32_q"].shape[-1]
+    for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        table = rope_cos_sin_cache_ref(D, 131072, float(f["theta"]), dtype=dt)
+        # the reference's cos/sin rows ([cos, cos] / [sin, sin] over the two halves) are this table's rows
+        assert torch.equal(table[pos][:, : D // 2], f[f"{tag}_cos"][0][:, : D // 2])
+        assert torch.equal(table[pos][:, D // 2:], f[f"{tag}_sin"][0][:, : D // 2])
+        q = f[f"{tag}_q"][0].transpose(0, 1)           # [T, H, D]
+        k = f[f"{tag}_k"][0].transpose(0, 1)
+        qo, ko = rope_neox_ref(pos, q, k, table)
+        assert torch.equal(qo, f[f"{tag}_q_out"][0].transpose(0, 1)), tag
+        assert torch.equal(ko, f[f"{tag}_k_out"][0].transpose(0, 1)), tag
+
+
+def test_gqa_head_mapping_equals_reference_repeat_kv():
+    """repeat_kv (hf_7B_model/window_attention.py:82-91): q-head h reads kv-head h // n_rep -- the mapping the
+    kernels apply instead of materialising the copies."""
+    f = load("ref_rope.npz")
+    x, y = f["repeat_kv_in"], f["repeat_kv_out"]
+    n_rep = y.shape[1] // x.shape[1]
+    for h in range(y.shape[1]):
+        assert torch.equal(y[:, h], x[:, h // n_rep])
+
+
+@pytest.mark.parametrize("tag", ["7b", "70b"])
+def test_rolling_cache_restatement_equals_reference_cache(tag):
+    from oracle.cache import RollingCacheRef, window_positions_ref
+
+    f = load("ref_cache.npz")
+    W, chunks = int(f["window"]), [int(c) for c in f["chunks"]]
+    keys, vals = f["keys"], f["values"]
+    c, t = RollingCacheRef(), 0
+    held = window_positions_ref(chunks, W)
+    for i, n in enumerate(chunks):
+        meta = (torch.full((1, 2, 3, 8), 7.0), torch.full((1, 2, 3, 8), -7.0)) if (tag == "70b" and i == 0) else None
+        st = c.update(0, n, attn_state=(keys[:, :, t:t + n].clone(), vals[:, :, t:t + n].clone()), meta_state=meta, window_size=W)
+        t += n
+        assert torch.equal(st["attn_state"][0], f[f"{tag}_k_after_{i}"]) and torch.equal(st["attn_state"][1], f[f"{tag}_v_after_{i}"])
+        assert c.seen_tokens == int(f[f"{tag}_seen_after_{i}"]) == t
+        # the window holds these positions, in order: the paged cache reads the same rows through its block table
+        assert torch.equal(st["attn_state"][0], keys[:, :, held[i]])
+    if tag == "70b":
+        assert torch.equal(c.states[0]["meta_state"][0], f["70b_meta_k_kept"])
+    c2 = RollingCacheRef()
+    st = c2.update(0, 10, attn_state=(keys[:, :, :10].clone(), vals[:, :, :10].clone()), window_size=W)
+    assert torch.equal(st["attn_state"][0], f[f"{tag}_k_long_first"])
+    c3 = RollingCacheRef()
+    c3.update(0, 5, recurrent_state=torch.ones(1, 2, 3))
+    st = c3.update(0, 1, recurrent_state=torch.full((1, 2, 3), 2.0))
+    assert torch.equal(st["recurrent_state"], f[f"{tag}_recurrent_after_2"]) and c3.seen_tokens == int(f[f"{tag}_recurrent_seen"])
+
+
+def test_rolling_window_is_the_paged_window():
+    """Once full, the eager window holds the last W positions [L-W, L) in order; the paged decode of the 70B
+    path reads exactly those through the block table (window_left = W - 1 keys before the query + the query)."""
+    from oracle.cache import window_positions_ref
+
+    W = 6
+    held = window_positions_ref([W] + [1] * 9, W)
+    for step, h in enumerate(held):
+        L = W + step
+        assert h == list(range(L - W, L))
