@@ -48,8 +48,13 @@ def _checkpoint(g_, cfg):
     return w
 
 
-def test_hymeta_for_causal_lm_prefill_then_decode():
+@pytest.mark.parametrize("engine_style", [False, True])
+def test_hymeta_for_causal_lm_prefill_then_decode(engine_style):
+    """``engine_style``: the model is built from a (duck-typed) ``VllmConfig``, its paged KV caches are bound to the
+    registered attention layers by name and the step's metadata comes from the forward context -- the way vLLM
+    constructs and drives the class -- instead of being passed to ``forward``."""
     from oracle.model import hymeta_model_ref
+    from vllm_hymeta.models import attention
     from vllm_hymeta.models.configuration_hymeta import HymetaConfig
     from vllm_hymeta.models.modeling_hymeta import HymetaForCausalLM
 
@@ -60,7 +65,12 @@ def test_hymeta_for_causal_lm_prefill_then_decode():
                        sliding_window=48, max_position_embeddings=1024)
     assert cfg.num_layer_experts == [1, 1, 1, 4] and cfg.interleaved_sliding_window == [48, 48, 48, 0]
     ckpt = _checkpoint(g_, cfg)
-    model = HymetaForCausalLM(cfg, max_num_seqs=4, device=dev)
+    if engine_style:
+        from test_vllm_boundary import vllm_config_like
+        attention.release_layers("model.")
+        model = HymetaForCausalLM(vllm_config=vllm_config_like(cfg, max_num_seqs=4, device=dev), prefix="")
+    else:
+        model = HymetaForCausalLM(cfg, max_num_seqs=4, device=dev)
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, dtype=torch.long, device=dev), torch.zeros(1, dtype=torch.long, device=dev), attn_metadata=object())
     loaded = model.load_weights(ckpt.items())
@@ -84,13 +94,24 @@ def test_hymeta_for_causal_lm_prefill_then_decode():
     pre_pos = torch.cat([torch.arange(L) for L in lens]).to(dev)
     pre_slots = torch.tensor([slot(s, t) for s, L in enumerate(lens) for t in range(L)], device=dev)
     md = _md(dev, prefill_lens=lens, context_lens=[0, 0], slot_mapping=pre_slots)
-    h_pre = model(pre_ids, pre_pos, attn_metadata=md, kv_caches=kv_caches, **run)
+    if engine_style:
+        layers = attention.registered_layers()
+        for i, kv in enumerate(kv_caches):
+            attention.bind_kv_cache(layers[f"model.layers.{i}.attn.vanilla_attn.attn"], kv)
+
+        def step(ids_, pos_, md_):
+            with attention.forward_context(md_):
+                return model(ids_, pos_, **run)
+    else:
+        def step(ids_, pos_, md_):
+            return model(ids_, pos_, attn_metadata=md_, kv_caches=kv_caches, **run)
+    h_pre = step(pre_ids, pre_pos, md)
 
     dec_ids = torch.stack([x[L] for x, L in zip(ids, lens)]).to(dev)
     dec_pos = torch.tensor(lens, device=dev)
     dec_slots = torch.tensor([slot(s, L) for s, L in enumerate(lens)], device=dev)
     md = _md(dev, decode_seq_lens=[L + 1 for L in lens], block_tables=bt, slot_mapping=dec_slots)
-    h_dec = model(dec_ids, dec_pos, attn_metadata=md, kv_caches=kv_caches, **run)
+    h_dec = step(dec_ids, dec_pos, md)
     logits = model.compute_logits(h_dec)
     torch.cuda.synchronize()
 
@@ -101,3 +122,5 @@ def test_hymeta_for_causal_lm_prefill_then_decode():
     assert_bf16_close(h_pre.cpu(), ref_pre, "70B model, prefill hidden states", rel=2e-2, frac=2.0 ** -4)
     assert_bf16_close(h_dec.cpu(), ref_dec, "70B model, decode hidden states", rel=2e-2, frac=2.0 ** -4)
     assert_bf16_close(logits.cpu(), ref_logits, "70B model, decode logits", rel=2e-2, frac=2.0 ** -4)
+    if engine_style:
+        attention.release_layers("model.")

@@ -37,9 +37,12 @@ def _checkpoint(g_, cfg):
     return w
 
 
-@pytest.mark.parametrize("state_per_kv_head", [True, False])
-def test_glaswa_for_causal_lm_prefill_then_decode(state_per_kv_head):
+@pytest.mark.parametrize("state_per_kv_head,engine_style", [(True, False), (False, False), (True, True)])
+def test_glaswa_for_causal_lm_prefill_then_decode(state_per_kv_head, engine_style):
+    """``engine_style``: built from a (duck-typed) ``VllmConfig``, paged KV caches bound to the registered
+    sliding-window attention layers by name, step metadata from the forward context (how vLLM drives the class)."""
     from oracle.model import glaswa_model_ref
+    from vllm_hymeta.models import attention
     from vllm_hymeta.model_for_7B.configuration_gla_swa import GLAswaConfig
     from vllm_hymeta.model_for_7B.modeling_gla_swa import GLAswaForCausalLM
 
@@ -48,7 +51,12 @@ def test_glaswa_for_causal_lm_prefill_then_decode(state_per_kv_head):
     cfg = GLAswaConfig(vocab_size=512, hidden_size=512, num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=2,
                        intermediate_size=1024, sliding_window=48, max_position_embeddings=1024)
     ckpt = _checkpoint(g_, cfg)
-    model = GLAswaForCausalLM(cfg, max_num_seqs=4, device=dev, state_per_kv_head=state_per_kv_head)
+    if engine_style:
+        from test_vllm_boundary import vllm_config_like
+        attention.release_layers("model.")
+        model = GLAswaForCausalLM(vllm_config=vllm_config_like(cfg, max_num_seqs=4, device=dev), prefix="")
+    else:
+        model = GLAswaForCausalLM(cfg, max_num_seqs=4, device=dev, state_per_kv_head=state_per_kv_head)
     loaded = model.load_weights(ckpt.items())
     assert "model.layers.0.attn.qkv_proj.weight" in loaded and "model.layers.1.mlp.gate_up_proj.weight" in loaded
     assert not any(".layers.4." in n for n in loaded)
@@ -72,13 +80,24 @@ def test_glaswa_for_causal_lm_prefill_then_decode(state_per_kv_head):
     pre_pos = torch.cat([torch.arange(L) for L in lens]).to(dev)
     pre_slots = torch.tensor([slot(s, t) for s, L in enumerate(lens) for t in range(L)], device=dev)
     md = _md(dev, prefill_lens=lens, context_lens=[0, 0], slot_mapping=pre_slots)
-    h_pre = model(pre_ids, pre_pos, attn_metadata=md, kv_caches=kv_caches, **run)
+    if engine_style:
+        layers = attention.registered_layers()
+        for i, kv in zip(cfg.attn_layers, kv_caches):
+            attention.bind_kv_cache(layers[f"model.layers.{i}.attn.attn"], kv)
+
+        def step(ids_, pos_, md_):
+            with attention.forward_context(md_):
+                return model(ids_, pos_, **run)
+    else:
+        def step(ids_, pos_, md_):
+            return model(ids_, pos_, attn_metadata=md_, kv_caches=kv_caches, **run)
+    h_pre = step(pre_ids, pre_pos, md)
 
     dec_ids = torch.stack([x[L] for x, L in zip(ids, lens)]).to(dev)
     dec_pos = torch.tensor(lens, device=dev)
     dec_slots = torch.tensor([slot(s, L) for s, L in enumerate(lens)], device=dev)
     md = _md(dev, decode_seq_lens=[L + 1 for L in lens], block_tables=bt, slot_mapping=dec_slots)
-    h_dec = model(dec_ids, dec_pos, attn_metadata=md, kv_caches=kv_caches, **run)
+    h_dec = step(dec_ids, dec_pos, md)
     logits = model.compute_logits(h_dec)
     torch.cuda.synchronize()
 
@@ -96,6 +115,8 @@ def test_glaswa_for_causal_lm_prefill_then_decode(state_per_kv_head):
     assert model(None, dec_pos, attn_metadata=None) is None          # profiling run: no metadata, no work
     with pytest.raises(ValueError):
         model.model(None, dec_pos, attn_metadata=md)
+    if engine_style:
+        attention.release_layers("model.")
 
 
 def test_glaswa_for_causal_lm_gptq_checkpoint():

@@ -24,29 +24,27 @@ from typing import Dict, Iterable, List, Optional, Set, Tuple
 import torch
 
 from .. import loader
+from .._compat import HasInnerState, IntermediateTensors, IsHybrid, SupportsPP, SupportsV0Only, model_build_args
 from ..linear import HymetaLinear
+from ..models.attention import bind_kv_cache, current_attn_metadata, forward_context, standalone_prefix
 from ..models.block import GLAswaBlock, HymetaRMSNorm
 from ..models.moe import HymetaMLP
 from ..parallel import shard_heads, tp_rank_and_size
 from .gla_attention import GatedLinearAttention
 from .gla_cache import GLACacheManager, GLACacheParams
-from .window_attention import SlidingWindowAttention, rope_cos_sin_cache
+from .window_attention import SlidingWindowAttention, rope_cos_sin_cache, swa_attention_layer
 
 GLAswaGLU = HymetaMLP     # vllm_hymeta/model_for_7B/modeling_gla_swa.py:60-131
 
 
-def _forward_context_metadata():
-    try:   # pragma: no cover - only where vLLM is installed
-        from vllm.forward_context import get_forward_context
-        return get_forward_context().attn_metadata
-    except Exception:
-        return None
-
-
 class GLAswaModel(torch.nn.Module):
     def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda",
-                 state_per_kv_head: bool = True):
-        """``quant``: ``{"bits", "group_size", "zero_offset"}`` of a GPTQ checkpoint (ignored for bf16 /
+                 state_per_kv_head: bool = True, cache_config=None, prefix: Optional[str] = None):
+        """``prefix``: name of this module in the whole model (``"model"`` under vLLM); sliding-window layer ``i``
+        registers its attention layer as ``<prefix>.layers.<i>.attn.attn`` (reference ``:201,257,346``), the name
+        under which the engine binds that layer's paged KV cache.  ``None``: a private name.
+
+        ``quant``: ``{"bits", "group_size", "zero_offset"}`` of a GPTQ checkpoint (ignored for bf16 /
         W8A8 tensors, which identify themselves by dtype).
 
         ``state_per_kv_head``: keep one GLA state per key/value head instead of one per query head.  The
@@ -56,12 +54,19 @@ class GLAswaModel(torch.nn.Module):
         the cache size by that factor with bit-identical outputs; ``False`` restores the reference's shape."""
         super().__init__()
         self.config = config
+        self.prefix = standalone_prefix("model") if prefix is None else prefix
         self.device = torch.device(device)
         self.tp_group = tp_group
         self.tp_rank, self.tp_size = tp_rank_and_size(tp_group)
         self.quant = dict(bits=4, group_size=128, zero_offset=1)
         self.quant.update(quant or {})
         self.shard = shard_heads(config.num_attention_heads, config.num_key_value_heads, self.tp_size, self.tp_rank)
+        # the sliding-window layers' attention objects exist from construction on: the engine looks them up by
+        # name when it allocates the KV cache; load_weights builds the rest of each layer around them
+        self.attn_layers = torch.nn.ModuleDict({
+            str(i): swa_attention_layer(self.shard, config.head_dim, config.sliding_window,
+                                        f"{self.prefix}.layers.{i}.attn.attn", cache_config=cache_config)
+            for i in config.attn_layers if i < config.num_hidden_layers})
         self.gla_layers = [i for i in range(config.num_hidden_layers) if i not in config.attn_layers]
         state_heads = self.shard.num_kv_heads if state_per_kv_head else self.shard.num_heads
         self.cache_shape = (len(self.gla_layers), max_num_seqs, state_heads, config.head_dim, config.head_dim)
@@ -79,10 +84,22 @@ class GLAswaModel(torch.nn.Module):
     def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor, intermediate_tensors=None,
                 inputs_embeds: Optional[torch.Tensor] = None, attn_metadata=None,
                 kv_caches: Optional[List[torch.Tensor]] = None, **kwargs) -> Optional[torch.Tensor]:
-        if attn_metadata is None:
-            attn_metadata = _forward_context_metadata()
+        """Under an engine the step's metadata comes from the forward context and every sliding-window layer's
+        paged KV cache is the one the engine bound to its attention layer.  Callers without an engine pass
+        ``attn_metadata`` and, once, ``kv_caches`` (one ``[2, nblk, bs, Hkv, D]`` tensor per sliding-window layer, in
+        layer order): they are set / bound here and the same path runs."""
+        if kv_caches is not None:
+            for layer, kv in zip(self.attn_layers.values(), kv_caches):
+                bind_kv_cache(layer, kv)
+        if attn_metadata is not None:
+            with forward_context(attn_metadata):
+                return self._forward(input_ids, positions, inputs_embeds, attn_metadata, **kwargs)
+        attn_metadata = current_attn_metadata()
         if attn_metadata is None:
             return None
+        return self._forward(input_ids, positions, inputs_embeds, attn_metadata, **kwargs)
+
+    def _forward(self, input_ids, positions, inputs_embeds, attn_metadata, **kwargs) -> torch.Tensor:
         if input_ids is not None and inputs_embeds is not None:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
         if input_ids is None and inputs_embeds is None:
@@ -93,14 +110,12 @@ class GLAswaModel(torch.nn.Module):
         params = GLACacheParams(gla_cache_tensors, state_indices_tensor)
         hidden_states = self.get_input_embeddings(input_ids) if inputs_embeds is None else inputs_embeds
 
-        gla_index = swa_index = 0
+        gla_index = 0
         residual = None      # the residual stream travels beside the blocks' outputs (fused add + norm)
         for i, layer in enumerate(self.layers):
             if i in self.config.attn_layers:
-                kv = kv_caches[swa_index] if kv_caches is not None else torch.empty(0, device=hidden_states.device)
-                swa_index += 1
                 hidden_states, residual = layer(hidden_states, carry_residual=True, residual=residual, positions=positions,
-                                                kv_cache=kv, attn_metadata=attn_metadata)
+                                                attn_metadata=attn_metadata)
             else:
                 p = params.at_layer_idx(gla_index)
                 gla_index += 1
@@ -110,19 +125,32 @@ class GLAswaModel(torch.nn.Module):
         return self.norm(hidden_states, residual)[0] if residual is not None else self.norm(hidden_states)
 
 
-class GLAswaForCausalLM(torch.nn.Module):
+class GLAswaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only, SupportsPP):
     packed_modules_mapping = {
         "qkv_proj": ["q_proj", "k_proj", "v_proj"],
         "gate_up_proj": ["gate_proj", "up_proj"],
     }
 
-    def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda",
-                 state_per_kv_head: bool = True):
+    def __init__(self, config=None, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda",
+                 state_per_kv_head: bool = True, *, vllm_config=None, prefix: Optional[str] = None):
+        """vLLM constructs the class as ``GLAswaForCausalLM(vllm_config=..., prefix=...)`` (reference
+        ``modeling_gla_swa.py:510-530``); the keyword form builds the same model without an engine."""
         super().__init__()
+        cache_config = None
+        if vllm_config is not None:
+            args = model_build_args(vllm_config, prefix or "")
+            config, max_num_seqs, quant, tp_group, device, cache_config = (
+                args.config, args.max_num_seqs, args.quant, args.tp_group, args.device, args.cache_config)
+            model_prefix = f"{prefix}.model" if prefix else "model"
+        else:
+            if config is None:
+                raise TypeError("GLAswaForCausalLM needs vllm_config= or a model config")
+            model_prefix = None if prefix is None else (f"{prefix}.model" if prefix else "model")
         self.config = config
         self.CONCAT_FFN = True
+        self.unpadded_vocab_size = config.vocab_size
         self.model = GLAswaModel(config, max_num_seqs=max_num_seqs, quant=quant, tp_group=tp_group, device=device,
-                                 state_per_kv_head=state_per_kv_head)
+                                 state_per_kv_head=state_per_kv_head, cache_config=cache_config, prefix=model_prefix)
         self.lm_head: Optional[torch.Tensor] = None             # [vocab, hidden] fp32 (the reference's lm_head.float())
         self.kv_cache = [torch.tensor([]) for _ in config.attn_layers]
 
@@ -139,7 +167,17 @@ class GLAswaForCausalLM(torch.nn.Module):
         return self.model(input_ids, positions, intermediate_tensors, inputs_embeds, **kwargs)
 
     def compute_logits(self, hidden_states: torch.Tensor, sampling_metadata=None) -> torch.Tensor:
+        """fp32 logits of the rows the sampler asks for (vLLM's ``LogitsProcessor`` prunes the hidden states to
+        ``sampling_metadata.selected_token_indices`` first)."""
+        idx = getattr(sampling_metadata, "selected_token_indices", None)
+        if idx is not None:
+            hidden_states = hidden_states.index_select(0, idx)
         return torch.nn.functional.linear(hidden_states.float(), self.lm_head)
+
+    def make_empty_intermediate_tensors(self, batch_size: int, dtype: torch.dtype, device: torch.device) -> IntermediateTensors:
+        return IntermediateTensors({
+            "hidden_states": torch.zeros((batch_size, self.config.hidden_size), dtype=dtype, device=device),
+            "residual": torch.zeros((batch_size, self.config.hidden_size), dtype=dtype, device=device)})
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]) -> Set[str]:
@@ -181,7 +219,7 @@ class GLAswaForCausalLM(torch.nn.Module):
             o_proj = make(loader.shard_row_parallel(lin(f"{p}.attn.o_proj"), m.tp_size, m.tp_rank, q["bits"], q["group_size"]))
             if i in cfg.attn_layers:
                 attn = SlidingWindowAttention(cfg.hidden_size, H, KVH, cfg.sliding_window, make(qkv), o_proj, m.cos_sin_cache,
-                                              shard=sh, tp_group=m.tp_group)
+                                              shard=sh, tp_group=m.tp_group, attn=m.attn_layers[str(i)])
             else:
                 gk1 = loader.slice_out_features(lin(f"{p}.attn.gk_proj.linear1"), sh.kv_head_start * D,
                                                 (sh.kv_head_start + sh.num_kv_heads) * D, q["bits"])

@@ -14,6 +14,7 @@ import torch
 
 from .. import hip_ops
 from ..linear import HymetaLinear
+from ..models.attention import MetaAttention, bind_kv_cache, current_attn_metadata, forward_context, standalone_prefix
 from ..parallel import HeadShard, all_reduce_sum, shard_heads
 
 
@@ -32,7 +33,11 @@ def rope_cos_sin_cache(head_dim: int, max_position: int, base: float, device=Non
 class SlidingWindowAttention(torch.nn.Module):
     def __init__(self, hidden_size: int, num_heads: int, num_key_value_heads: int, sliding_window: int,
                  qkv_proj: HymetaLinear, o_proj: HymetaLinear, cos_sin_cache: torch.Tensor,
-                 shard: Optional[HeadShard] = None, tp_group=None):
+                 shard: Optional[HeadShard] = None, tp_group=None, attn: Optional[MetaAttention] = None):
+        """``attn``: the registered attention layer that owns this layer's paged KV cache (the reference's
+        ``self.attn = Attention(..., per_layer_sliding_window=W + 1)``, ``modeling_gla_swa.py:193-202``; here the
+        meta-token layer with no meta tokens).  The model class creates it at construction so that the engine
+        finds it by name; a layer built on its own makes one under a private name."""
         super().__init__()
         self.shard = shard or shard_heads(num_heads, num_key_value_heads, 1, 0)
         self.head_dim = hidden_size // num_heads
@@ -40,41 +45,37 @@ class SlidingWindowAttention(torch.nn.Module):
         self.qkv_proj, self.o_proj = qkv_proj, o_proj
         self.register_buffer("cos_sin_cache", cos_sin_cache)
         self.tp_group = tp_group
+        if attn is None:
+            attn = swa_attention_layer(self.shard, self.head_dim, sliding_window, standalone_prefix("attn.attn"))
+        if (attn.num_heads, attn.num_kv_heads, attn.head_size) != (self.shard.num_heads, self.shard.num_kv_heads, self.head_dim):
+            raise ValueError("attention layer and head shard disagree on the head geometry")
+        self.attn = attn
 
-    def forward(self, hidden_states: torch.Tensor, positions: torch.Tensor, kv_cache: torch.Tensor,
-                attn_metadata) -> torch.Tensor:
-        """kv_cache ``[2, nblk, bs, Hkv_local, D]`` of this layer (numel 0: profiling run)."""
+    def forward(self, hidden_states: torch.Tensor, positions: torch.Tensor, kv_cache: Optional[torch.Tensor] = None,
+                attn_metadata=None) -> torch.Tensor:
+        """The attention runs through the registered layer and the opaque op, which read the paged cache bound to
+        the layer (numel 0: profiling run) and the step's metadata from the forward context; ``kv_cache
+        [2, nblk, bs, Hkv_local, D]`` / ``attn_metadata`` given explicitly are bound / set for the call."""
         H, Hkv, D = self.shard.num_heads, self.shard.num_kv_heads, self.head_dim
         T = hidden_states.shape[0]
         qkv = self.qkv_proj(hidden_states)
-        q = qkv[:, : H * D].view(T, H, D)
-        k = qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
-        v = qkv[:, (H + Hkv) * D:].view(T, Hkv, D)
-        hip_ops.rope_neox_(positions, q, k, self.cos_sin_cache)
-        have_cache = kv_cache.numel() > 0
-        if have_cache:
-            hip_ops.reshape_and_cache(k, v, kv_cache[0], kv_cache[1], attn_metadata.slot_mapping)
-        out = torch.empty(T, H, D, dtype=hidden_states.dtype, device=hidden_states.device)
-        n_pre = getattr(attn_metadata, "num_prefills", 0)
-        t_pre = getattr(attn_metadata, "num_prefill_tokens", 0)
-        if n_pre > 0:
-            pre = attn_metadata.prefill_metadata
-            paged = have_cache and pre.block_tables is not None and pre.block_tables.numel() > 0
-            if paged:
-                hip_ops.meta_swa_prefill(q[:t_pre], pre.query_start_loc, pre.max_query_len,
-                                         key_cache=kv_cache[0], value_cache=kv_cache[1],
-                                         block_tables=pre.block_tables, seq_lens_k=pre.seq_lens_tensor,
-                                         window_left=self.window_left, out=out[:t_pre],
-                                         max_seqlen_k=pre.max_prefill_seq_len or 0)
-            else:
-                hip_ops.meta_swa_prefill(q[:t_pre], pre.seq_start_loc, pre.max_prefill_seq_len,
-                                         key=k[:t_pre], value=v[:t_pre], cu_seqlens_k=pre.seq_start_loc,
-                                         window_left=self.window_left, out=out[:t_pre],
-                                         max_seqlen_k=pre.max_prefill_seq_len or 0)
-        if T > t_pre:
-            dec = attn_metadata.decode_metadata
-            hip_ops.meta_swa_paged_decode(q[t_pre:], kv_cache[0], kv_cache[1], dec.seq_lens_tensor,
-                                          dec.block_tables, window_left=self.window_left,
-                                          max_seqlen_k=dec.max_decode_seq_len or 0, out=out[t_pre:])
-        y = self.o_proj(out.view(T, H * D))
+        q = qkv[:, : H * D]
+        k = qkv[:, H * D:(H + Hkv) * D]
+        v = qkv[:, (H + Hkv) * D:]
+        hip_ops.rope_neox_(positions, q.view(T, H, D), k.view(T, Hkv, D), self.cos_sin_cache)
+        if kv_cache is not None:
+            bind_kv_cache(self.attn, kv_cache)
+        if attn_metadata is not None and current_attn_metadata() is not attn_metadata:
+            with forward_context(attn_metadata):
+                out = self.attn(q, k, v)
+        else:
+            out = self.attn(q, k, v)
+        y = self.o_proj(out)
         return all_reduce_sum(y, self.tp_group)
+
+
+def swa_attention_layer(shard: HeadShard, head_dim: int, sliding_window: int, prefix: str, cache_config=None) -> MetaAttention:
+    """The 7B sliding-window layer's attention object: ``sliding_window`` keys before the query plus the query
+    itself (``per_layer_sliding_window = W + 1``, reference ``modeling_gla_swa.py:200``), no meta tokens."""
+    return MetaAttention(shard.num_heads, head_dim, head_dim ** -0.5, shard.num_kv_heads, cache_config=cache_config,
+                         per_layer_sliding_window=sliding_window + 1, prefix=prefix, num_meta_tokens=0)

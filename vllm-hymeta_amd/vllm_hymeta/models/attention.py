@@ -41,9 +41,35 @@ def forward_context(attn_metadata, virtual_engine: int = 0):
         _STEP.update(saved)
 
 
+_standalone = [0]
+
+
+def standalone_prefix(tag: str) -> str:
+    """A layer-name prefix no other model or layer of this process uses: for models and layers built
+    directly (tests, benchmarks, other serving loops), where nobody hands out the names.  vLLM passes the
+    reference's names (``model.layers.<i>...``) and rejects duplicates itself."""
+    _standalone[0] += 1
+    return f"standalone{_standalone[0]}.{tag}"
+
+
+def current_attn_metadata():
+    """The step's attention metadata (vLLM's forward context, or ``forward_context()`` of this module)."""
+    return _context()[0]
+
+
+def bind_kv_cache(layer: "MetaAttention", kv_cache: torch.Tensor, virtual_engine: int = 0) -> None:
+    """What vLLM's ``bind_kv_cache`` does for every registered attention layer after it has allocated the
+    paged cache: ``layer.kv_cache[virtual_engine]`` becomes the layer's ``[2, num_blocks, block_size, Hkv, D]``
+    tensor.  Callers without vLLM (tests, benchmarks) bind their own tensors with it."""
+    while len(layer.kv_cache) <= virtual_engine:
+        layer.kv_cache.append(torch.tensor([]))
+    layer.kv_cache[virtual_engine] = kv_cache
+
+
 def _context():
-    """``(attn_metadata, virtual_engine, layers by name)`` of the current step."""
-    if HAVE_VLLM:   # pragma: no cover - only where vLLM is installed
+    """``(attn_metadata, virtual_engine, layers by name)`` of the current step: what a caller set with
+    ``forward_context()`` if anything, else vLLM's forward context."""
+    if HAVE_VLLM and _STEP["attn_metadata"] is None:   # pragma: no cover - only where vLLM is installed
         from vllm.forward_context import get_forward_context
         ctx = get_forward_context()
         return ctx.attn_metadata, ctx.virtual_engine, ctx.no_compile_layers
@@ -99,15 +125,19 @@ class MetaAttention(torch.nn.Module):
         self.dtype = torch.get_default_dtype()
         self.use_direct_call = False            # ROCm is "cuda-alike": always through the opaque ops
         self.use_output = attn_backend.accept_output_buffer
-        registry = _LAYERS
         if HAVE_VLLM:   # pragma: no cover - only where vLLM is installed
             from vllm.config import get_current_vllm_config
             cfg = get_current_vllm_config()
             registry = cfg.compilation_config.static_forward_context
             pipeline_parallel_size = cfg.parallel_config.pipeline_parallel_size
-        if prefix in registry:
-            raise ValueError(f"Duplicate layer name: {prefix}")
-        registry[prefix] = self
+            if prefix in registry:
+                raise ValueError(f"Duplicate layer name: {prefix}")
+            registry[prefix] = self
+            _LAYERS[prefix] = self          # for callers that set their own forward_context() beside vLLM
+        else:
+            if prefix in _LAYERS:
+                raise ValueError(f"Duplicate layer name: {prefix}")
+            _LAYERS[prefix] = self
         self.layer_name = prefix
         self.attn_type = attn_type
         self.kv_sharing_target_layer_name = kv_sharing_target_layer_name
@@ -145,6 +175,17 @@ class MetaAttention(torch.nn.Module):
 def release_layer(prefix: str) -> None:
     """Forget a layer name of the vLLM-free registry (tests that build models repeatedly)."""
     _LAYERS.pop(prefix, None)
+
+
+def release_layers(prefix: str) -> None:
+    """Forget every layer whose name starts with ``prefix`` (a whole model's layers)."""
+    for name in [n for n in _LAYERS if n.startswith(prefix)]:
+        del _LAYERS[name]
+
+
+def registered_layers() -> Dict[str, "MetaAttention"]:
+    """The vLLM-free registry (name -> layer), as vLLM's ``static_forward_context`` holds it under an engine."""
+    return dict(_LAYERS)
 
 
 # ------------------------------------------------------------------ the opaque ops

@@ -21,7 +21,7 @@ from typing import Optional
 import torch
 
 from .. import _C, hip_ops
-from ..attention.meta_attention import MetaAttentionImpl
+from .attention import MetaAttention, bind_kv_cache, current_attn_metadata, forward_context, standalone_prefix
 from ..linear import HymetaLinear
 from ..parallel import HeadShard, all_reduce_sum, all_reduce_variance, shard_heads
 
@@ -99,18 +99,27 @@ class MetaFlashAttention(torch.nn.Module):
 
     def __init__(self, hidden_size: int, num_heads: int, num_key_value_heads: int, qkv_proj: HymetaLinear,
                  cos_sin_cache: torch.Tensor, sliding_window: Optional[int], num_meta_tokens: int = 128,
-                 shard: Optional[HeadShard] = None):
+                 shard: Optional[HeadShard] = None, attn: Optional[MetaAttention] = None):
         """``sliding_window``: W keys including the query itself; ``None`` / 0 = full attention (the
-        ``interleaved_sliding_window`` entry 0 of the config)."""
+        ``interleaved_sliding_window`` entry 0 of the config).
+
+        ``attn``: the registered attention layer that owns this layer's paged KV cache (reference
+        ``self.attn = MetaAttention(...)``, ``:734-744``).  The model classes create it when they are
+        constructed, so that the engine finds it by name and binds the cache; a layer built on its own makes
+        one under a private name."""
         super().__init__()
         self.shard = shard or shard_heads(num_heads, num_key_value_heads, 1, 0)
         self.head_dim = hidden_size // num_heads
         self.qkv_proj = qkv_proj
         self.register_buffer("cos_sin_cache", cos_sin_cache)
         self.num_meta_tokens = num_meta_tokens
-        self.impl = MetaAttentionImpl(self.shard.num_heads, self.head_dim, self.head_dim ** -0.5,
-                                      self.shard.num_kv_heads, None, sliding_window or None, "auto",
-                                      num_meta_tokens=num_meta_tokens)
+        if attn is None:
+            attn = MetaAttention(self.shard.num_heads, self.head_dim, self.head_dim ** -0.5, self.shard.num_kv_heads,
+                                 per_layer_sliding_window=sliding_window or None,
+                                 prefix=standalone_prefix("vanilla_attn.attn"), num_meta_tokens=num_meta_tokens)
+        if (attn.num_heads, attn.num_kv_heads, attn.head_size) != (self.shard.num_heads, self.shard.num_kv_heads, self.head_dim):
+            raise ValueError("attention layer and head shard disagree on the head geometry")
+        self.attn = attn
 
     def _qkv(self, hidden_states, positions, offset):
         H, Hkv, D = self.shard.num_heads, self.shard.num_kv_heads, self.head_dim
@@ -135,16 +144,25 @@ class MetaFlashAttention(torch.nn.Module):
                                        meta_key=meta_fattn_cache[0], meta_value=meta_fattn_cache[1])
         return out.view(M, -1)
 
-    def forward(self, hidden_states: torch.Tensor, positions: torch.Tensor, kv_cache: torch.Tensor,
-                meta_fattn_cache: torch.Tensor, attn_metadata) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, positions: torch.Tensor, kv_cache: Optional[torch.Tensor],
+                meta_fattn_cache: torch.Tensor, attn_metadata=None) -> torch.Tensor:
         """positions are the sequence positions of the real tokens; the meta tokens occupy 0..M-1, so
-        real token p is roped at p + M (reference ``modeling_hymeta.py:1314-1323``)."""
+        real token p is roped at p + M (reference ``modeling_hymeta.py:1314-1323``).
+
+        The attention itself runs through the registered layer ``self.attn`` and the opaque op
+        (reference ``:795``), which reads the paged cache bound to that layer and the step's metadata from
+        the forward context.  ``kv_cache`` / ``attn_metadata`` given explicitly (callers without an engine)
+        are bound / set for the call."""
         q, k, v = self._qkv(hidden_states, positions, self.num_meta_tokens)
         T, H, D = q.shape
-        out = torch.empty(T, H, D, dtype=hidden_states.dtype, device=hidden_states.device)
-        self.impl.forward(None, q, k, v, None, meta_fattn_cache[0], meta_fattn_cache[1], kv_cache,
-                          attn_metadata, out)
-        return out.view(T, H * D)
+        if kv_cache is not None:
+            bind_kv_cache(self.attn, kv_cache)
+        k2, v2 = (meta_fattn_cache[0], meta_fattn_cache[1]) if self.num_meta_tokens > 0 else (None, None)
+        q2d, k2d, v2d = q.reshape(T, -1), k.reshape(T, -1), v.reshape(T, -1)     # views of the fused buffer
+        if attn_metadata is not None and current_attn_metadata() is not attn_metadata:
+            with forward_context(attn_metadata):
+                return self.attn(q2d, k2d, v2d, query2=None, key2=k2, value2=v2)
+        return self.attn(q2d, k2d, v2d, query2=None, key2=k2, value2=v2)
 
 
 class IntraHybridAttention(torch.nn.Module):
@@ -177,7 +195,9 @@ class IntraHybridAttention(torch.nn.Module):
         return all_reduce_sum(self.out_proj(self.combine(out_attn, out_linear)), self.tp_group)
 
     def forward(self, hidden_states, positions, kv_cache, hymeta_cache, meta_linear_cache, meta_fattn_cache,
-                state_indices_tensor, attn_metadata, lower_bound=None) -> torch.Tensor:
+                state_indices_tensor, attn_metadata=None, lower_bound=None) -> torch.Tensor:
+        if attn_metadata is None:
+            attn_metadata = current_attn_metadata()
         out_attn = self.vanilla_attn(hidden_states, positions, kv_cache, meta_fattn_cache, attn_metadata)
         out_linear = self.linear_attn(hidden_states, hymeta_cache, meta_linear_cache, state_indices_tensor,
                                       attn_metadata, lower_bound)

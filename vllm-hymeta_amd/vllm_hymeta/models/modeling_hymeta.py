@@ -16,7 +16,8 @@ What differs in mechanism:
 * a new sequence's state slot is seeded from the meta state by the prefill kernel
   (``context_lens == 0``), not zeroed on the host (``_clear_prefill_cache``, ``:1202-1227``);
 * tensors are ingested in checkpoint format and cut for the rank by ``vllm_hymeta.loader``.
-Pipeline parallelism (``IntermediateTensors``) is vLLM's and is not restated here.
+Pipeline parallelism is not implemented (a ``pipeline_parallel_size`` above 1 is refused when the model is built);
+``make_empty_intermediate_tensors`` keeps the reference's interface.
 """
 
 from __future__ import annotations
@@ -26,21 +27,15 @@ from typing import Dict, Iterable, List, Optional, Set, Tuple
 import torch
 
 from .. import loader
+from .._compat import HasInnerState, IntermediateTensors, IsHybrid, SupportsPP, SupportsV0Only, model_build_args
 from ..linear import HymetaLinear
 from ..model_for_7B.window_attention import rope_cos_sin_cache
 from ..parallel import shard_heads, tp_rank_and_size
+from .attention import MetaAttention, bind_kv_cache, current_attn_metadata, forward_context, standalone_prefix
 from .block import HybridBlock, HymetaRMSNorm
 from .hybrid_attention import HLinearAttention, IntraHybridAttention, MetaFlashAttention
 from .hymeta_cache import HymetaCacheManager, HymetaCacheParams
 from .moe import HymetaMLP, HymetaMoE
-
-
-def _forward_context_metadata():
-    try:   # pragma: no cover - only where vLLM is installed
-        from vllm.forward_context import get_forward_context
-        return get_forward_context().attn_metadata
-    except Exception:
-        return None
 
 
 def _layer_experts(config, layer_idx: int) -> int:
@@ -67,9 +62,15 @@ def _layer_window(config, layer_idx: int) -> Optional[int]:
 
 
 class HymetaModel(torch.nn.Module):
-    def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda"):
+    def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda",
+                 cache_config=None, prefix: Optional[str] = None):
+        """``prefix``: name of this module in the whole model (``"model"`` under vLLM); the softmax branch of layer
+        ``i`` registers its attention layer as ``<prefix>.layers.<i>.attn.vanilla_attn.attn`` (reference ``:742,
+        843,955,1133``), the name under which the engine binds that layer's paged KV cache.  ``None``: a private
+        name (models built directly, several per process)."""
         super().__init__()
         self.config = config
+        self.prefix = standalone_prefix("model") if prefix is None else prefix
         self.device = torch.device(device)
         self.tp_group = tp_group
         self.tp_rank, self.tp_size = tp_rank_and_size(tp_group)
@@ -89,6 +90,13 @@ class HymetaModel(torch.nn.Module):
         self.register_buffer("cos_sin_cache", rope_cos_sin_cache(D, max_pos + self.num_meta_tokens, int(config.rope_theta),
                                                                  device=self.device),
                              persistent=False)
+        # the attention layer objects exist from construction on (the engine looks them up by name when it
+        # allocates the KV cache, before and independently of the weights); load_weights builds the rest around them
+        self.attn_layers = torch.nn.ModuleList([
+            MetaAttention(self.shard.num_heads, D, D ** -0.5, self.shard.num_kv_heads, cache_config=cache_config,
+                          per_layer_sliding_window=_layer_window(config, i) or None,
+                          prefix=f"{self.prefix}.layers.{i}.attn.vanilla_attn.attn", num_meta_tokens=self.num_meta_tokens)
+            for i in range(L)])
         self.embeddings: Optional[torch.Tensor] = None
         self.layers = torch.nn.ModuleList()
         self.norm: Optional[HymetaRMSNorm] = None
@@ -120,10 +128,22 @@ class HymetaModel(torch.nn.Module):
     def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor, intermediate_tensors=None,
                 inputs_embeds: Optional[torch.Tensor] = None, attn_metadata=None,
                 kv_caches: Optional[List[torch.Tensor]] = None, **kwargs) -> Optional[torch.Tensor]:
-        if attn_metadata is None:
-            attn_metadata = _forward_context_metadata()
+        """Under an engine the step's metadata comes from the forward context and every layer's paged KV cache is
+        the one the engine bound to its attention layer (reference ``:1243-1246``).  Callers without an engine pass
+        ``attn_metadata`` and, once, ``kv_caches`` (one ``[2, nblk, bs, Hkv, D]`` tensor per layer): they are set /
+        bound here and the same path runs."""
+        if kv_caches is not None:
+            for layer, kv in zip(self.attn_layers, kv_caches):
+                bind_kv_cache(layer, kv)
+        if attn_metadata is not None:
+            with forward_context(attn_metadata):
+                return self._forward(input_ids, positions, inputs_embeds, attn_metadata, **kwargs)
+        attn_metadata = current_attn_metadata()
         if attn_metadata is None:
             return None
+        return self._forward(input_ids, positions, inputs_embeds, attn_metadata, **kwargs)
+
+    def _forward(self, input_ids, positions, inputs_embeds, attn_metadata, **kwargs) -> torch.Tensor:
         if input_ids is not None and inputs_embeds is not None:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
         if input_ids is None and inputs_embeds is None:
@@ -137,28 +157,45 @@ class HymetaModel(torch.nn.Module):
         residual = None      # the residual stream travels beside the blocks' outputs (fused add + norm)
         for i, layer in enumerate(self.layers):
             c = params.at_layer_idx(i)
-            kv = kv_caches[i] if kv_caches is not None else torch.empty(0, device=hidden_states.device)
             hidden_states, residual = layer(hidden_states, carry_residual=True, residual=residual, positions=positions,
-                                            kv_cache=kv, hymeta_cache=c.hymeta_cache,
+                                            kv_cache=None, hymeta_cache=c.hymeta_cache,
                                             meta_linear_cache=c.meta_linear_cache, meta_fattn_cache=c.meta_fattn_cache,
                                             state_indices_tensor=c.state_indices_tensor, attn_metadata=attn_metadata,
                                             lower_bound=self._lower_bound(i))
         return self.norm(hidden_states, residual)[0] if residual is not None else self.norm(hidden_states)
 
 
-class HymetaForCausalLM(torch.nn.Module):
+class HymetaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only, SupportsPP):
     packed_modules_mapping = {
         "qkv_proj": ["q_proj", "k_proj", "v_proj"],
         "gate_up_proj": ["gate_proj", "up_proj"],
     }
 
-    def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda"):
+    def __init__(self, config=None, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda",
+                 *, vllm_config=None, prefix: Optional[str] = None):
+        """vLLM constructs the class as ``HymetaForCausalLM(vllm_config=..., prefix=...)`` (reference ``:1386-1411``):
+        the HF config, ``scheduler_config.max_num_seqs`` (state slots), the quantisation parameters, the
+        tensor-parallel group and the cache config are read from ``vllm_config``.  The keyword form
+        ``HymetaForCausalLM(config, max_num_seqs=..., quant=..., tp_group=..., device=...)`` builds the same model
+        without an engine."""
         super().__init__()
+        cache_config = None
+        if vllm_config is not None:
+            args = model_build_args(vllm_config, prefix or "")
+            config, max_num_seqs, quant, tp_group, device, cache_config = (
+                args.config, args.max_num_seqs, args.quant, args.tp_group, args.device, args.cache_config)
+            model_prefix = f"{prefix}.model" if prefix else "model"          # maybe_prefix(prefix, "model"), :1410
+        else:
+            if config is None:
+                raise TypeError("HymetaForCausalLM needs vllm_config= or a model config")
+            model_prefix = None if prefix is None else (f"{prefix}.model" if prefix else "model")
         self.config = config
         self.CONCAT_FFN = True
         if not hasattr(config, "sliding_window"):
             config.sliding_window = None
-        self.model = HymetaModel(config, max_num_seqs=max_num_seqs, quant=quant, tp_group=tp_group, device=device)
+        self.unpadded_vocab_size = config.vocab_size
+        self.model = HymetaModel(config, max_num_seqs=max_num_seqs, quant=quant, tp_group=tp_group, device=device,
+                                 cache_config=cache_config, prefix=model_prefix)
         self.lm_head: Optional[torch.Tensor] = None             # [vocab, hidden] fp32 (:1429)
         self.kv_cache = [torch.tensor([]) for _ in range(config.num_hidden_layers)]
 
@@ -175,7 +212,18 @@ class HymetaForCausalLM(torch.nn.Module):
         return self.model(input_ids, positions, intermediate_tensors, inputs_embeds, **kwargs)
 
     def compute_logits(self, hidden_states: torch.Tensor, sampling_metadata=None) -> torch.Tensor:
+        """fp32 logits of the rows the sampler asks for (vLLM's ``LogitsProcessor`` prunes the hidden states to
+        ``sampling_metadata.selected_token_indices`` first; reference ``:1459-1469``)."""
+        idx = getattr(sampling_metadata, "selected_token_indices", None)
+        if idx is not None:
+            hidden_states = hidden_states.index_select(0, idx)
         return torch.nn.functional.linear(hidden_states.float(), self.lm_head)
+
+    def make_empty_intermediate_tensors(self, batch_size: int, dtype: torch.dtype, device: torch.device) -> IntermediateTensors:
+        """Reference ``:1471-1483``."""
+        return IntermediateTensors({
+            "hidden_states": torch.zeros((batch_size, self.config.hidden_size), dtype=dtype, device=device),
+            "residual": torch.zeros((batch_size, self.config.hidden_size), dtype=dtype, device=device)})
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]) -> Set[str]:
@@ -238,7 +286,7 @@ class HymetaForCausalLM(torch.nn.Module):
                 return make(fused)
 
             vanilla = MetaFlashAttention(cfg.hidden_size, H, KVH, qkv("vanilla_attn"), m.cos_sin_cache, _layer_window(cfg, i),
-                                         num_meta_tokens=m.num_meta_tokens, shard=sh)
+                                         num_meta_tokens=m.num_meta_tokens, shard=sh, attn=m.attn_layers[i])
             linear = HLinearAttention(cfg.hidden_size, H, KVH, qkv("linear_attn"), i, num_meta_tokens=m.num_meta_tokens, shard=sh)
             out_proj = make(loader.shard_row_parallel(lin(f"{p}.attn.out_proj"), m.tp_size, m.tp_rank, q["bits"], q["group_size"]))
             attn = IntraHybridAttention(vanilla, linear, out_proj, plain[f"{p}.attn.norm1.weight"][hs].to(dev),
