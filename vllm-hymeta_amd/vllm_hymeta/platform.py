@@ -12,8 +12,10 @@ import logging
 logger = logging.getLogger(__name__)
 
 META_BACKEND = "vllm_hymeta.attention.meta_attention.MetaAttentionBackend"
-# Stock sliding-window backend the 7B model runs on when VLLM_ATTENTION_BACKEND=XFORMERS is set
-# (the reference's switch, platform.py:24-27); on ROCm vLLM's own FlashAttention-compatible backend.
+# The reference runs its 7B model on vLLM's stock backend, selected with VLLM_ATTENTION_BACKEND=XFORMERS
+# (platform.py:24-27).  Here both families run on the meta-token backend (the 7B sliding-window layers are
+# MetaAttention layers with no meta tokens), so the switch is only kept for non-Hymeta models served by the
+# same installation: it hands back vLLM's own ROCm backend.
 STOCK_BACKEND = "vllm.attention.backends.rocm_flash_attn.ROCmFlashAttentionBackend"
 
 try:  # pragma: no cover - only where vLLM is installed
@@ -37,8 +39,8 @@ class HymetaRocmPlatform(_Base):
                              use_v1, use_mla) -> str:
         name = getattr(selected_backend, "name", selected_backend)
         if selected_backend == _XFORMERS or name == "XFORMERS":
-            logger.info("Hymeta: stock sliding-window backend selected (7B model).")
+            logger.info("Hymeta: vLLM's stock ROCm attention backend selected (non-Hymeta models only: both Hymeta "
+                        "families need the meta-token backend, unset VLLM_ATTENTION_BACKEND for them).")
             return STOCK_BACKEND
-        logger.info("Hymeta: MetaAttentionBackend selected (70B model). Set "
-                    "VLLM_ATTENTION_BACKEND=XFORMERS for the 7B model or non-Hymeta models.")
+        logger.info("Hymeta: MetaAttentionBackend selected (Hymeta 70B and 7B).")
         return META_BACKEND
