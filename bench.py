@@ -1,21 +1,21 @@
 #!/usr/bin/env python3
-"""Benchmark of the Hymeta attention hot path on MI355X.
+"""Benchmark of the Hymeta serving hot path on MI355X.
 
-Workload at N=1 (BASELINE.json configs[1]): Hymeta-7B bf16 TP=1, context 8192,
-block_size 256, greedy decode of a batch of sequences.  One step = one decode
-token for every sequence through the attention hot path of all 28 layers:
-
-  14 GLA layers : fused gate (relu, logsigmoid/16) + recurrent state update +
-                  per-head RMS norm                     (hymeta_gla_decode)
-  14 SWA layers : paged KV write of the new token + paged sliding-window decode over
-                  4097 keys, one launch                  (hymeta_meta_swa_paged_decode, fused write)
-
-The projections / MLP around the attention kernels are outside the hot path and
+Workload at N=1 (BASELINE.json configs[1]): Hymeta-7B bf16 TP=1, context 8192, block_size 256, greedy
+decode of a batch of sequences.  One step = one decode token for every sequence through the WHOLE
+28-layer stack of the model class the plugin registers (``GLAswaForCausalLM``, random-init weights of the
+published geometry loaded by checkpoint name): block norms, qkv / gate / output projections, GLA decode
+(14 layers) or paged sliding-window decode over 4097 keys with the fused KV write (14 layers), gated MLP,
+final norm.  The step is replayed from one HIP graph, as the serving engine replays its decode step; the
+per-step metadata (positions, sequence lengths, cache slots) lives in static buffers that a few tiny device
+ops advance between replays.  Embedding lookup is in the step; LM head and sampler belong to the engine and
 are not run.  Inputs are synthetic (seeded) and resident in HBM before timing.
 
-N>1 (python -m torch.distributed.run ... bench.py --gpus N): the path shards by
-sequence with no data-path collective, so every rank runs the same per-GPU
-batch on its own KV cache / state ("weak" scaling); time = max over ranks.
+``value`` = output tokens/s of that step; ``roofline`` prices the step against HBM: the bytes a step must
+move (every linear's weights once, the visible K/V rows, the GLA states read + written) / step time.
+
+N>1 (python -m torch.distributed.run ... bench.py --gpus N): tensor parallelism over heads with RCCL
+all-reduces, see ``tp_main``.
 
 Prints ONE JSON line on rank 0.
 """
@@ -35,10 +35,13 @@ import torch  # noqa: E402
 
 # Hymeta-7B geometry (vllm_hymeta/model_for_7B/configuration_gla_swa.py:15-43 in the reference)
 H, HKV, D = 28, 4, 128
-N_GLA, N_SWA = 14, 14
+HIDDEN, INTER = 3584, 18944
+N_LAYERS, N_GLA, N_SWA = 28, 14, 14
 WINDOW = 4096          # 7B attends to W+1 keys: flash window_left = W (hf_7B_model/window_attention.py:215)
 BLOCK = 256
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+GROUP = 128            # GPTQ group size of the synthetic 4-bit checkpoint
+WBYTES = {"bf16": 2.0, "w8a8": 1.0, "gptq4": 0.5}
 
 
 def parse():
@@ -46,147 +49,318 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="decode sequences per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="decode sequences (global batch)")
     ap.add_argument("--ctx", type=int, default=8192)
+    ap.add_argument("--quant", choices=("bf16", "gptq4", "w8a8"), default="bf16", help="linears of the timed model")
     ap.add_argument("--gla-state", choices=("kv_head", "query_head"), default="kv_head",
                     help="GLA state layout: one state per key/value head (the package's default; the 7 query heads "
                          "of a group hold identical states) or one per query head (the reference's cache shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prefill", action="store_true", help="skip the 32k prefill (TTFT) side measurement")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the 32k TTFT / single-request latency side measurements")
     ap.add_argument("--prefill-ctx", type=int, default=32768)
-    ap.add_argument("--no-model", action="store_true",
-                    help="skip the whole-model decode step (projections + MLP around the hot path) side measurement")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip every side measurement (quantised models, kernel table, 70B shard): the timed region only")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs")
     return ap.parse_args()
 
 
-def build_workload(args, dev, total_steps):
-    from vllm_hymeta import hip_ops  # noqa: F401  (fails loudly if the HIP library is missing)
-
-    B, ctx = args.batch, args.ctx
-    g = torch.Generator(device="cpu")
-    g.manual_seed(0)
-    blocks_per_seq = (ctx + total_steps + BLOCK - 1) // BLOCK
-    nblk = B * blocks_per_seq
-    w = {}
-    # one KV cache per SWA layer, [2, nblk, bs, Hkv, D] (meta_attention.py:81-92)
-    w["kv"] = [torch.randn(2, nblk, BLOCK, HKV, D, device=dev, dtype=torch.bfloat16) for _ in range(N_SWA)]
-    perm = torch.randperm(nblk, generator=g).to(torch.int32)
-    w["block_tables"] = perm.view(B, blocks_per_seq).to(dev)
-    # per-step metadata, precomputed: sequence length incl. the new token, and its slot
-    seq_lens, slots = [], []
-    bt_cpu = perm.view(B, blocks_per_seq).long()
-    for s in range(total_steps):
-        pos = ctx + s  # position of the token decoded at step s
-        seq_lens.append(torch.full((B,), pos + 1, dtype=torch.int32))
-        slots.append(bt_cpu[:, pos // BLOCK] * BLOCK + pos % BLOCK)
-    w["seq_lens"] = [t.to(dev) for t in seq_lens]
-    w["slot_mapping"] = [t.to(dev) for t in slots]
-    # GLA recurrent state per layer: [slots, H, D, D] bf16 in the reference (gla_cache.py:9-33), whose 7
-    # query heads per group hold identical states; [slots, Hkv, D, D] in this package's model class
-    w["state"] = gla_states(B, HKV if args.gla_state == "kv_head" else H, dev)
-    w["slot_idx"] = torch.arange(B, dtype=torch.int32, device=dev)
-    w["g_norm"] = torch.ones(D, dtype=torch.bfloat16, device=dev)
-    # fused qkv(+gk) projection outputs of the step (synthetic), one buffer per layer kind
-    w["qkv_gla"] = torch.randn(B, (H + 2 * HKV) * D, device=dev, dtype=torch.float32).to(torch.bfloat16)
-    w["gk"] = torch.randn(B, HKV, D, device=dev, dtype=torch.float32).to(torch.bfloat16)
-    w["qkv_swa"] = torch.randn(B, (H + 2 * HKV) * D, device=dev, dtype=torch.float32).to(torch.bfloat16)
-    w["out"] = torch.empty(B, H, D, device=dev, dtype=torch.bfloat16)
-    max_k = ctx + total_steps
-    w["max_seqlen_k"] = max_k
-    w["splits"] = hip_ops.paged_decode_splits(B, HKV, max_k, WINDOW, 0)
-    return w
+# --------------------------------------------------------------------------- synthetic checkpoint
+def config_7b(vocab=4096):
+    """The published 7B geometry; the vocabulary is cut down (embedding and LM head are the engine's side)."""
+    from vllm_hymeta.model_for_7B.configuration_gla_swa import GLAswaConfig
+    return GLAswaConfig(vocab_size=vocab)
 
 
-def gla_states(B, heads, dev):
-    return [(torch.randn(B, heads, D, D, device=dev, dtype=torch.float32) * 0.1).to(torch.bfloat16) for _ in range(N_GLA)]
+def synthetic_checkpoint_7b(cfg, dev, quant, seed=0):
+    """(name, tensor) pairs of a random-init checkpoint under the published names, generated on the device one
+    tensor at a time.  ``quant``: "bf16"; "gptq4" (gptqmodel tensors: qweight / qzeros / scales / g_idx, 4 bit,
+    group 128, the rank-16 gate projection left in bf16 as hf_7B_model/gla_swa_gptq.py:18-24 leaves it); "w8a8"
+    (compressed-tensors int8 weight + per-channel weight_scale, hf_model/quant_w8a8.py:121-124)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    hidden, inter = cfg.hidden_size, cfg.intermediate_size
+    Hq, Hk, Dh = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, device=dev, generator=g, dtype=torch.float32) * scale).to(torch.bfloat16)
+
+    def linear(prefix, out_f, in_f, bias=False, quantise=True):
+        if bias:
+            yield prefix + ".bias", rnd(out_f, scale=0.02)
+        if quant == "bf16" or not quantise:
+            yield prefix + ".weight", rnd(out_f, in_f, scale=in_f ** -0.5)
+        elif quant == "w8a8":
+            yield prefix + ".weight", torch.randint(-127, 128, (out_f, in_f), dtype=torch.int8, device=dev, generator=g)
+            yield prefix + ".weight_scale", (torch.rand(out_f, 1, device=dev, generator=g) * (2.0 / 127) * in_f ** -0.5).float()
+        else:
+            yield prefix + ".qweight", torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // 8, out_f), dtype=torch.int32, device=dev, generator=g)
+            yield prefix + ".qzeros", torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // GROUP, out_f // 8), dtype=torch.int32, device=dev, generator=g)
+            yield prefix + ".scales", (torch.rand(in_f // GROUP, out_f, device=dev, generator=g) * (0.25 * in_f ** -0.5)).to(torch.float16)
+            yield prefix + ".g_idx", (torch.arange(in_f, dtype=torch.int32, device=dev) // GROUP)
+
+    yield "model.embeddings.weight", rnd(cfg.vocab_size, hidden, scale=0.5)
+    yield "model.norm.weight", torch.ones(hidden, dtype=torch.bfloat16, device=dev)
+    yield "lm_head.weight", rnd(cfg.vocab_size, hidden, scale=0.02)
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        yield from linear(p + "attn.q_proj", Hq * Dh, hidden, bias=True)
+        yield from linear(p + "attn.k_proj", Hk * Dh, hidden, bias=True)
+        yield from linear(p + "attn.v_proj", Hk * Dh, hidden, bias=True)
+        yield from linear(p + "attn.o_proj", hidden, Hq * Dh)
+        if i not in cfg.attn_layers:
+            yield from linear(p + "attn.gk_proj.0", 16, hidden, quantise=False)
+            yield from linear(p + "attn.gk_proj.1", Hk * Dh, 16, bias=True, quantise=False)
+            yield p + "attn.g_norm.weight", torch.ones(Dh, dtype=torch.bfloat16, device=dev)
+        yield p + "attn_norm.weight", torch.ones(hidden, dtype=torch.bfloat16, device=dev)
+        yield p + "mlp_norm.weight", torch.ones(hidden, dtype=torch.bfloat16, device=dev)
+        yield from linear(p + "mlp.gate_proj", inter, hidden)
+        yield from linear(p + "mlp.up_proj", inter, hidden)
+        yield from linear(p + "mlp.down_proj", hidden, inter)
 
 
-def split_qkv(buf, B):
-    q = buf[:, : H * D].view(B, H, D)
-    k = buf[:, H * D:(H + HKV) * D].view(B, HKV, D)
-    v = buf[:, (H + HKV) * D:].view(B, HKV, D)
-    return q, k, v
+def build_model_7b(dev, quant, max_num_seqs, gla_state="kv_head", tp_group=None):
+    from vllm_hymeta.model_for_7B.modeling_gla_swa import GLAswaForCausalLM
+
+    cfg = config_7b()
+    q = {"bits": 4, "group_size": GROUP, "zero_offset": 1} if quant == "gptq4" else None
+    model = GLAswaForCausalLM(cfg, max_num_seqs=max_num_seqs, quant=q, tp_group=tp_group, device=dev,
+                              state_per_kv_head=gla_state == "kv_head")
+    model.load_weights(synthetic_checkpoint_7b(cfg, dev, quant))
+    return model
 
 
-def run_step(w, s, B, events=None):
-    from vllm_hymeta import _C, hip_ops
-
-    q, k, v = split_qkv(w["qkv_gla"], B)
-    for layer in range(N_GLA):
-        hip_ops.gla_decode(q, k, v, w["gk"], w["state"][layer], w["slot_idx"], out=w["out"],
-                           gate_mode=_C.GATE_7B, out_norm_weight=w["g_norm"], out_norm_eps=1e-6)
-    q, k, v = split_qkv(w["qkv_swa"], B)
-    for layer in range(N_SWA):
-        kv = w["kv"][layer]
-        # the dominant kernel is timed on one layer per step (a different one each step): an event pair
-        # around every launch would put 28 extra packets between the kernels of the timed region
-        timed = events is not None and layer == s % N_SWA
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        hip_ops.meta_swa_paged_decode(q, kv[0], kv[1], w["seq_lens"][s], w["block_tables"],
-                                      window_left=WINDOW, max_seqlen_k=w["max_seqlen_k"],
-                                      num_splits=w["splits"], out=w["out"],
-                                      new_key=k, new_value=v, slot_mapping=w["slot_mapping"][s])
-        if timed:
-            e1.record()
-            events.append((e0, e1))
+def linear_weight_bytes(quant, tp=1):
+    """Bytes of linear weights one decode step of one rank must read (qkv, o, gate_up, down of every layer)."""
+    per_layer = (H + 2 * HKV) * D * HIDDEN + HIDDEN * H * D + 3 * INTER * HIDDEN
+    return int(N_LAYERS * per_layer * WBYTES[quant] / tp)
 
 
-def prefill_side_measurement(dev, L):
-    """Attention share of the time to first token of ONE L-token prompt (Hymeta-7B, TP=1): the
-    28 layers' prefill kernels (14 GLA chunked prefill with fused gate + norm and state write-back,
-    14 sliding-window varlen attention + paged KV write of the prompt).  Outside the timed decode
-    region; reported next to the headline value."""
-    from vllm_hymeta import _C, hip_ops
+def attention_bytes(B, ctx, heads=H, kv_heads=HKV, state_heads=HKV):
+    """Algorithmic bytes of the attention kernels of one step: GLA states read + written, visible K/V rows."""
+    keys = min(ctx + 1, WINDOW + 1)
+    gla = N_GLA * B * (2 * state_heads * D * D * 2 + heads * D * 4 + 3 * kv_heads * D * 2)
+    swa = N_SWA * B * (2 * kv_heads * D * 2 * keys + heads * D * 4)
+    return gla + swa
 
-    g = torch.Generator(device="cpu")
-    g.manual_seed(1)
-    qkv = torch.randn(L, (H + 2 * HKV) * D, generator=g).to(torch.bfloat16).to(dev)
-    q = qkv[:, : H * D].view(L, H, D)
-    k = qkv[:, H * D:(H + HKV) * D].view(L, HKV, D)
-    v = qkv[:, (H + HKV) * D:].view(L, HKV, D)
-    gk = torch.randn(L, HKV, D, generator=g).to(torch.bfloat16).to(dev)
-    state = torch.zeros(1, HKV, D, D, dtype=torch.bfloat16, device=dev)
-    slot = torch.zeros(1, dtype=torch.int32, device=dev)
-    cu = torch.tensor([0, L], dtype=torch.int32, device=dev)
-    ctx0 = torch.zeros(1, dtype=torch.int32, device=dev)
-    g_norm = torch.ones(D, dtype=torch.bfloat16, device=dev)
-    out = torch.empty(L, H, D, dtype=torch.bfloat16, device=dev)
-    nblk = (L + BLOCK - 1) // BLOCK
-    kv = torch.zeros(2, nblk, BLOCK, HKV, D, dtype=torch.bfloat16, device=dev)
-    slots = torch.arange(L, dtype=torch.int64, device=dev)
 
-    def gla():
-        hip_ops.gla_prefill_varlen(q, k, v, gk, state, slot, cu, L, context_lens=ctx0, out=out,
-                                   gate_mode=_C.GATE_7B, out_norm_weight=g_norm, out_norm_eps=1e-6)
+# --------------------------------------------------------------------------- decode runner
+class DecodeRunner:
+    """A batch of ``B`` sequences at context ``ctx`` decoding one token per step through ``model``: owns the paged KV
+    caches (random content, scattered blocks), the static per-step metadata and the captured graph of the step."""
 
-    def swa():
-        hip_ops.reshape_and_cache(k, v, kv[0], kv[1], slots)
-        hip_ops.meta_swa_prefill(q, cu, L, key=k, value=v, cu_seqlens_k=cu, window_left=WINDOW, out=out)
+    def __init__(self, model, B, ctx, total_steps, dev, seed=0):
+        from vllm_hymeta.attention.meta_attention import MetaAttentionMetadata
 
-    def timed(fn, iters=5):
+        self.model, self.B, self.dev = model, B, dev
+        m = model.model
+        kvh = m.shard.num_kv_heads
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed)
+        bps = (ctx + total_steps + 1 + BLOCK - 1) // BLOCK
+        nblk = B * bps
+        self.kv = [torch.randn(2, nblk, BLOCK, kvh, D, device=dev, dtype=torch.bfloat16) for _ in m.attn_layers]
+        self.block_tables = torch.randperm(nblk, generator=g).to(torch.int32).view(B, bps).to(dev)
+        self.positions = torch.full((B,), ctx, dtype=torch.int64, device=dev)       # position of the token being decoded
+        self.seq_lens = torch.full((B,), ctx + 1, dtype=torch.int32, device=dev)
+        self.slot_mapping = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.input_ids = torch.randint(0, m.config.vocab_size, (B,), generator=g).to(dev)
+        self._refresh_slots()
+        cache, idx = model.get_seqlen_agnostic_capture_inputs(B)
+        idx.copy_(torch.arange(B, dtype=torch.int32, device=dev))
+        cache[0].copy_((torch.randn(cache[0].shape, device=dev, dtype=torch.float32) * 0.1).to(torch.bfloat16))
+        self.capture_inputs = (cache, idx)
+        self.max_k = ctx + total_steps + 1
+        self.md = MetaAttentionMetadata(
+            num_prefills=0, num_prefill_tokens=0, num_decode_tokens=B, slot_mapping=self.slot_mapping,
+            multi_modal_placeholder_index_maps=None, enable_kv_scales_calculation=False, seq_lens=None,
+            seq_lens_tensor=self.seq_lens, max_prefill_seq_len=0, max_decode_seq_len=self.max_k,
+            context_lens_tensor=None, block_tables=self.block_tables, use_cuda_graph=True, max_query_len=1,
+            max_decode_query_len=1, query_start_loc=torch.arange(B + 1, dtype=torch.int32, device=dev),
+            seq_start_loc=None)
+        self.graph = None
+        self.out = None
+
+    def _refresh_slots(self):
+        blk = torch.gather(self.block_tables.long(), 1, (self.positions // BLOCK).unsqueeze(1)).squeeze(1)
+        self.slot_mapping.copy_(blk * BLOCK + self.positions % BLOCK)
+
+    def advance(self):
+        """The next token's metadata, in place on the device (what the engine copies into its graph buffers)."""
+        self.positions += 1
+        self.seq_lens += 1
+        self._refresh_slots()
+
+    def eager_step(self):
+        return self.model(self.input_ids, self.positions, attn_metadata=self.md, kv_caches=self.kv,
+                          seqlen_agnostic_capture_inputs=self.capture_inputs)
+
+    def capture(self):
+        for _ in range(2):                       # sizes every workspace, loads every kernel
+            self.eager_step()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            self.eager_step()
+            with torch.cuda.graph(self.graph, stream=side):
+                self.out = self.eager_step()
+        torch.cuda.synchronize()
+
+    def step(self):
+        self.advance()
+        self.graph.replay()
+
+
+def timed_steps(runner, warmup, steps, dist=None):
+    for _ in range(warmup):
+        runner.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        runner.step()
+    e1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    return elapsed, e0.elapsed_time(e1) / steps
+
+
+# --------------------------------------------------------------------------- side measurements (N = 1)
+def graph_timed(fn, iters=10, reps=3):
+    """ms per call of ``fn``, replayed from a HIP graph of ``iters`` calls, so that kernels shorter than a Python
+    launch are timed on the GPU's clock."""
+    fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
         fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(iters):
+                fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps * iters)
 
-    t_gla, t_swa = timed(gla), timed(swa)
-    pos = torch.arange(L, dtype=torch.float64)
-    vis = torch.minimum(pos + 1, torch.tensor(float(WINDOW + 1), dtype=torch.float64)).sum().item()
-    return {
-        "prompt_tokens": L,
-        "gla_prefill_ms_per_layer": round(t_gla, 4),
-        "swa_prefill_ms_per_layer": round(t_swa, 4),
-        "attention_ttft_ms": round(N_GLA * t_gla + N_SWA * t_swa, 3),
-        "swa_prefill_tflops": round(4.0 * D * H * vis / (t_swa * 1e-3) / 1e12, 1),
-        "prefill_tokens_per_s": round(L / ((N_GLA * t_gla + N_SWA * t_swa) * 1e-3), 1),
-    }
+
+def kernel_table(runner, quant):
+    """Per-kernel time of the step's launches at the timed shape, each over the 14 / 28 layers' own operands in turn
+    (weights and caches cold, as inside the step), with the HBM rate of its algorithmic bytes."""
+    from vllm_hymeta import _C, hip_ops
+
+    m, B, dev = runner.model.model, runner.B, runner.dev
+    x = (torch.randn(B, HIDDEN, device=dev) * 0.5).to(torch.bfloat16)
+    xi = (torch.randn(B, INTER, device=dev) * 0.5).to(torch.bfloat16)
+    xa = (torch.randn(B, H * D, device=dev) * 0.5).to(torch.bfloat16)
+    layers = list(m.layers)
+    rows = {}
+
+    def add(name, fn, count, nbytes):
+        ms = graph_timed(fn, iters=1, reps=5) / count
+        rows[name] = {"us": round(ms * 1e3, 2), "gbs": round(nbytes / (ms * 1e-3) / 1e9, 1), "bytes": int(nbytes)}
+
+    wb = WBYTES[quant]
+    add("qkv_proj", lambda: [l.attn.qkv_proj(x) for l in layers], len(layers), (H + 2 * HKV) * D * HIDDEN * wb)
+    add("o_proj", lambda: [l.attn.o_proj(xa) for l in layers], len(layers), HIDDEN * H * D * wb)
+    add("gate_up_proj", lambda: [l.mlp.gate_up_proj(x) for l in layers], len(layers), 2 * INTER * HIDDEN * wb)
+    add("down_proj", lambda: [l.mlp.down_proj(xi) for l in layers], len(layers), HIDDEN * INTER * wb)
+    qkv = (torch.randn(B, (H + 2 * HKV) * D, device=dev)).to(torch.bfloat16)
+    q, k, v = qkv[:, : H * D].view(B, H, D), qkv[:, H * D:(H + HKV) * D].view(B, HKV, D), qkv[:, (H + HKV) * D:].view(B, HKV, D)
+    out = torch.empty(B, H, D, device=dev, dtype=torch.bfloat16)
+    keys = int(min(int(runner.seq_lens[0]), WINDOW + 1))
+    add("paged_decode (+KV write)", lambda: [hip_ops.meta_swa_paged_decode(
+        q, kv[0], kv[1], runner.seq_lens, runner.block_tables, window_left=WINDOW, max_seqlen_k=runner.max_k, out=out,
+        new_key=k, new_value=v, slot_mapping=runner.slot_mapping) for kv in runner.kv], len(runner.kv),
+        B * (2 * HKV * D * 2 * keys + H * D * 4))
+    (state,), idx = runner.capture_inputs
+    gk = torch.randn(B, HKV, D, device=dev).to(torch.bfloat16)
+    g_norm = torch.ones(D, dtype=torch.bfloat16, device=dev)
+    sh = state.shape[2]
+    add("gla_decode", lambda: [hip_ops.gla_decode(q, k, v, gk, state[i], idx, out=out, gate_mode=_C.GATE_7B,
+                                                  out_norm_weight=g_norm, out_norm_eps=1e-6) for i in range(state.shape[0])],
+        state.shape[0], B * (2 * sh * D * D * 2 + H * D * 4 + 3 * HKV * D * 2))
+    return rows
+
+
+class PrefillRunner:
+    """ONE prompt of ``L`` tokens through the whole model (time to first token), then single-sequence decode."""
+
+    def __init__(self, model, L, new_tokens, dev):
+        from vllm_hymeta.attention.meta_attention import MetaAttentionMetadata
+
+        self.model, self.L, self.dev = model, L, dev
+        m = model.model
+        nblk = (L + new_tokens + 1 + BLOCK - 1) // BLOCK
+        self.kv = [torch.zeros(2, nblk, BLOCK, m.shard.num_kv_heads, D, device=dev, dtype=torch.bfloat16) for _ in m.attn_layers]
+        g = torch.Generator(device="cpu")
+        g.manual_seed(3)
+        self.ids = torch.randint(0, m.config.vocab_size, (L,), generator=g).to(dev)
+        self.pos = torch.arange(L, dtype=torch.int64, device=dev)
+        cu = torch.tensor([0, L], dtype=torch.int32, device=dev)
+        self.md = MetaAttentionMetadata(
+            num_prefills=1, num_prefill_tokens=L, num_decode_tokens=0, slot_mapping=torch.arange(L, dtype=torch.int64, device=dev),
+            multi_modal_placeholder_index_maps=None, enable_kv_scales_calculation=False, seq_lens=[L],
+            seq_lens_tensor=torch.tensor([L], dtype=torch.int32, device=dev), max_prefill_seq_len=L, max_decode_seq_len=0,
+            context_lens_tensor=torch.zeros(1, dtype=torch.int32, device=dev),
+            block_tables=torch.zeros(1, 0, dtype=torch.int32, device=dev), use_cuda_graph=False, max_query_len=L,
+            max_decode_query_len=1, query_start_loc=cu, seq_start_loc=cu)
+        cache, idx = model.get_seqlen_agnostic_capture_inputs(1)
+        idx.zero_()
+        self.capture_inputs = (cache, idx)
+
+    def prefill(self):
+        return self.model(self.ids, self.pos, attn_metadata=self.md, kv_caches=self.kv,
+                          seqlen_agnostic_capture_inputs=self.capture_inputs)
+
+
+def prefill_and_latency(model, dev, L, new_tokens=128, runs=5):
+    """The reference's latency protocol (hf_7B_model/speed_7B.py:196-221, bench/speed_vllm.py:41-53): one request =
+    an L-token prompt + 128 generated tokens, batch 1.  TTFT = the prompt through all 28 layers (projections and MLP
+    included, library GEMMs at this row count), p50 of ``runs``; decode = 128 replays of the batch-1 step graph."""
+    pre = PrefillRunner(model, L, new_tokens, dev)
+    pre.prefill()
+    torch.cuda.synchronize()
+    ttft = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        pre.prefill()
+        torch.cuda.synchronize()
+        ttft.append((time.perf_counter() - t0) * 1e3)
+    ttft.sort()
+    dec = DecodeRunner(model, 1, L, new_tokens + 8, dev, seed=5)
+    dec.capture()
+    total = []
+    for _ in range(3):
+        dec.positions.fill_(L)
+        dec.seq_lens.fill_(L + 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pre.prefill()
+        for _ in range(new_tokens):
+            dec.step()
+        torch.cuda.synchronize()
+        total.append((time.perf_counter() - t0) * 1e3)
+    total.sort()
+    t_dec = (total[len(total) // 2] - ttft[len(ttft) // 2]) / new_tokens
+    return ({"prompt_tokens": L, "runs": runs, "ttft_ms_p50": round(ttft[len(ttft) // 2], 2), "ttft_ms_min": round(ttft[0], 2),
+             "ttft_ms_max": round(ttft[-1], 2), "prefill_tokens_per_s": round(L / (ttft[len(ttft) // 2] * 1e-3), 1)},
+            {"protocol": f"1 request: {L}-token prompt + {new_tokens} generated tokens, batch 1 (the reference's speed scripts)",
+             "latency_ms_p50": round(total[len(total) // 2], 2), "decode_ms_per_token": round(t_dec, 4),
+             "decode_tokens_per_s": round(1e3 / t_dec, 1),
+             "reference_published_ms": "2332 +- 19 (7B bf16, HF eager, unstated GPU; hf_7B_model/speed_7B.py:205-208)"})
 
 
 def shard70b_side_measurement(dev, B=64, ctx=32768, chunk=2048):
@@ -231,29 +405,8 @@ def shard70b_side_measurement(dev, B=64, ctx=32768, chunk=2048):
             gla(layer)
             attn(layer)
 
-    def timed(fn, iters=10):
-        """ms per call, replayed from a HIP graph of ``iters`` calls (as a serving loop replays its decode
-        step), so that kernels shorter than a Python launch are timed on the GPU's clock."""
-        fn()
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
-                for _ in range(iters):
-                    fn()
-        graph.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            graph.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / (3 * iters)
-
-    t_step = timed(step, 5)
-    t_win, t_full, t_gla = timed(lambda: attn(0)), timed(lambda: attn(3)), timed(lambda: gla(1))
+    t_step = graph_timed(step, 5)
+    t_win, t_full, t_gla = graph_timed(lambda: attn(0)), graph_timed(lambda: attn(3)), graph_timed(lambda: gla(1))
     # algorithmic bytes of the step: states read + written, visible K/V rows (+ meta) per layer kind
     b_gla = B * (2 * Hs * D * D * 2)
     b_win = B * 2 * Ks * D * 2 * (W + M)
@@ -279,7 +432,7 @@ def shard70b_side_measurement(dev, B=64, ctx=32768, chunk=2048):
         hip_ops.gla_prefill_varlen(cq, ck, ck, None, cstate, slot_idx[:1], cuq, chunk, context_lens=ctx_len, meta_state=mstate,
                                    out=cout, gate_mode=_C.GATE_70B_LOWER_BOUND, lower_bound=lb)
 
-    t_cw, t_cf, t_cg = timed(lambda: chunk_attn(W - 1)), timed(lambda: chunk_attn(-1)), timed(chunk_gla)
+    t_cw, t_cf, t_cg = graph_timed(lambda: chunk_attn(W - 1)), graph_timed(lambda: chunk_attn(-1)), graph_timed(chunk_gla)
     return {
         "shape": f"TP=4 rank: {Hs} q-heads, {Ks} kv-head, {M} meta tokens, ctx {ctx}, {B} sequences, block_size {BLOCK}",
         "decode_ms_per_step": round(t_step, 4),
@@ -295,112 +448,12 @@ def shard70b_side_measurement(dev, B=64, ctx=32768, chunk=2048):
     }
 
 
-def model_decode_side_measurement(dev, w, B, s, quant):
-    """One decode token for every sequence through the WHOLE 28-layer stack (random-init Hymeta-7B
-    geometry): block norms, qkv / gate / output projections and the gated MLP around the same
-    attention kernels, caches and metadata as the timed hot path.  ``quant`` = "bf16" (library GEMMs),
-    "w8a8" (int8 weights, per-token int8 activations, the int8-MFMA GEMM) or "gptq4" (GPTQ 4-bit, group 128,
-    the fused dequant-GEMM).  Replayed from one HIP graph, as the
-    serving engine replays its decode step.  Outside the timed region; reported beside the value."""
-    from vllm_hymeta import _C, hip_ops
-    from vllm_hymeta.linear import HymetaLinear
-    from vllm_hymeta.model_for_7B.window_attention import rope_cos_sin_cache
-
-    hidden, inter, group = 3584, 18944, 128
-    g = torch.Generator(device="cpu")
-    g.manual_seed(2)
-
-    def linear(out_f, in_f, bias=False):
-        b = torch.zeros(out_f, dtype=torch.bfloat16, device=dev) if bias else None
-        if quant == "bf16":
-            wt = (torch.randn(out_f, in_f, device=dev, dtype=torch.float32) * in_f ** -0.5).to(torch.bfloat16)
-            return HymetaLinear.from_weight(wt, b)
-        if quant == "w8a8":   # int8 per-channel weights, dynamic per-token int8 activations (hf_model/quant_w8a8.py:121-124)
-            qw8 = torch.randint(-127, 128, (out_f, in_f), dtype=torch.int8, device=dev)
-            ws = (torch.rand(out_f, device=dev) * (2.0 / 127) * in_f ** -0.5).float()
-            return HymetaLinear.from_w8a8(qw8, ws, bias=b)
-        qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // 8, out_f), dtype=torch.int32, device=dev)
-        qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // group, out_f // 8), dtype=torch.int32, device=dev)
-        sc = (torch.rand(in_f // group, out_f, device=dev) * (0.25 * in_f ** -0.5)).to(torch.float16)
-        return HymetaLinear.from_gptq(qw, qz, sc, 4, group, bias=b)
-
-    qkv_n = (H + 2 * HKV) * D
-    layers = []
-    for li in range(N_GLA + N_SWA):
-        lay = {"gla": li % 2 == 0, "qkv": linear(qkv_n, hidden, True), "o": linear(hidden, H * D),
-               "gate_up": linear(2 * inter, hidden), "down": linear(hidden, inter),
-               "n1": torch.ones(hidden, dtype=torch.bfloat16, device=dev),
-               "n2": torch.ones(hidden, dtype=torch.bfloat16, device=dev)}
-        if lay["gla"]:   # the rank-16 gate projection stays bf16 (hf_7B_model/gla_swa_gptq.py:18-24)
-            lay["gk0"] = (torch.randn(16, hidden, device=dev) * hidden ** -0.5).to(torch.bfloat16)
-            lay["gk1"] = (torch.randn(HKV * D, 16, device=dev) * 0.25).to(torch.bfloat16)
-            lay["gk1_b"] = torch.zeros(HKV * D, dtype=torch.bfloat16, device=dev)
-        layers.append(lay)
-    rope = rope_cos_sin_cache(D, 65536, 1e6, device=dev)
-    positions = w["seq_lens"][s].to(torch.int64) - 1
-    x0 = (torch.randn(B, hidden, generator=g) * 0.5).to(torch.bfloat16).to(dev)
-
-    def step():
-        # the residual stream travels beside the blocks' outputs, as in the model classes: the sum
-        # happens inside the next block's fused add + norm
-        x, res = x0, None
-        i_gla = i_swa = 0
-        for lay in layers:
-            if res is None:
-                res = x.clone()
-                h = hip_ops.add_rmsnorm(x, lay["n1"], 1e-6)
-            else:
-                h = hip_ops.add_rmsnorm(x, lay["n1"], 1e-6, residual=res)
-            qkv = lay["qkv"](h)
-            q, k, v = split_qkv(qkv, B)
-            if lay["gla"]:
-                gk = hip_ops.lowrank_gate(h, lay["gk0"], lay["gk1"], lay["gk1_b"])
-                att = hip_ops.gla_decode(q, k, v, gk.view(B, HKV, D), w["state"][i_gla], w["slot_idx"],
-                                         gate_mode=_C.GATE_7B, out_norm_weight=w["g_norm"], out_norm_eps=1e-6)
-                i_gla += 1
-            else:
-                hip_ops.rope_neox_(positions, q, k, rope)
-                kv = w["kv"][i_swa]
-                att = hip_ops.meta_swa_paged_decode(q, kv[0], kv[1], w["seq_lens"][s], w["block_tables"],
-                                                    window_left=WINDOW, max_seqlen_k=w["max_seqlen_k"],
-                                                    num_splits=w["splits"], new_key=k, new_value=v,
-                                                    slot_mapping=w["slot_mapping"][s])
-                i_swa += 1
-            a_out = lay["o"](att.view(B, H * D))
-            n2 = hip_ops.add_rmsnorm(a_out, lay["n2"], 1e-6, residual=res)
-            x = lay["down"](hip_ops.silu_and_mul(lay["gate_up"](n2)))
-        return hip_ops.add_rmsnorm(x, layers[0]["n1"], 1e-6, residual=res)     # the model's final norm
-
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.stream(side):
-        step()
-        with torch.cuda.graph(graph, stream=side):
-            step()
-    torch.cuda.synchronize()
-    graph.replay()
-    torch.cuda.synchronize()
-    iters = 5
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        graph.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    wbytes = (N_GLA + N_SWA) * (qkv_n * hidden + hidden * H * D + 3 * inter * hidden) * {"bf16": 2.0, "w8a8": 1.0, "gptq4": 0.5}[quant]
-    return {"ms_per_step": round(ms, 4), "tokens_per_s": round(B / (ms * 1e-3), 1),
-            "linear_weight_bytes": int(wbytes), "layers": N_GLA + N_SWA, "sequences": B}
-
-
 def cpu_baseline(args):
-    """The CPU restatement (oracle/) of the same step on the host cores, on a bounded sample:
-    a 2-sequence batch, full 28-layer hot path, context 8192."""
+    """The CPU restatement (oracle/) of the same decode step on the host cores, on a bounded sample: 2 sequences at
+    the timed context through ONE GLA layer and ONE sliding-window layer of the published geometry (block norms,
+    projections, attention, gated MLP; 2 of the 28 layers), scaled to 28 layers."""
     from oracle import gla_decode_step_ref, meta_swa_paged_decode_ref, reshape_and_cache_ref
-    from oracle.layers import gate_7b_ref, rms_norm_ref
+    from oracle.layers import _linear, add_rms_norm_ref, gate_7b_ref, rms_norm_ref, rope_cos_sin_cache_ref, rope_neox_ref
 
     Bc, ctx = 2, args.ctx
     torch.manual_seed(0)
@@ -409,20 +462,41 @@ def cpu_baseline(args):
     vc = torch.randn(Bc * nb, BLOCK, HKV, D).to(torch.bfloat16)
     bt = torch.arange(Bc * nb, dtype=torch.int32).view(Bc, nb)
     state = (torch.randn(Bc, H, D, D) * 0.1).to(torch.bfloat16)
-    q = torch.randn(Bc, H, D).to(torch.bfloat16)
-    k, v, gk = (torch.randn(Bc, HKV, D).to(torch.bfloat16) for _ in range(3))
-    w = torch.ones(D, dtype=torch.bfloat16)
     slot = torch.arange(Bc, dtype=torch.int32)
+    rb = lambda *s, sc=1.0: (torch.randn(*s) * sc).to(torch.bfloat16)
+    qkv_n = (H + 2 * HKV) * D
+    lay = [dict(qkv=rb(qkv_n, HIDDEN, sc=HIDDEN ** -0.5), qkv_b=rb(qkv_n, sc=0.02), o=rb(HIDDEN, H * D, sc=HIDDEN ** -0.5),
+                gate_up=rb(2 * INTER, HIDDEN, sc=HIDDEN ** -0.5), down=rb(HIDDEN, INTER, sc=INTER ** -0.5)) for _ in range(2)]
+    gk0, gk1, gk1_b = rb(16, HIDDEN, sc=HIDDEN ** -0.5), rb(HKV * D, 16, sc=0.25), rb(HKV * D, sc=0.02)
+    ones_h, ones_d = torch.ones(HIDDEN, dtype=torch.bfloat16), torch.ones(D, dtype=torch.bfloat16)
+    table = rope_cos_sin_cache_ref(D, ctx + 64, 1e6)
+    x0 = rb(Bc, HIDDEN, sc=0.5)
+
+    def mlp(p, n):
+        gu = _linear(n, p["gate_up"])
+        return _linear((torch.nn.functional.silu(gu[:, :INTER].float()) * gu[:, INTER:].float()).to(torch.bfloat16), p["down"])
 
     def step(s):
-        for _ in range(N_GLA):
-            qg, kg, gg = gate_7b_ref(q, k, gk)
-            rms_norm_ref(gla_decode_step_ref(qg, kg, v, gg, state, slot), w)
-        pos = ctx + s
+        x, pos = x0, ctx + s
+        # GLA layer
+        h, _ = add_rms_norm_ref(x, None, ones_h)
+        qkv = _linear(h, lay[0]["qkv"], lay[0]["qkv_b"])
+        q, k, v = qkv[:, : H * D].view(Bc, H, D), qkv[:, H * D:(H + HKV) * D].view(Bc, HKV, D), qkv[:, (H + HKV) * D:].view(Bc, HKV, D)
+        gk = _linear(_linear(h, gk0), gk1, gk1_b).view(Bc, HKV, D)
+        qg, kg, gg = gate_7b_ref(q, k, gk)
+        att = rms_norm_ref(gla_decode_step_ref(qg, kg, v, gg, state, slot), ones_d)
+        n, r = add_rms_norm_ref(_linear(att.reshape(Bc, H * D).to(torch.bfloat16), lay[0]["o"]), x, ones_h)
+        x = (r.float() + mlp(lay[0], n).float()).to(torch.bfloat16)
+        # sliding-window layer
+        h, _ = add_rms_norm_ref(x, None, ones_h)
+        qkv = _linear(h, lay[1]["qkv"], lay[1]["qkv_b"])
+        q, k, v = qkv[:, : H * D].view(Bc, H, D), qkv[:, H * D:(H + HKV) * D].view(Bc, HKV, D), qkv[:, (H + HKV) * D:].view(Bc, HKV, D)
+        q, k = rope_neox_ref(torch.full((Bc,), pos), q, k, table)
         slots = bt[:, pos // BLOCK].long() * BLOCK + pos % BLOCK
-        for _ in range(N_SWA):
-            reshape_and_cache_ref(k, v, kc, vc, slots)
-            meta_swa_paged_decode_ref(q, kc, vc, [pos + 1] * Bc, bt, None, None, WINDOW)
+        reshape_and_cache_ref(k, v, kc, vc, slots)
+        att = meta_swa_paged_decode_ref(q, kc, vc, [pos + 1] * Bc, bt, None, None, WINDOW)
+        n, r = add_rms_norm_ref(_linear(att.reshape(Bc, H * D).to(torch.bfloat16), lay[1]["o"]), x, ones_h)
+        return (r.float() + mlp(lay[1], n).float()).to(torch.bfloat16)
 
     step(0)  # warm-up
     n, t0 = 0, time.perf_counter()
@@ -430,79 +504,56 @@ def cpu_baseline(args):
         step(1 + n)
         n += 1
         el = time.perf_counter() - t0
-        if el > 10.0 or n >= 6:
+        if el > 10.0 or n >= 8:
             break
-    return {"value": round(Bc * n / el, 3), "unit": "tokens/s", "cores": torch.get_num_threads(),
+    per_step_28 = el / n * (N_LAYERS / 2)
+    return {"value": round(Bc / per_step_28, 3), "unit": "tokens/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"oracle/ (torch CPU, {torch.get_num_threads()} threads) on {Bc} sequences x {n} decode "
-                      f"steps of the same 28-layer hot path at ctx {ctx}"}
+            "sample": f"oracle/ (torch CPU, {torch.get_num_threads()} threads): {Bc} sequences x {n} decode steps at ctx {ctx} through "
+                      "one GLA layer + one sliding-window layer of the published geometry (norms, projections, attention, MLP), "
+                      "time scaled from 2 to 28 layers"}
+
+
+# --------------------------------------------------------------------------- main (N = 1)
+def read_traffic(B, ctx):
+    tpath = os.path.join(ROOT, "profiles", "traffic_model_decode.json")
+    if os.path.exists(tpath):
+        try:
+            rec = json.load(open(tpath))
+            if rec.get("batch") == B and rec.get("ctx") == ctx:
+                return rec.get("hbm_bytes_per_step")
+        except Exception:
+            pass
+    return None
 
 
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        from bench_tp import tp_main      # tensor-parallel mode: its own file, imported before any GPU call
+        return tp_main(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP kernels are the product path; there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from vllm_hymeta import hip_ops  # noqa: F401  (fails loudly if the HIP library is missing)
 
-    B = args.batch
-    total = args.warmup + args.steps
-    w = build_workload(args, dev, total)
-    torch.cuda.synchronize()
+    B, total = args.batch, args.warmup + args.steps
+    model = build_model_7b(dev, args.quant, max_num_seqs=B, gla_state=args.gla_state)
+    runner = DecodeRunner(model, B, args.ctx, total + 8, dev)
+    runner.capture()
+    elapsed, gpu_ms = timed_steps(runner, args.warmup, args.steps)
 
-    for s in range(args.warmup):
-        run_step(w, s, B)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    events = []
-    t0 = time.perf_counter()
-    for s in range(args.warmup, total):
-        run_step(w, s, B, events)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # dominant kernel: the paged sliding-window decode (split-KV kernel; + its merge when split)
-    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(len(events), 1)
+    state_heads = HKV if args.gla_state == "kv_head" else H
+    step_bytes = linear_weight_bytes(args.quant) + attention_bytes(B, args.ctx, state_heads=state_heads)
+    achieved = step_bytes / (gpu_ms * 1e-3) / 1e9
     keys = min(args.ctx + 1, WINDOW + 1)
-    alg_bytes = B * (2 * HKV * D * 2 * keys + H * D * 4)   # K and V rows + q and o, per launch
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_paged_decode.json")
-    if os.path.exists(tpath):
-        try:
-            rec = json.load(open(tpath))
-            if rec.get("batch") == B and rec.get("ctx") == args.ctx:
-                traffic = rec.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-    tokens = world * B * args.steps
     line = {
-        "metric": "decode output tokens/s (attention hot path)",
-        "value": round(tokens / elapsed, 1),
+        "metric": "decode output tokens/s (whole model step)",
+        "value": round(B * args.steps / elapsed, 1),
         "unit": "tokens/s",
-        "n_gpus": world,
+        "n_gpus": 1,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -512,57 +563,55 @@ def main():
         "dtype": "bf16",
         "data": "synthetic",
         "config": {
-            "workload": f"Hymeta-7B bf16 TP=1 decode, ctx {args.ctx}, block_size {BLOCK}, {B} sequences/GPU; "
-                        "step = 14 x GLA decode (fused gate + g_norm) + 14 x (paged KV write + "
-                        f"sliding-window paged decode over {keys} keys, one fused launch); projections/MLP not in the hot path",
+            "workload": f"Hymeta-7B {args.quant} TP=1 decode, ctx {args.ctx}, block_size {BLOCK}, {B} sequences; step = one token per "
+                        "sequence through all 28 layers of GLAswaForCausalLM (embedding, norms, qkv/o/gate_up/down projections, 14 x GLA "
+                        f"decode, 14 x paged sliding-window decode over {keys} keys with fused KV write, final norm), one HIP graph per "
+                        "step; LM head and sampler (the engine's) not run",
             "batch_per_gpu": B,
             "ctx": args.ctx,
-            "parallelism": "replicas" if world > 1 else "single GPU",
+            "linears": args.quant,
+            "parallelism": "single GPU",
+            "gla_state": ("one state per kv-head, shared by its 7 query heads (identical in the reference)"
+                          if args.gla_state == "kv_head" else "one state per query head (the reference's cache shape)"),
         },
         "roofline": {
-            "kernel": "paged_decode_split_kernel" + (" (+ paged_decode_merge_kernel)" if w["splits"] > 1 else ""),
+            "kernel": "whole decode step (one graph launch): linear weights + visible K/V rows + GLA states",
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "avg_launch_ms": round(kern_ms, 5),
+            "traffic": read_traffic(B, args.ctx),
+            "algorithmic_bytes_per_launch": int(step_bytes),
+            "linear_weight_bytes": linear_weight_bytes(args.quant),
+            "attention_bytes": int(attention_bytes(B, args.ctx, state_heads=state_heads)),
+            "avg_launch_ms": round(gpu_ms, 5),
         },
     }
-    line["config"]["gla_state"] = ("one state per kv-head, shared by its 7 query heads (identical in the reference)"
-                                   if args.gla_state == "kv_head" else "one state per query head (the reference's cache shape)")
-    if world == 1 and not args.no_model:
-        # the same step with the other state layout, outside the timed region
-        other = H if args.gla_state == "kv_head" else HKV
-        kept, w["state"] = w["state"], gla_states(B, other, dev)
-        for s in range(args.warmup):
-            run_step(w, s, B)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for s in range(args.warmup, total):
-            run_step(w, s, B)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        w["state"] = kept
-        line["other_gla_state_layout"] = {"gla_state": "per query head" if other == H else "per kv-head",
-                                          "ms_per_step": round(el / args.steps * 1e3, 4),
-                                          "tokens_per_s": round(B * args.steps / el, 1)}
+    if not args.no_side:
+        line["kernels"] = kernel_table(runner, args.quant)
+        if not args.no_prefill:
+            line["prefill"], line["latency_b1"] = prefill_and_latency(model, dev, args.prefill_ctx)
+            line["ttft_ms_p50"] = line["prefill"]["ttft_ms_p50"]
+        del runner, model
         torch.cuda.empty_cache()
-    if world == 1 and not args.no_prefill:
-        line["prefill"] = prefill_side_measurement(dev, args.prefill_ctx)
-    if world == 1 and not args.no_model:
-        line["model_decode"] = {q: model_decode_side_measurement(dev, w, B, total - 1, q) for q in ("bf16", "w8a8", "gptq4")}
-    if world == 1 and not args.no_model:
-        del w
-        torch.cuda.empty_cache()
+        line["model_decode"] = {args.quant: {"ms_per_step": line["ms_per_step"], "tokens_per_s": line["value"]}}
+        for q in ("bf16", "gptq4", "w8a8"):
+            if q == args.quant:
+                continue
+            mq = build_model_7b(dev, q, max_num_seqs=B, gla_state=args.gla_state)
+            rq = DecodeRunner(mq, B, args.ctx, total + 8, dev)
+            rq.capture()
+            el, ms = timed_steps(rq, args.warmup, args.steps)
+            sb = linear_weight_bytes(q) + attention_bytes(B, args.ctx, state_heads=state_heads)
+            line["model_decode"][q] = {"ms_per_step": round(ms, 4), "tokens_per_s": round(B / (ms * 1e-3), 1),
+                                       "hbm_frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernels": kernel_table(rq, q)}
+            del rq, mq
+            torch.cuda.empty_cache()
         line["shard_70b_tp4"] = shard70b_side_measurement(dev)
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
