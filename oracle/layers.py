@@ -200,7 +200,7 @@ def hybrid_layer_70b_ref(x: torch.Tensor, meta_x: torch.Tensor, positions: torch
                          num_heads: int, num_kv_heads: int, sliding_window: Optional[int],
                          lower_bound: Optional[torch.Tensor], first_layer: bool,
                          rope_theta: float = 1e6, max_position: int = 131072,
-                         norm_eps: float = 1e-6, return_meta: bool = False) -> torch.Tensor:
+                         norm_eps: float = 1e-6, return_meta: bool = False, linears: Optional[dict] = None) -> torch.Tensor:
     """One 70B intra-hybrid attention block on ONE sequence, prefill form, with the meta tokens
     already "cached": the softmax branch sees the roped K/V of ``meta_x`` (positions 0..M-1) as
     always-visible keys and ropes the real tokens at ``positions + M``; the GLA branch starts from
@@ -212,17 +212,27 @@ def hybrid_layer_70b_ref(x: torch.Tensor, meta_x: torch.Tensor, positions: torch
     ``norm1.weight``, ``norm2.weight`` (fp32), ``out_proj.weight``.  ``sliding_window`` = W keys
     including the query (None: full attention).  Returns ``[T, hidden]`` bf16; with ``return_meta``
     ``[M + T, hidden]``, the meta tokens' own rows first (their queries see every meta key and no
-    real key; their GLA output is the pass from the zero state)."""
+    real key; their GLA output is the pass from the zero state).
+
+    ``linears``: quantised projections.  Callables ``{"vanilla_attn.qkv", "linear_attn.qkv", "out_proj"}`` taking the
+    bf16 input rows and returning the projection (fused q | k | v columns for the two qkv entries) replace the bf16
+    weights of ``p`` (which then only needs the norm weights); each stands for the restated arithmetic of a GPTQ or
+    W8A8 linear (``oracle/quant.py``)."""
     from .gla import gla_recurrent_ref
     from .meta_swa import meta_swa_dense_ref
 
     T, M = x.shape[0], meta_x.shape[0]
-    D = p["vanilla_attn.q_proj.weight"].shape[0] // num_heads
+    D = p["norm1.weight"].shape[0] // num_heads
     rep = num_heads // num_kv_heads
     cache = rope_cos_sin_cache_ref(D, max_position, rope_theta)
 
     def qkv(prefix, h):
         n = h.shape[0]
+        if linears is not None:
+            y = linears[f"{prefix}.qkv"](h).to(h.dtype)
+            return (y[:, : num_heads * D].reshape(n, num_heads, D),
+                    y[:, num_heads * D:(num_heads + num_kv_heads) * D].reshape(n, num_kv_heads, D),
+                    y[:, (num_heads + num_kv_heads) * D:].reshape(n, num_kv_heads, D))
         return (_linear(h, p[f"{prefix}.q_proj.weight"], p[f"{prefix}.q_proj.bias"]).view(n, num_heads, D),
                 _linear(h, p[f"{prefix}.k_proj.weight"], p[f"{prefix}.k_proj.bias"]).view(n, num_kv_heads, D),
                 _linear(h, p[f"{prefix}.v_proj.weight"], p[f"{prefix}.v_proj.bias"]).view(n, num_kv_heads, D))
@@ -248,6 +258,8 @@ def hybrid_layer_70b_ref(x: torch.Tensor, meta_x: torch.Tensor, positions: torch
         o_lin = torch.cat([o_meta, o_lin])
     o_lin = o_lin.to(x.dtype).reshape(-1, num_heads * D)
     y = hybrid_combine_ref(o_attn, o_lin, p["norm1.weight"], p["norm2.weight"], norm_eps)
+    if linears is not None:
+        return linears["out_proj"](y).to(x.dtype)
     return _linear(y, p["out_proj.weight"])
 
 

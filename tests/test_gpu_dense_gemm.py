@@ -18,6 +18,12 @@ pytestmark = pytest.mark.gpu
     (33, 18944, 3584, False, 0),       # 7B down projection: few column tiles, deep K
     (64, 3584, 1024, True, 5),
     (64, 1024, 4096, True, 1),
+    # the weight-streaming kernel (library's choice, K a multiple of 256): whole tiles, K slices + the reduce launch
+    (64, 3584, 4608, True, 0),         # 7B qkv at the bench batch: 128-column tiles, K slices
+    (48, 3584, 37888, False, 0),       # 7B gate_up: 148 whole tiles of 256 columns, rows past M masked
+    (64, 18944, 3584, True, 0),        # 7B down projection: deep K in slices
+    (5, 512, 320, True, 0),            # 64-column tiles (N not a multiple of 128), two chunks
+    (20, 256, 64, False, 0),           # one tile, one chunk
 ])
 def test_bf16_gemm(M, K, N, bias, split_k):
     from vllm_hymeta import hip_ops
@@ -57,9 +63,9 @@ def test_bf16_gemm_strided_views_and_linear_dispatch():
 
     small, big = randn_bf16(g_, 64, 512).cuda(), randn_bf16(g_, 65, 512).cuda()
     assert hip_ops.bf16_gemm_supported(small, w) and not hip_ops.bf16_gemm_supported(big, w)
-    assert not hip_ops.bf16_gemm_preferred(small, w), "a wide linear stays with the library"
     deep = randn_bf16(g_, 128, 512, scale=512 ** -0.5).cuda()          # K = 4 N
-    assert hip_ops.bf16_gemm_preferred(small, deep)
+    assert hip_ops.bf16_gemm_preferred(small, w) and hip_ops.bf16_gemm_preferred(small, deep), "every decode-sized linear runs on the kernel"
+    assert not hip_ops.bf16_gemm_preferred(big, w)
     for wt, bias in ((w, b), (deep, None)):
         lin = HymetaLinear.from_weight(wt, bias)
         for xin in (small, big):

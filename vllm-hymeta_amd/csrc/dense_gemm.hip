@@ -12,6 +12,7 @@
 // meet in LDS, and the K slices of one 64-column tile meet in fp32 slabs: the last slice to
 // arrive sums them in slice order (deterministic), adds the bias and writes bf16.
 #include "common.h"
+#include "stream_gemm.h"
 
 namespace hymeta {
 namespace {
@@ -152,9 +153,11 @@ extern "C" int hymeta_bf16_gemm_split_k(int32_t M, int32_t K, int32_t N) {
 extern "C" size_t hymeta_bf16_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
   if (M <= 0 || N <= 0) return 0;
   const size_t counters = kTicketBytes;   // zero at first use, left zero by every call
-  if (split_k <= 0) {   // a bound for whatever the library chooses: tiles x slices <= 256 + tiles
+  if (split_k <= 0) {   // a bound for whatever the library chooses: tiles x slices <= 256 + tiles, or the streaming kernel's slabs
     const size_t tiles = N / kCols > 0 ? N / kCols : 1;
-    return counters + (256 + tiles) * kCols * static_cast<size_t>(M) * sizeof(float);
+    const size_t old_bound = counters + (256 + tiles) * kCols * static_cast<size_t>(M) * sizeof(float);
+    const size_t stream_bound = counters + stream_gemm_workspace_bound(M, N);
+    return old_bound > stream_bound ? old_bound : stream_bound;
   }
   if (split_k == 1) return 0;
   return counters + static_cast<size_t>(split_k) * M * N * sizeof(float);
@@ -171,6 +174,22 @@ extern "C" int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream
   if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.weight) | reinterpret_cast<uintptr_t>(a.out) |
        reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.workspace)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
+  // the streaming kernel (activations shared through LDS, work dealt in equal ranges over the whole chip) takes every
+  // shape it covers when the library chooses the decomposition
+  if (a.split_k <= 0) {
+    StreamPlan plan;
+    const bool have_ws = a.workspace != nullptr;
+    if (stream_gemm_plan(a.M, a.K * 2, a.N, have_ws, &plan) &&
+        (!have_ws || a.workspace_bytes >= kTicketBytes + stream_gemm_workspace_bytes(a.M, a.N, plan))) {
+      StreamArgs sa = {};
+      sa.x = static_cast<const char*>(a.x), sa.w = static_cast<const char*>(a.weight);
+      sa.bias = static_cast<const uint16_t*>(a.bias), sa.out = static_cast<uint16_t*>(a.out);
+      sa.slabs = have_ws ? static_cast<char*>(a.workspace) + kTicketBytes : nullptr;
+      sa.M = a.M, sa.N = a.N;
+      sa.x_stride_bytes = a.x_stride_m * 2, sa.w_stride_bytes = a.w_stride_n * 2, sa.out_stride = a.out_stride_m;
+      return stream_gemm_launch<false>(sa, plan, begin_launches(stream));
+    }
+  }
   const int ksteps = a.K / 32;
   int splits = a.split_k > 0 ? a.split_k : (a.workspace != nullptr ? hymeta_bf16_gemm_split_k(a.M, a.K, a.N) : 1);
   if (splits > ksteps) splits = ksteps;

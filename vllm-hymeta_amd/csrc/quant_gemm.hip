@@ -19,7 +19,10 @@
 // where sum_k x comes from one extra MFMA against an all-ones B fragment.
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "common.h"
+#include "stream_gemm.h"
 
 namespace hymeta {
 namespace {
@@ -1050,7 +1053,13 @@ extern "C" int hymeta_w8a8_gemm_split_k(int32_t M, int32_t K, int32_t N) {
 }
 
 extern "C" size_t hymeta_w8a8_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
-  if (M <= 0 || N <= 0 || split_k <= 1) return 0;
+  if (M <= 0 || N <= 0) return 0;
+  if (split_k <= 0) {   // a bound for whatever the library chooses (the streaming kernel's slabs, or the older kernel's)
+    const size_t stream_bound = kTicketBytes + stream_gemm_workspace_bound(M, N);
+    const size_t old_bound = kTicketBytes + static_cast<size_t>(16) * M * N * sizeof(int);
+    return stream_bound > old_bound ? stream_bound : old_bound;
+  }
+  if (split_k <= 1) return 0;
   // [ticket counters: zero at first use, left zero by every call][int32 slabs [split_k][M][N]]
   return kTicketBytes + static_cast<size_t>(split_k) * M * N * sizeof(int);
 }
@@ -1067,6 +1076,27 @@ extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream
        reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.xq) | reinterpret_cast<uintptr_t>(a.w_scale) |
        reinterpret_cast<uintptr_t>(a.workspace)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
+  // 17 rows and more: the streaming kernel (activations shared through LDS, whole-line weight loads) when the library
+  // chooses the decomposition; up to 16 rows the 64-column kernel below already streams the weights at 4.5-4.8 TB/s
+  static const int stream_from = [] { const char* e = getenv("HYMETA_W8A8_STREAM_FROM"); return e ? atoi(e) : 17; }();
+  if (a.split_k <= 0 && a.M >= stream_from) {
+    StreamPlan plan;
+    const bool have_ws = a.workspace != nullptr;
+    if (stream_gemm_plan(a.M, a.K, a.N, have_ws, &plan) &&
+        (!have_ws || a.workspace_bytes >= kTicketBytes + stream_gemm_workspace_bytes(a.M, a.N, plan))) {
+      hipStream_t s = begin_launches(stream);
+      hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
+      if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+      StreamArgs sa = {};
+      sa.x = reinterpret_cast<const char*>(a.xq), sa.w = reinterpret_cast<const char*>(a.qweight);
+      sa.bias = static_cast<const uint16_t*>(a.bias), sa.out = static_cast<uint16_t*>(a.out);
+      sa.x_scale = a.x_scale, sa.w_scale = a.w_scale;
+      sa.slabs = have_ws ? static_cast<char*>(a.workspace) + kTicketBytes : nullptr;
+      sa.M = a.M, sa.N = a.N;
+      sa.x_stride_bytes = a.K, sa.w_stride_bytes = a.K, sa.out_stride = a.out_stride_m;
+      return stream_gemm_launch<true>(sa, plan, s);
+    }
+  }
   const int ksteps = a.K / 64;
   int splits = a.split_k > 0 ? a.split_k : (a.workspace != nullptr ? hymeta_w8a8_gemm_split_k(a.M, a.K, a.N) : 1);
   if (splits > ksteps) splits = ksteps;

@@ -1,0 +1,38 @@
+// Host-side interface of the weight-streaming GEMM (stream_gemm.hip), shared by the bf16 and W8A8 entry points.
+#pragma once
+
+#include "common.h"
+
+namespace hymeta {
+
+struct StreamArgs {
+  const char* x;          // [M, K] row-major, x_stride_bytes per row (bf16, or int8 for W8A8)
+  const char* w;          // [N, K] row-major, w_stride_bytes per row
+  const uint16_t* bias;   // bf16 [N] or null
+  uint16_t* out;          // bf16 [M, N]
+  const float* x_scale;   // W8A8: fp32 [M]
+  const float* w_scale;   // W8A8: fp32 [N]
+  char* slabs;            // [splits][M][N] 4-byte partial sums (splits > 1)
+  int M, N;
+  int64_t x_stride_bytes, w_stride_bytes, out_stride;
+  int tiles, chunks, splits;    // filled from the plan
+};
+
+struct StreamPlan {
+  int nf;        // 16-column fragments per wave: a workgroup's tile is 64 nf columns
+  int tiles, chunks;   // chunks: 512-byte pieces of a weight row
+  int splits;          // K slices per tile (1: the workgroup writes the tile itself)
+  int ring;      // pairs of k-steps each wave keeps in flight (2 or 4)
+};
+
+// Whether the streaming kernel takes the shape (M <= 64 rows, K a multiple of 512 bytes, N of 64 columns), and how
+// it is cut.  Without a workspace every workgroup owns whole tiles (no slabs).
+bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* plan);
+// Slab bytes of that plan (0 without K slices); no ticket counters are used.
+size_t stream_gemm_workspace_bytes(int M, int N, const StreamPlan& plan);
+// A bound on stream_gemm_workspace_bytes over every plan the library may choose for (M, N).
+size_t stream_gemm_workspace_bound(int M, int N);
+template <bool I8>
+int stream_gemm_launch(StreamArgs args, const StreamPlan& plan, hipStream_t stream);
+
+}  // namespace hymeta

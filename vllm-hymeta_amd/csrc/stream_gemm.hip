@@ -1,0 +1,326 @@
+// Weight-streaming GEMM for decode-sized batches (up to 64 rows): out = x W^T (+ bias), W [N, K] K-contiguous
+// as torch stores a Linear weight (bf16), or int8 with per-channel scales against int8 activations (W8A8).
+//
+// At these row counts the weights are the traffic and every weight is used once: the kernel is a stream of W
+// from HBM through the matrix cores, and everything else is arranged so that nothing competes with that stream.
+//   * W is read in whole 128-byte lines: one load instruction covers 8 weight rows x 128 bytes (lane = row l / 8,
+//     16-byte piece l % 8).  A compute unit keeps about 64 line requests in flight whatever their size, and a
+//     load in MFMA fragment shape (16 rows x 64 bytes, a lane's neighbours in other rows) asks for half lines:
+//     measured on the 7B gate_up matrix, the bare stream runs at 5.3-6.1 TB/s in whole lines against 3.3-4.3 in
+//     fragment shape (tools/membw2.hip).  The lines pass through a wave-private LDS image (ds_write_b128 as
+//     loaded, ds_read_b128 as B fragments; pieces XOR-ed with the row so that both are conflict free); each wave
+//     keeps a ring of R pairs of k-steps in flight in registers, issued unconditionally so that the compiler can
+//     count them (a pair past the end re-reads the last one).
+//   * The activations are shared: a workgroup of 4 waves owns 64 rows x (4 x 16 NF) columns, every wave the
+//     same k range and its own columns.  x is staged through LDS in full 128-byte lines, 256 k-values (one
+//     "chunk" = 8 k-steps) of all rows per buffer, two buffers, one barrier per chunk; fragment-shaped loads
+//     of x straight from L2 (16 rows x 64 B per instruction) would double the address-path work of a kernel
+//     whose weight loads already have that shape.  16-byte pieces are XOR-ed with the row inside the LDS image,
+//     which makes both the staging stores and the fragment reads (ds_read_b128) conflict free.
+//   * A workgroup owns one (column tile, K slice).  With one slice it writes the tile; with more, the slices' fp32
+//     (int32) partial tiles go to slabs [slice][M][N] and a second small kernel sums them in slice order, adds the
+//     bias and writes bf16.  (Tickets and an in-launch last-arriver sum were measured first: at 256-column tiles the
+//     agent-scope release / acquire per hand-off and the serial slab reads cost more than the launch they save,
+//     99 against 63 us on the 7B gate_up matrix.)  One compute unit pulls 29-35 GB/s of weights with this kernel, so
+//     about 150 workgroups already draw what HBM delivers; the host side picks the widest tile (x is re-read once
+//     per tile) and the fewest slices that give that many.
+#include <cstdlib>
+
+#include "stream_gemm.h"
+
+namespace hymeta {
+namespace {
+
+constexpr int kChunkSteps = 8;                 // k-steps (of 64 bytes per row) per staged chunk
+constexpr int kChunkBytes = 64 * kChunkSteps;  // 512 bytes of one row
+constexpr int kPieces = kChunkBytes / 16;      // 16-byte pieces per row of a chunk
+constexpr int kMaxSplits = 16;
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <bool I8> struct Acc { typedef f32x4 type; };
+template <> struct Acc<true> { typedef i32x4 type; };
+
+template <bool I8>
+__device__ __forceinline__ typename Acc<I8>::type mma(const u32x4& a, const u32x4& b, const typename Acc<I8>::type& c) {
+  if constexpr (I8) {
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+}
+
+// MT: 16-row fragments (rows = 16 MT); NF: 16-column fragments per wave (tile = 64 NF columns); R: ring depth.
+template <int MT, int NF, int R, bool I8, bool NT>
+__global__ __launch_bounds__(256, ((NF == 4 || MT * NF >= 8) ? 1 : 2)) void stream_gemm_kernel(StreamArgs a) {
+  typedef typename Acc<I8>::type acc_t;
+  constexpr int kRowsT = 16 * MT;
+  constexpr int kTileCols = 64 * NF;
+  constexpr int kPitch = kTileCols + 4;          // floats per row of the epilogue image
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kBufBytes = kRowsT * kChunkBytes;
+  constexpr int kWaveImg = 2 * NF * 2048;          // a wave's two weight images (one pair of k-steps each)
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int n = lane & 15, cq = lane >> 4;
+  char* wimg = smem + 2 * kBufBytes + wave * kWaveImg;
+  const int t = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
+  const int c_lo = static_cast<int>(static_cast<int64_t>(split) * a.chunks / a.splits);
+  const int c_hi = static_cast<int>(static_cast<int64_t>(split + 1) * a.chunks / a.splits);
+
+  // staging geometry: 16-byte piece idx = j * 256 + tid of the [rows][32 pieces] chunk image
+  constexpr int kStage = kRowsT * kPieces / 256;   // pieces per thread
+  const char* xsrc[kStage];
+  int xdst[kStage];
+#pragma unroll
+  for (int j = 0; j < kStage; ++j) {
+    const int idx = j * 256 + tid;
+    const int row = idx / kPieces, piece = idx % kPieces;
+    xsrc[j] = a.x + static_cast<int64_t>(min(row, a.M - 1)) * a.x_stride_bytes + piece * 16;
+    xdst[j] = row * kChunkBytes + ((piece & 16) | ((piece ^ row) & 15)) * 16;
+  }
+  // fragment reads: row 16 mt + n, piece 4 s + cq
+  int aoff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) aoff[mt] = (16 * mt + n) * kChunkBytes;
+
+  {
+    const int nsteps = (c_hi - c_lo) * kChunkSteps;
+    const int col0 = t * kTileCols + wave * 16 * NF;
+
+    // weight loads: group i = 16 rows, sub j = its rows 8j .. 8j+7; lane = (row l / 8, piece l % 8) of a 128-byte line.
+    // The lane's piece is XOR-ed with the row (swz) so that the lane-linear LDS image serves conflict-free fragment reads.
+    const char* wl[NF][2];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = 8 * j + (lane >> 3);
+        wl[i][j] = a.w + static_cast<int64_t>(col0 + 16 * i + r) * a.w_stride_bytes + static_cast<int64_t>(c_lo) * kChunkBytes +
+                   (((lane & 7) ^ ((r >> 1) & 7)) * 16);
+      }
+
+    acc_t acc[MT][NF];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < NF; ++i) acc[mt][i] = acc_t{0, 0, 0, 0};
+
+    // ring of R slots, each a PAIR of k-steps = one 128-byte line of each of the wave's 16 NF rows
+    u32x4 ring[R][2 * NF];
+    const int npairs = nsteps / 2;
+    auto issue = [&](int slot, int pair) {
+      const int off = 128 * min(pair, npairs - 1);
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ring[slot][2 * i + j] = NT ? ld16nt(wl[i][j] + off) : ld16g(wl[i][j] + off);
+    };
+#pragma unroll
+    for (int r = 0; r < R; ++r) issue(r, r);
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 xs[kStage];
+    auto stage_load = [&](int c) {
+      const int64_t off = static_cast<int64_t>(min(c, c_hi - 1)) * kChunkBytes;
+#pragma unroll
+      for (int j = 0; j < kStage; ++j) xs[j] = ld16g(xsrc[j] + off);
+    };
+    auto stage_store = [&](char* buf) {
+#pragma unroll
+      for (int j = 0; j < kStage; ++j) *reinterpret_cast<u32x4*>(buf + xdst[j]) = xs[j];
+    };
+    stage_load(c_lo);
+    stage_store(smem);
+    __syncthreads();
+
+    for (int c = c_lo; c < c_hi; ++c) {
+      const char* cur = smem + ((c - c_lo) & 1) * kBufBytes;
+      stage_load(c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int pair0 = (c - c_lo) * (kChunkSteps / 2);
+#pragma unroll
+      for (int p = 0; p < kChunkSteps / 2; ++p) {
+        const int slot = p % R;
+        char* region = wimg + (p & 1) * (NF * 2048);
+#pragma unroll
+        for (int q = 0; q < 2 * NF; ++q) *reinterpret_cast<u32x4*>(region + q * 1024 + lane * 16) = ring[slot][q];
+        // the scheduler must not sink the refill towards its use a whole ring later (it would, to save registers,
+        // and every pair would then wait out a full memory latency)
+        __builtin_amdgcn_sched_barrier(0);
+        issue(slot, pair0 + p + R);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          u32x4 af[MT], bfr[NF];
+          const int piece = 4 * (2 * p + h) + cq;
+          const int poff = ((piece & 16) | ((piece ^ n) & 15)) * 16;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(cur + aoff[mt] + poff);
+          const int woff = n * 128 + (((4 * h + cq) ^ ((n >> 1) & 7)) * 16);
+#pragma unroll
+          for (int i = 0; i < NF; ++i) bfr[i] = *reinterpret_cast<const u32x4*>(region + i * 2048 + woff);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < NF; ++i) acc[mt][i] = mma<I8>(af[mt], bfr[i], acc[mt][i]);
+        }
+      }
+      stage_store(smem + (((c - c_lo) & 1) ^ 1) * kBufBytes);
+      __syncthreads();
+    }
+
+    // ---- epilogue: the tile as a row-major 4-byte image in LDS
+    float* img = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v;
+          if constexpr (I8) v = __int_as_float(acc[mt][i][r]); else v = acc[mt][i][r];
+          img[(16 * mt + 4 * cq + r) * kPitch + wave * 16 * NF + 16 * i + n] = v;
+        }
+    __syncthreads();
+    constexpr int kVecs = kRowsT * kTileCols / 4 / 256;      // 4-column vectors per thread
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx / (kTileCols / 4), c4 = idx % (kTileCols / 4);
+      if (row >= a.M) continue;
+      const int col = t * kTileCols + 4 * c4;
+      const acc_t sum = *reinterpret_cast<const acc_t*>(img + row * kPitch + 4 * c4);
+      if (a.splits > 1) {
+        *reinterpret_cast<acc_t*>(a.slabs + ((static_cast<int64_t>(split) * a.M + row) * a.N + col) * 4) = sum;
+        continue;
+      }
+      f32x4 y;
+      if constexpr (I8) {
+        const float xs_ = a.x_scale[row];
+        const f32x4 ws = *reinterpret_cast<const f32x4*>(a.w_scale + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = static_cast<float>(sum[e]) * xs_ * ws[e];
+      } else {
+        y = sum;
+      }
+      if (a.bias != nullptr) {
+        const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + col);
+        y += f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+      }
+      const u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+      *reinterpret_cast<u32x2*>(a.out + static_cast<int64_t>(row) * a.out_stride + col) = o;
+    }
+  }
+}
+
+// Sum of the K slices' partial tiles, in slice order; one thread per 4 columns of a row.
+template <bool I8>
+__global__ __launch_bounds__(256) void stream_gemm_reduce_kernel(StreamArgs a) {
+  typedef typename Acc<I8>::type acc_t;
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int per_row = a.N / 4;
+  if (idx >= static_cast<int64_t>(a.M) * per_row) return;
+  const int row = static_cast<int>(idx / per_row), col = 4 * static_cast<int>(idx % per_row);
+  acc_t sum = acc_t{0, 0, 0, 0};
+  for (int sp = 0; sp < a.splits; ++sp)
+    sum += *reinterpret_cast<const acc_t*>(a.slabs + ((static_cast<int64_t>(sp) * a.M + row) * a.N + col) * 4);
+  f32x4 y;
+  if constexpr (I8) {
+    const float xs_ = a.x_scale[row];
+    const f32x4 ws = *reinterpret_cast<const f32x4*>(a.w_scale + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = static_cast<float>(sum[e]) * xs_ * ws[e];
+  } else {
+    y = sum;
+  }
+  if (a.bias != nullptr) {
+    const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + col);
+    y += f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+  }
+  const u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+  *reinterpret_cast<u32x2*>(a.out + static_cast<int64_t>(row) * a.out_stride + col) = o;
+}
+
+template <int MT, int NF, bool I8, int RING>
+int launch_stream(const StreamArgs& a, hipStream_t s) {
+  constexpr int R = RING;     // pairs of k-steps in flight per wave
+  constexpr size_t img = static_cast<size_t>(16 * MT) * (64 * NF + 4) * 4;                 // epilogue image
+  constexpr size_t stream = 2u * 16 * MT * kChunkBytes + 4u * 2 * NF * 2048;                  // x chunks + the waves' weight images
+  constexpr size_t lds = img > stream ? img : stream;
+  auto kern = stream_gemm_kernel<MT, NF, R, I8, true>;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
+      (void)hipGetLastError();
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles * a.splits), dim3(256), lds, s, a);
+  if (a.splits > 1) {
+    if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+    const int64_t threads = static_cast<int64_t>(a.M) * (a.N / 4);
+    hipLaunchKernelGGL(stream_gemm_reduce_kernel<I8>, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, s, a);
+  }
+  return launch_status();
+}
+
+}  // namespace
+
+// Tuning overrides, read once: HYMETA_STREAM_NF (1, 2 or 4), HYMETA_STREAM_WGS (workgroups of a split launch).
+static int tune(const char* name) {
+  const char* e = getenv(name);
+  return e == nullptr ? 0 : atoi(e);
+}
+
+bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* p) {
+  if (M <= 0 || M > 64 || K_bytes % kChunkBytes != 0 || N % 64 != 0) return false;
+  static const int nf_forced = tune("HYMETA_STREAM_NF"), splits_forced = tune("HYMETA_STREAM_SPLITS");
+  static const int ring_forced = tune("HYMETA_STREAM_RING");
+  const int chunks = K_bytes / kChunkBytes;
+  constexpr int kWant = 144;     // workgroups that draw what HBM delivers (measured: 148 whole tiles of the 7B gate_up matrix)
+  // widest tile that, cut into K slices of at least two chunks, still gives that many workgroups
+  int nf = 4;
+  while (nf > 1 && (N % (64 * nf) != 0 || static_cast<int64_t>(N / (64 * nf)) * (have_workspace ? chunks / 2 : 1) < kWant)) nf >>= 1;
+  if (nf_forced > 0) nf = nf_forced;
+  if (N % (64 * nf) != 0) return false;
+  const int tiles = N / (64 * nf);
+  int splits = 1;
+  if (have_workspace) {
+    splits = (kWant + tiles - 1) / tiles;
+    if (splits_forced > 0) splits = splits_forced;
+    if (splits > chunks) splits = chunks;
+    if (splits > kMaxSplits) splits = kMaxSplits;
+    if (splits < 1) splits = 1;
+  }
+  p->nf = nf, p->tiles = tiles, p->chunks = chunks, p->splits = splits;
+  p->ring = ring_forced == 4 || ring_forced == 2 ? ring_forced : 2;
+  return true;
+}
+
+size_t stream_gemm_workspace_bytes(int M, int N, const StreamPlan& p) {
+  return p.splits > 1 ? static_cast<size_t>(p.splits) * M * N * 4 : 0;
+}
+
+size_t stream_gemm_workspace_bound(int M, int N) {
+  return static_cast<size_t>(kMaxSplits) * M * N * 4 / (N >= 16384 ? 4 : 1);   // wide matrices never take more than kMaxSplits / 4 slices
+}
+
+template <bool I8>
+int stream_gemm_launch(StreamArgs a, const StreamPlan& p, hipStream_t s) {
+  a.tiles = p.tiles, a.chunks = p.chunks, a.splits = p.splits;
+  const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+#define HYMETA_STREAM_CASE(MT_, NF_) \
+  if (mt == MT_ && p.nf == NF_) return p.ring == 4 ? launch_stream<MT_, NF_, I8, 4>(a, s) : launch_stream<MT_, NF_, I8, 2>(a, s);
+  HYMETA_STREAM_CASE(1, 1) HYMETA_STREAM_CASE(1, 2) HYMETA_STREAM_CASE(1, 4)
+  HYMETA_STREAM_CASE(2, 1) HYMETA_STREAM_CASE(2, 2) HYMETA_STREAM_CASE(2, 4)
+  HYMETA_STREAM_CASE(4, 1) HYMETA_STREAM_CASE(4, 2) HYMETA_STREAM_CASE(4, 4)
+#undef HYMETA_STREAM_CASE
+  return HYMETA_ERR_UNSUPPORTED;
+}
+
+template int stream_gemm_launch<false>(StreamArgs, const StreamPlan&, hipStream_t);
+template int stream_gemm_launch<true>(StreamArgs, const StreamPlan&, hipStream_t);
+
+}  // namespace hymeta

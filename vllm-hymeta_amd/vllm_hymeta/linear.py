@@ -1,5 +1,6 @@
-"""Linear layers of the attention blocks: bf16 (hipBLASLt through torch) or one of the fused
-dequant-GEMMs (GPTQ 4/8-bit, W8A8).  Stands where the reference puts vLLM's
+"""Linear layers of the attention blocks: bf16 or one of the fused dequant-GEMMs (GPTQ 4/8-bit, W8A8).
+Decode-sized batches (up to 64 rows) always run on this package's weight-streaming kernels; prefill-sized
+batches of bf16 / expanded GPTQ / int8 weights go to the library GEMM.  Stands where the reference puts vLLM's
 ``QKVParallelLinear`` / ``RowParallelLinear`` / ``ReplicatedLinear`` with a ``quant_config``
 (``vllm_hymeta/model_for_7B/gla_attention.py:147-176``): a tensor-parallel shard is simply a
 ``HymetaLinear`` built from the shard's rows (column parallel) or columns (row parallel)."""
@@ -17,18 +18,13 @@ from . import hip_ops
 # projection shapes: the fused kernel wins up to a few hundred rows, the library from there on).
 GPTQ_EXPAND_ROWS = 256
 # Rows above which a W8A8 linear puts the library int8 GEMM between its own quantisation and
-# scaling kernels.  The fused kernel streams the weights once per 64 rows and is ahead up to 32 rows
-# (gate_up of the 7B model: 35 against 44 us); from 33 rows on the library path is (64 rows: 46 against
-# 58 us, 256 rows: 89 against 173 us), except on deep narrow matrices (K >= 4 N, the down projection),
-# where the fused kernel's K slices keep it ahead up to 64 rows (43 against 47 us).  Both paths give
-# the same bits (exact int32 sums).
-W8A8_LIBRARY_ROWS = 32
-W8A8_LIBRARY_ROWS_DEEP = 64
+# scaling kernels: the streaming int8 kernel covers up to 64 rows (one pass over the weights); both
+# paths give the same bits (exact int32 sums).
+W8A8_LIBRARY_ROWS = 64
 
 
 def w8a8_use_library(rows: int, in_features: int, out_features: int) -> bool:
-    deep = in_features >= 4 * out_features
-    return rows > (W8A8_LIBRARY_ROWS_DEEP if deep else W8A8_LIBRARY_ROWS)
+    return rows > W8A8_LIBRARY_ROWS
 
 
 class HymetaLinear(torch.nn.Module):
@@ -61,9 +57,8 @@ class HymetaLinear(torch.nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.kind == "bf16":
-            # decode-sized batches of a deep, narrow linear (the 7B down projection): K cut across
-            # workgroups; everything else is a plain library GEMM
-            if hip_ops.bf16_gemm_preferred(x, self.weight):
+            # decode-sized batches: the weight-streaming kernel; prefill-sized ones: a plain library GEMM
+            if hip_ops.bf16_gemm_supported(x, self.weight):
                 return hip_ops.bf16_gemm(x, self.weight, self.bias)
             return torch.nn.functional.linear(x, self.weight, self.bias)
         if self.kind == "gptq":
