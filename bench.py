@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="decode sequences (global batch)")
-    ap.add_argument("--ctx", type=int, default=8192)
+    ap.add_argument("--ctx", type=int, default=None, help="context length (default: 8192 at N=1, 32768 in the tensor-parallel mode)")
     ap.add_argument("--quant", choices=("bf16", "gptq4", "w8a8"), default="bf16", help="linears of the timed model")
     ap.add_argument("--gla-state", choices=("kv_head", "query_head"), default="kv_head",
                     help="GLA state layout: one state per key/value head (the package's default; the 7 query heads "
@@ -61,7 +61,16 @@ def parse():
     ap.add_argument("--no-side", action="store_true",
                     help="skip every side measurement (quantised models, kernel table, 70B shard): the timed region only")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs")
-    return ap.parse_args()
+    ap.add_argument("--tp-layers", type=int, default=28, help="tensor-parallel mode: layers of the 70B stack (28 = the model)")
+    ap.add_argument("--tp-eager", action="store_true", help="tensor-parallel mode: launch the step eagerly instead of from a HIP graph")
+    ap.add_argument("--force-tp", action="store_true",
+                    help="run the tensor-parallel mode with whatever WORLD_SIZE the launcher set, 1 included (a one-GPU rehearsal "
+                         "of the multi-GPU step: the collectives run over a one-rank group)")
+    args = ap.parse_args()
+    args.ctx_given = args.ctx is not None
+    if args.ctx is None:
+        args.ctx = 8192
+    return args
 
 
 # --------------------------------------------------------------------------- synthetic checkpoint
@@ -530,7 +539,7 @@ def read_traffic(B, ctx):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    if world > 1 or args.force_tp:
         from bench_tp import tp_main      # tensor-parallel mode: its own file, imported before any GPU call
         return tp_main(args)
     if not torch.cuda.is_available():

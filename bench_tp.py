@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""Tensor-parallel mode of bench.py (N > 1): python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N.
+
+Workload (BASELINE.json configs[3] / [4]): the 70B family's decode step at 32k context, one process per GPU, tensor
+parallelism over heads inside a group of TP = min(N, 4) ranks (28 query heads and 4 kv-heads admit 2 and 4; the
+reference's sharding rules refuse 8, vllm_hymeta/models/modeling_hymeta.py:401-420); N = 8 is two independent TP=4
+replicas, each with its own batch.  One step = one token for every sequence of a replica through all 28 layers of
+``HymetaForCausalLM``: on every layer the softmax branch (paged window / full attention over the sequence plus the 128
+meta keys, fused KV write) and the GLA branch on this rank's 28/TP heads, the ``[T, 2]`` variance all-reduce of the two
+group norms (:151-173), ``out_proj`` + all-reduce (:858-861), then the dense MLP or the 16-expert top-1 mixture with
+its shared expert + all-reduce (:312-324).  The collectives are torch.distributed on the "nccl" backend (= RCCL over
+xGMI), recorded into the step's HIP graph with the kernels.
+
+Random-init weights of the published geometry are generated identically on every rank (same seed) under the checkpoint's
+names and cut for the rank by the model's own ``load_weights``.  Rank 0 prints ONE JSON line: ``value`` = output tokens/s
+of the whole job (all replicas), the step time is the max over ranks.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+import bench as B1
+
+FULL_LAYERS = (3, 10, 17, 24)
+
+
+def config_70b(layers=28, vocab=4096):
+    """The published 70B geometry; the vocabulary is cut down (embedding and LM head are the engine's side).  ``layers``
+    below 28 keeps the first layers (a rehearsal on a GPU that cannot hold a 1/TP share of all experts)."""
+    from vllm_hymeta.models.configuration_hymeta import HymetaConfig
+    return HymetaConfig(vocab_size=vocab, num_hidden_layers=layers)
+
+
+def synthetic_checkpoint_70b(cfg, dev, quant, seed=0):
+    """(name, tensor) pairs under the published names (hf_model/modeling_hymeta.py parameter names; ``mode.norm`` as the
+    checkpoint spells it), one tensor at a time on the device.  ``quant``: the attention, MLP and shared-expert linears
+    as bf16 / W8A8 (hf_model/quant_w8a8.py:121-124) / GPTQ-4 (vllm_hymeta/models/hymeta_gptq.py); the routed experts and
+    the router stay bf16, as both quantisation scripts leave them."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    hidden, inter = cfg.hidden_size, cfg.intermediate_size
+    H, HKV, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+
+    def rnd(*shape, scale=1.0, dtype=torch.bfloat16):
+        return (torch.randn(*shape, device=dev, generator=g, dtype=torch.float32) * scale).to(dtype)
+
+    def linear(prefix, out_f, in_f, bias=False, quantise=True):
+        if bias:
+            yield prefix + ".bias", rnd(out_f, scale=0.02)
+        if quant == "bf16" or not quantise:
+            yield prefix + ".weight", rnd(out_f, in_f, scale=in_f ** -0.5)
+        elif quant == "w8a8":
+            yield prefix + ".weight", torch.randint(-127, 128, (out_f, in_f), dtype=torch.int8, device=dev, generator=g)
+            yield prefix + ".weight_scale", (torch.rand(out_f, 1, device=dev, generator=g) * (2.0 / 127) * in_f ** -0.5).float()
+        else:
+            yield prefix + ".qweight", torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // 8, out_f), dtype=torch.int32, device=dev, generator=g)
+            yield prefix + ".qzeros", torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // B1.GROUP, out_f // 8), dtype=torch.int32, device=dev, generator=g)
+            yield prefix + ".scales", (torch.rand(in_f // B1.GROUP, out_f, device=dev, generator=g) * (0.25 * in_f ** -0.5)).to(torch.float16)
+            yield prefix + ".g_idx", (torch.arange(in_f, dtype=torch.int32, device=dev) // B1.GROUP)
+
+    def mlp(prefix, size, quantise=True):
+        yield from linear(prefix + ".gate_proj", size, hidden, quantise=quantise)
+        yield from linear(prefix + ".up_proj", size, hidden, quantise=quantise)
+        yield from linear(prefix + ".down_proj", hidden, size, quantise=quantise)
+
+    yield "model.embeddings.weight", rnd(cfg.vocab_size, hidden, scale=0.5)
+    yield "mode.norm.weight", torch.ones(hidden, dtype=torch.bfloat16, device=dev)
+    yield "lm_head.weight", rnd(cfg.vocab_size, hidden, scale=0.02)
+    yield "model.meta_tokens", rnd(cfg.num_meta_tokens, hidden, scale=0.5)
+    yield "model.lower_bounds", rnd(cfg.num_hidden_layers, hidden, dtype=torch.float32)
+    ones = lambda n, dt=torch.bfloat16: torch.ones(n, dtype=dt, device=dev)
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        for br in ("vanilla_attn", "linear_attn"):
+            yield from linear(p + f"attn.{br}.q_proj", H * D, hidden, bias=True)
+            yield from linear(p + f"attn.{br}.k_proj", HKV * D, hidden, bias=True)
+            yield from linear(p + f"attn.{br}.v_proj", HKV * D, hidden, bias=True)
+        yield from linear(p + "attn.out_proj", hidden, H * D)
+        yield p + "attn.norm1.weight", ones(hidden, torch.float32)
+        yield p + "attn.norm2.weight", ones(hidden, torch.float32)
+        yield p + "attn_norm.weight", ones(hidden)
+        yield p + "mlp_norm.weight", ones(hidden)
+        if cfg.num_layer_experts[i] == 1:
+            yield from mlp(p + "mlp", inter)
+        else:
+            yield p + "block_sparse_moe.gate.weight", rnd(cfg.num_layer_experts[i], hidden, scale=0.5)
+            for e in range(cfg.num_layer_experts[i]):
+                yield from mlp(p + f"block_sparse_moe.experts.{e}", inter, quantise=False)
+            yield from mlp(p + "shared_mlp", cfg.shared_intermediate_size)
+
+
+def build_model_70b(dev, quant, max_num_seqs, tp_group, layers):
+    from vllm_hymeta.models.modeling_hymeta import HymetaForCausalLM
+
+    cfg = config_70b(layers)
+    q = {"bits": 4, "group_size": B1.GROUP, "zero_offset": 1} if quant == "gptq4" else None
+    model = HymetaForCausalLM(cfg, max_num_seqs=max_num_seqs, quant=q, tp_group=tp_group, device=dev)
+    model.load_weights(synthetic_checkpoint_70b(cfg, dev, quant))
+    return model, cfg
+
+
+def experts_hit(model, runner):
+    """Distinct experts the batch routes to, per mixture layer (one eager step with a hook on each mixture: the host
+    read stays outside the timed region)."""
+    from vllm_hymeta.models.moe import HymetaMoE
+
+    hit, hooks = [], []
+
+    def pre(mod, inputs):
+        x = inputs[0].reshape(-1, inputs[0].shape[-1])
+        top = torch.nn.functional.linear(x, mod.gate_weight).float().topk(mod.top_k, dim=-1).indices
+        hit.append(int(top.unique().numel()))
+
+    for mod in model.modules():
+        if isinstance(mod, HymetaMoE):
+            hooks.append(mod.register_forward_pre_hook(pre))
+    runner.eager_step()
+    torch.cuda.synchronize()
+    for h in hooks:
+        h.remove()
+    return hit
+
+
+def step_bytes_70b(cfg, quant, tp, batch, ctx, hit):
+    """Algorithmic HBM bytes of one step of ONE rank: every linear's weight share once, the routed experts' shares the
+    batch touches, the visible K/V rows (window + meta, or the whole sequence on the 4 full-attention layers) of this
+    rank's kv-heads, the GLA states of its heads read + written."""
+    wb = B1.WBYTES[quant]
+    L = cfg.num_hidden_layers
+    HIDDEN, INTER, H, HKV, D = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    M_META = cfg.num_meta_tokens
+    attn_w = L * (2 * (H + 2 * HKV) * D * HIDDEN + HIDDEN * H * D) * wb / tp
+    moe_layers = [i for i in range(L) if cfg.num_layer_experts[i] > 1]
+    dense_w = (L - len(moe_layers)) * 3 * INTER * HIDDEN * wb / tp
+    shared_w = len(moe_layers) * 3 * cfg.shared_intermediate_size * HIDDEN * wb / tp
+    expert_w = sum(hit) * 3 * INTER * HIDDEN * 2.0 / tp
+    kvh, heads = max(1, HKV // tp), H // tp
+    full = [i for i in range(L) if i in FULL_LAYERS]
+    kv = batch * 2 * kvh * D * 2 * ((L - len(full)) * (min(ctx + 1, cfg.sliding_window) + M_META) + len(full) * (ctx + 1 + M_META))
+    gla = L * batch * 2 * heads * D * D * 2
+    parts = {"attention_linears": attn_w, "dense_mlp": dense_w, "shared_expert": shared_w, "routed_experts": expert_w,
+             "kv_rows": kv, "gla_states": gla}
+    return int(sum(parts.values())), {k: int(v) for k, v in parts.items()}
+
+
+def collectives_alone(cfg, batch, group, dev, reps=5):
+    """ms of the step's collectives replayed alone from one graph (per layer: the [B, 2] fp32 statistics, the out_proj
+    output and the feed-forward output, [B, hidden] bf16 each), back to back with no compute between them."""
+    stats = torch.zeros(batch, 2, dtype=torch.float32, device=dev)
+    y = torch.zeros(batch, cfg.hidden_size, dtype=torch.bfloat16, device=dev)
+
+    def run():
+        for _ in range(cfg.num_hidden_layers):
+            dist.all_reduce(stats, group=group)
+            dist.all_reduce(y, group=group)
+            dist.all_reduce(y, group=group)
+
+    run()
+    torch.cuda.synchronize()
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            run()
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def tp_layout(world):
+    """(tensor-parallel degree, replicas): 4 ranks per group when the job has a multiple of 4, else 2, else 1 (28 query
+    heads / 4 kv-heads: the reference's sharding rules admit 1, 2 and 4)."""
+    tp = 4 if world % 4 == 0 else 2 if world % 2 == 0 else 1
+    return tp, world // tp
+
+
+class EagerRunner:
+    """The same step without a graph (``--tp-eager``)."""
+
+    def __init__(self, runner):
+        self.r = runner
+
+    def step(self):
+        self.r.advance()
+        self.r.eager_step()
+
+
+def tp_main(args):
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", flush=True)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU per rank (the HIP kernels are the product path; there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group(backend=args.dist_backend, device_id=dev if args.dist_backend == "nccl" else None)
+    from vllm_hymeta import hip_ops, parallel  # noqa: F401  (fails loudly if the HIP library is missing)
+
+    tp, replicas = tp_layout(world)
+    groups = [dist.new_group(list(range(r * tp, (r + 1) * tp))) for r in range(replicas)]   # every rank creates every group
+    tp_group = groups[rank // tp]
+    if tp == 1:
+        parallel.SINGLE_RANK_COLLECTIVES = True      # one-GPU rehearsal: keep the collectives in the step
+
+    batch, ctx, total = args.batch, args.ctx if args.ctx_given else 32768, args.warmup + args.steps
+    model, cfg = build_model_70b(dev, args.quant, batch, tp_group, args.tp_layers)
+    runner = B1.DecodeRunner(model, batch, ctx, total + 8, dev, seed=rank // tp)
+    hit = experts_hit(model, runner)
+    if args.tp_eager:
+        for _ in range(2):
+            runner.eager_step()
+        stepper = EagerRunner(runner)
+    else:
+        runner.capture()
+        stepper = runner
+    torch.cuda.synchronize()
+    elapsed, gpu_ms = B1.timed_steps(stepper, args.warmup, args.steps, dist=dist)
+    t = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, gpu_ms = float(t[0]), float(t[1])
+    coll_ms = collectives_alone(cfg, batch, tp_group, dev)
+    c = torch.tensor([coll_ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(c, op=dist.ReduceOp.MAX)
+    coll_ms = float(c[0])
+
+    nbytes, parts = step_bytes_70b(cfg, args.quant, tp, batch, ctx, hit)
+    achieved = nbytes / (gpu_ms * 1e-3) / 1e9
+    line = {
+        "metric": "decode output tokens/s (whole model step)",
+        "value": round(replicas * batch * args.steps / elapsed, 1),
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong" if replicas == 1 else "strong inside a replica (TP), weak over replicas",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"Hymeta-70B {args.quant} TP={tp} decode, ctx {ctx}, block_size {B1.BLOCK}, {batch} sequences per replica; step = "
+                        f"one token per sequence through {cfg.num_hidden_layers} layers of HymetaForCausalLM (embedding, norms, both "
+                        "attention branches on the rank's heads, out_proj, dense MLP / 16-expert top-1 mixture + shared expert, final "
+                        "norm) with the three all-reduces of every layer on RCCL; LM head and sampler (the engine's) not run.  "
+                        "The N=1 line of this bench is the 7B model: a different workload, not the base of this curve",
+            "batch_per_replica": batch,
+            "global_batch": replicas * batch,
+            "ctx": ctx,
+            "linears": args.quant,
+            "layers": cfg.num_hidden_layers,
+            "parallelism": f"tp{tp}" + (f" x {replicas} replicas" if replicas > 1 else ""),
+            "rccl_ranks": world,
+            "dist_backend": args.dist_backend,
+            "graph": not args.tp_eager,
+        },
+        "collectives": {
+            "per_step": 3 * cfg.num_hidden_layers,
+            "messages": f"per layer: [{batch}, 2] fp32 statistics, 2 x [{batch}, {cfg.hidden_size}] bf16",
+            "ms_per_step_alone": round(coll_ms, 4),
+            "share_of_step": round(coll_ms / gpu_ms, 4),
+        },
+        "roofline": {
+            "kernel": "whole decode step of one rank (one graph launch)",
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": B1.HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / B1.HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": nbytes,
+            "bytes": parts,
+            "experts_hit_per_mixture_layer": hit,
+            "avg_launch_ms": round(gpu_ms, 5),
+        },
+    }
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()

@@ -1,0 +1,91 @@
+"""Host side of the tensor-parallel bench mode on CPU, world_size 2 over gloo: the synthetic 70B checkpoint goes through
+the model's own load_weights on every rank, the ranks' shards tile the full tensors, the group layout and the byte
+model of the step are what the JSON line says.  (The step itself needs the GPU kernels.)"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_tp_layout():
+    from bench_tp import tp_layout
+    assert [tp_layout(n) for n in (1, 2, 4, 8, 6)] == [(1, 1), (2, 1), (4, 1), (4, 2), (2, 3)]
+
+
+def test_step_bytes_of_the_published_geometry():
+    from bench_tp import config_70b, step_bytes_70b
+    cfg = config_70b()
+    total, parts = step_bytes_70b(cfg, "bf16", 4, 64, 32768, [16] * 21)
+    assert parts["attention_linears"] == 28 * (2 * 4608 * 3584 + 3584 * 3584) * 2 // 4
+    assert parts["dense_mlp"] == 7 * 3 * 18944 * 3584 * 2 // 4 and parts["shared_expert"] == 21 * 3 * 18944 * 3584 * 2 // 4
+    assert parts["routed_experts"] == 21 * 16 * 3 * 18944 * 3584 * 2 // 4
+    assert parts["kv_rows"] == 64 * 2 * 128 * 2 * (24 * (4096 + 128) + 4 * (32769 + 128))
+    assert parts["gla_states"] == 28 * 64 * 2 * 7 * 128 * 128 * 2 and total == sum(parts.values())
+    # quantised linears: experts stay bf16
+    _, p8 = step_bytes_70b(cfg, "w8a8", 4, 64, 32768, [16] * 21)
+    assert p8["routed_experts"] == parts["routed_experts"] and p8["dense_mlp"] * 2 == parts["dense_mlp"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bench_tp import synthetic_checkpoint_70b
+        from vllm_hymeta.models.configuration_hymeta import HymetaConfig
+        from vllm_hymeta.models.modeling_hymeta import HymetaForCausalLM
+
+        cfg = HymetaConfig(vocab_size=64, hidden_size=512, num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=2,
+                           intermediate_size=256, shared_intermediate_size=128, num_local_experts=4, num_meta_tokens=8,
+                           max_position_embeddings=256)
+        cpu = torch.device("cpu")
+        full = dict(synthetic_checkpoint_70b(cfg, cpu, "bf16"))
+        model = HymetaForCausalLM(cfg, max_num_seqs=2, tp_group=dist.group.WORLD, device="cpu")
+        loaded = model.load_weights(synthetic_checkpoint_70b(cfg, cpu, "bf16"))
+        assert "model.norm.weight" in loaded          # the checkpoint's "mode.norm" spelling is routed
+        m = model.model
+        assert (m.tp_rank, m.tp_size) == (rank, world)
+        D, Hl, Kl = 128, 2, 1
+        lay = m.layers[1].attn
+        w = lay.vanilla_attn.qkv_proj.weight
+        assert w.shape == ((Hl + 2 * Kl) * D, 512)
+        p = "model.layers.1.attn.vanilla_attn."
+        assert torch.equal(w[: Hl * D], full[p + "q_proj.weight"][rank * Hl * D:(rank + 1) * Hl * D])
+        assert torch.equal(w[Hl * D:(Hl + Kl) * D], full[p + "k_proj.weight"][rank * Kl * D:(rank + 1) * Kl * D])
+        assert torch.equal(lay.out_proj.weight, full["model.layers.1.attn.out_proj.weight"][:, rank * Hl * D:(rank + 1) * Hl * D])
+        # layer 3 is a mixture layer: experts cut along the intermediate size, the shared expert like a dense MLP
+        moe = m.layers[3].mlp
+        assert moe.w13.shape == (4, 2 * 128, 512) and moe.w2.shape == (4, 512, 128)
+        e2 = "model.layers.3.block_sparse_moe.experts.2."
+        assert torch.equal(moe.w13[2, :128], full[e2 + "gate_proj.weight"][rank * 128:(rank + 1) * 128])
+        assert torch.equal(moe.w2[2], full[e2 + "down_proj.weight"][:, rank * 128:(rank + 1) * 128])
+        assert moe.shared_mlp.gate_up_proj.weight.shape == (2 * 64, 512) and not moe.shared_mlp.reduce_results
+        # the ranks' shards of a row-parallel weight tile the full tensor
+        parts = [torch.empty_like(lay.out_proj.weight) for _ in range(world)]
+        dist.all_gather(parts, lay.out_proj.weight.contiguous())
+        assert torch.equal(torch.cat(parts, dim=1), full["model.layers.1.attn.out_proj.weight"])
+        ret[rank] = "ok"
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        ret[rank] = traceback.format_exc() + repr(e)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_synthetic_70b_checkpoint_shards_over_two_ranks():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)

@@ -182,3 +182,37 @@ def test_make_linear_casts_checkpoint_floats_to_bf16():
           "weight_scale": torch.rand(32, 1, generator=g).to(torch.float16), "bias": torch.randn(32, generator=g).to(torch.float16)}
     lin = loader.make_linear(w8)
     assert lin.kind == "w8a8" and lin.qweight.dtype == torch.int8 and lin.w_scale.dtype == torch.float32 and lin.bias.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("make", [_bf16, _gptq, _w8a8])
+def test_cutting_tensor_by_tensor_equals_cutting_the_whole_linear(make):
+    """The streaming loader cuts every checkpoint tensor on arrival; the pieces equal what the whole-linear cuts give."""
+    g = torch.Generator().manual_seed(5)
+    K, N, tp, group = 128, 64, 2, 32
+    t = make(g, K, N)
+    t["bias"] = torch.randn(N, generator=g).to(torch.bfloat16)
+    for rank in range(tp):
+        whole = loader.shard_row_parallel(t, tp, rank, 4, group)
+        got = {leaf: loader.cut_leaf(leaf, x, loader.Cut("in", parts=tp, index=rank), 4, group) for leaf, x in t.items()}
+        got = {k: v for k, v in got.items() if v is not None}
+        assert set(got) == set(whole) - {"g_idx"} and ("bias" in got) == (rank == 0)
+        assert all(torch.equal(got[k], whole[k]) for k in got)
+        lo, hi = rank * N // tp, (rank + 1) * N // tp
+        whole = loader.slice_out_features(t, lo, hi, 4)
+        for cut in (loader.Cut("out", lo, hi), loader.Cut("out", parts=tp, index=rank)):
+            got = {leaf: loader.cut_leaf(leaf, x, cut, 4, group) for leaf, x in t.items()}
+            assert all(torch.equal(got[k], whole[k]) for k in whole if k != "g_idx")
+    # no cut: the tensor itself (a per-channel scale flattened)
+    assert loader.cut_leaf("weight", t.get("weight", t.get("qweight")), loader.Cut()) is t.get("weight", t.get("qweight"))
+
+
+def test_a_kept_piece_does_not_hold_the_whole_tensor():
+    full = torch.randn(64, 32)
+    piece = loader.own(loader.cut_leaf("weight", full, loader.Cut("out", parts=4, index=1)))
+    assert piece.untyped_storage().nbytes() == piece.numel() * 4 and torch.equal(piece, full[16:32])
+    piece = loader.own(loader.cut_leaf("weight", full, loader.Cut("in", parts=4, index=3)))
+    assert piece.is_contiguous() and piece.untyped_storage().nbytes() == piece.numel() * 4 and torch.equal(piece, full[:, 24:])
+    whole = loader.own(full)
+    assert whole is full
+    with pytest.raises(ValueError):
+        loader.cut_leaf("g_idx", torch.arange(64, dtype=torch.int32).flip(0) // 32, loader.Cut(), 4, 32)     # act-order

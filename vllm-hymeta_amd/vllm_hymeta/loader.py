@@ -185,6 +185,94 @@ def slice_in_features(t: Dict[str, torch.Tensor], lo: int, hi: int, bits: int = 
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# The same cuts one tensor at a time, for loading as a stream: a checkpoint tensor is cut for the rank
+# the moment it arrives and only the rank's piece is kept (on the device), so that loading never holds
+# more than the rank's share of the model plus the tensor in flight.
+# ------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Cut:
+    """How the tensors of one linear are cut for a rank: along the output features (``axis="out"``: the explicit range
+    ``[lo, hi)`` -- a head range -- or share ``index`` of ``parts`` equal shares), along the input features
+    (``axis="in"``: share ``index`` of ``parts``), or not at all (``axis="none"``)."""
+    axis: str = "none"
+    lo: Optional[int] = None
+    hi: Optional[int] = None
+    parts: int = 1
+    index: int = 0
+
+
+def _share(n: int, cut: Cut, what: str) -> Tuple[int, int]:
+    if n % cut.parts:
+        raise ValueError(f"{what} {n} must be divisible by tensor-parallel size {cut.parts}")
+    per = n // cut.parts
+    return cut.index * per, (cut.index + 1) * per
+
+
+def cut_leaf(leaf: str, t: torch.Tensor, cut: Cut, bits: int = 4, group_size: int = 128) -> Optional[torch.Tensor]:
+    """One checkpoint tensor of a linear (``leaf``: weight / bias / weight_scale / qweight / qzeros / scales / g_idx) ->
+    the rank's piece (a view), or ``None`` when the rank keeps nothing of it (the bias of a row-parallel linear on
+    ranks other than 0, which the all-reduce must sum once; ``g_idx``, checked here and not needed afterwards)."""
+    pack = 32 // bits
+    if leaf == "g_idx":
+        check_g_idx(t, group_size)
+        return None
+    if cut.axis == "none":
+        return t.reshape(-1) if leaf == "weight_scale" else t
+    if cut.axis == "out":
+        if cut.lo is not None:
+            lo, hi = cut.lo, cut.hi
+        else:
+            n = {"weight": t.shape[0], "qweight": t.shape[-1], "scales": t.shape[-1], "qzeros": t.shape[-1] * pack}.get(leaf, t.numel())
+            lo, hi = _share(n, cut, "output size")
+        if leaf in ("weight", "bias"):
+            return t[lo:hi]
+        if leaf == "weight_scale":
+            return t.reshape(-1)[lo:hi]
+        if leaf in ("qweight", "scales"):
+            return t[:, lo:hi]
+        if leaf == "qzeros":
+            if lo % pack or hi % pack:
+                raise ValueError(f"GPTQ output split [{lo}, {hi}) must fall on multiples of {pack} (packed zeros)")
+            return t[:, lo // pack:hi // pack]
+        raise ValueError(f"unknown linear tensor {leaf!r}")
+    if cut.axis != "in":
+        raise ValueError(f"unknown cut axis {cut.axis!r}")
+    if leaf == "bias":
+        return t if cut.index == 0 else None
+    if leaf == "weight_scale":
+        return t.reshape(-1)
+    if leaf == "weight":
+        lo, hi = _share(t.shape[1], cut, "input size")
+        return t[:, lo:hi]
+    k_total = t.shape[0] * (pack if leaf == "qweight" else group_size)
+    lo, hi = _share(k_total, cut, "input size")
+    if lo % group_size or hi % group_size:
+        raise ValueError(f"GPTQ input split [{lo}, {hi}) must fall on group boundaries ({group_size})")
+    if leaf == "qweight":
+        return t[lo // pack:hi // pack]
+    if leaf in ("qzeros", "scales"):
+        return t[lo // group_size:hi // group_size]
+    raise ValueError(f"unknown linear tensor {leaf!r}")
+
+
+def own(piece: torch.Tensor, device=None) -> torch.Tensor:
+    """``piece`` on ``device`` in storage of its own size: a view into a whole checkpoint tensor would keep all of it
+    alive."""
+    piece = piece.contiguous()
+    if device is not None:
+        piece = piece.to(device)
+    if piece.untyped_storage().nbytes() > piece.numel() * piece.element_size():
+        piece = piece.clone()
+    return piece
+
+
+def head_cuts(shard: HeadShard, head_dim: int) -> Dict[str, Cut]:
+    """Output-feature cuts of the q / k / v projections for a head shard."""
+    kv = Cut("out", shard.kv_head_start * head_dim, (shard.kv_head_start + shard.num_kv_heads) * head_dim)
+    return {"q": Cut("out", shard.head_start * head_dim, (shard.head_start + shard.num_heads) * head_dim), "k": kv, "v": kv}
+
+
 def concat_out_features(parts: Sequence[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
     """Fuse linears that share their input along the output axis (q|k|v -> qkv, gate|up -> gate_up)."""
     kind = linear_kind(parts[0])

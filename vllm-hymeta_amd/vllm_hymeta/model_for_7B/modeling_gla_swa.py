@@ -187,8 +187,26 @@ class GLAswaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only
         q = m.quant
         dev = m.device
         loaded: Set[str] = set()
-        parts: Dict[str, Dict[object, Dict[str, torch.Tensor]]] = {}    # module -> shard id -> tensors
+        parts: Dict[str, Dict[object, Dict[str, torch.Tensor]]] = {}    # module -> shard id -> this rank's tensors
         plain: Dict[str, torch.Tensor] = {}
+        H, KVH, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        sh = m.shard
+        heads = loader.head_cuts(sh, D)
+        row = loader.Cut("in", parts=m.tp_size, index=m.tp_rank)
+        col = loader.Cut("out", parts=m.tp_size, index=m.tp_rank)
+
+        def cut_of(module: str, shard_id) -> loader.Cut:
+            if module.endswith(".attn.qkv_proj"):
+                return heads[shard_id]
+            if module.endswith(".gk_proj.linear1"):
+                return heads["k"]
+            if module.endswith(".o_proj") or module.endswith(".down_proj"):
+                return row
+            if module.endswith(".gate_up_proj"):
+                return col
+            return loader.Cut()
+
+        # the checkpoint is a stream: every tensor is cut for this rank as it arrives and only the piece is kept
         for name, tensor in weights:
             route = loader.route_7b(name, cfg.num_hidden_layers)
             if route is None:
@@ -197,39 +215,36 @@ class GLAswaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only
             module, _, leaf = route.param.rpartition(".")
             if leaf in ("weight", "bias", "qweight", "qzeros", "scales", "g_idx", "weight_scale") and (
                     "proj" in module or module == "lm_head" or module.endswith("embeddings")):
-                parts.setdefault(module, {}).setdefault(route.shard_id, {})[leaf] = tensor
+                piece = loader.cut_leaf(leaf, tensor, cut_of(module, route.shard_id), q["bits"], q["group_size"])
+                if piece is not None:
+                    parts.setdefault(module, {}).setdefault(route.shard_id, {})[leaf] = loader.own(piece, dev)
             else:
-                plain[route.param] = tensor
+                plain[route.param] = tensor.to(dev)
 
         def lin(module: str, shard=None) -> Dict[str, torch.Tensor]:
-            return parts[module][shard]
+            return parts[module].pop(shard)
 
         def make(t: Dict[str, torch.Tensor]) -> HymetaLinear:
             return loader.make_linear(t, q["bits"], q["group_size"], q["zero_offset"], device=dev)
 
-        H, KVH, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        m.embeddings = lin("model.embeddings")["weight"].to(torch.bfloat16).to(dev)
-        m.norm = HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain["model.norm.weight"].to(dev))
-        self.lm_head = lin("lm_head")["weight"].float().to(dev)
+        m.embeddings = lin("model.embeddings")["weight"].to(torch.bfloat16)
+        m.norm = HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain["model.norm.weight"])
+        self.lm_head = lin("lm_head")["weight"].float()
         m.layers = torch.nn.ModuleList()
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}"
-            qkv, sh = loader.shard_qkv(lin(f"{p}.attn.qkv_proj", "q"), lin(f"{p}.attn.qkv_proj", "k"), lin(f"{p}.attn.qkv_proj", "v"),
-                                       H, KVH, D, m.tp_size, m.tp_rank, q["bits"])
-            o_proj = make(loader.shard_row_parallel(lin(f"{p}.attn.o_proj"), m.tp_size, m.tp_rank, q["bits"], q["group_size"]))
+            qkv = loader.concat_out_features([lin(f"{p}.attn.qkv_proj", s) for s in ("q", "k", "v")])
+            o_proj = make(lin(f"{p}.attn.o_proj"))
             if i in cfg.attn_layers:
                 attn = SlidingWindowAttention(cfg.hidden_size, H, KVH, cfg.sliding_window, make(qkv), o_proj, m.cos_sin_cache,
                                               shard=sh, tp_group=m.tp_group, attn=m.attn_layers[str(i)])
             else:
-                gk1 = loader.slice_out_features(lin(f"{p}.attn.gk_proj.linear1"), sh.kv_head_start * D,
-                                                (sh.kv_head_start + sh.num_kv_heads) * D, q["bits"])
-                attn = GatedLinearAttention(cfg.hidden_size, H, KVH, make(qkv), make(lin(f"{p}.attn.gk_proj.linear0")), make(gk1),
-                                            o_proj, plain[f"{p}.attn.g_norm.weight"].to(torch.bfloat16).to(dev), cfg.norm_eps,
+                attn = GatedLinearAttention(cfg.hidden_size, H, KVH, make(qkv), make(lin(f"{p}.attn.gk_proj.linear0")),
+                                            make(lin(f"{p}.attn.gk_proj.linear1")), o_proj,
+                                            plain[f"{p}.attn.g_norm.weight"].to(torch.bfloat16), cfg.norm_eps,
                                             cfg.gate_logit_normalizer, shard=sh, tp_group=m.tp_group)
-            mlp = GLAswaGLU(make(loader.shard_gate_up(lin(f"{p}.mlp.gate_up_proj", 0), lin(f"{p}.mlp.gate_up_proj", 1),
-                                                       m.tp_size, m.tp_rank, q["bits"])),
-                            make(loader.shard_row_parallel(lin(f"{p}.mlp.down_proj"), m.tp_size, m.tp_rank, q["bits"], q["group_size"])),
-                            tp_group=m.tp_group)
-            m.layers.append(GLAswaBlock(HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.attn_norm.weight"].to(dev)), attn,
-                                        HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.mlp_norm.weight"].to(dev)), mlp))
+            mlp = GLAswaGLU(make(loader.concat_out_features([lin(f"{p}.mlp.gate_up_proj", 0), lin(f"{p}.mlp.gate_up_proj", 1)])),
+                            make(lin(f"{p}.mlp.down_proj")), tp_group=m.tp_group)
+            m.layers.append(GLAswaBlock(HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.attn_norm.weight"]), attn,
+                                        HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.mlp_norm.weight"]), mlp))
         return loaded

@@ -20,7 +20,7 @@ from typing import Optional
 
 import torch
 
-from .. import _C, hip_ops
+from .. import _C, hip_ops, parallel
 from .attention import MetaAttention, bind_kv_cache, current_attn_metadata, forward_context, standalone_prefix
 from ..linear import HymetaLinear
 from ..parallel import HeadShard, all_reduce_sum, all_reduce_variance, shard_heads
@@ -179,7 +179,7 @@ class IntraHybridAttention(torch.nn.Module):
 
     def combine(self, out_attn: torch.Tensor, out_linear: torch.Tensor) -> torch.Tensor:
         stats = None
-        if self.linear_attn.shard.tp_size > 1:      # the statistics span the full hidden size: every rank's share
+        if self.linear_attn.shard.tp_size > 1 or parallel.SINGLE_RANK_COLLECTIVES:      # the statistics span the full hidden size: every rank's share
             stats = all_reduce_variance(hip_ops.rms_sumsq2(out_attn, out_linear), self.tp_group)
         return hip_ops.hybrid_combine(out_attn, out_linear, self.norm1_weight, self.norm2_weight,
                                       self.norm_eps, stats=stats)

@@ -232,10 +232,27 @@ class HymetaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only
         cfg, m = self.config, self.model
         q, dev = m.quant, m.device
         loaded: Set[str] = set()
-        parts: Dict[str, Dict[object, Dict[str, torch.Tensor]]] = {}       # linear module -> shard id -> tensors
-        experts: Dict[int, Dict[int, Dict[str, torch.Tensor]]] = {}        # layer -> expert -> projection -> weight
+        parts: Dict[str, Dict[object, Dict[str, torch.Tensor]]] = {}       # linear module -> shard id -> this rank's tensors
+        experts: Dict[int, Dict[int, Dict[str, torch.Tensor]]] = {}        # layer -> expert -> projection -> this rank's slice
         plain: Dict[str, torch.Tensor] = {}
         proj_of = {"w1": "gate_proj", "w3": "up_proj", "w2": "down_proj"}
+        H, KVH, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        sh = m.shard
+        hs = slice(sh.head_start * D, (sh.head_start + sh.num_heads) * D)
+        heads = loader.head_cuts(sh, D)
+        row = loader.Cut("in", parts=m.tp_size, index=m.tp_rank)
+        col = loader.Cut("out", parts=m.tp_size, index=m.tp_rank)
+
+        def cut_of(module: str, shard_id) -> loader.Cut:
+            if module.endswith(".qkv_proj"):
+                return heads[shard_id]
+            if module.endswith(".out_proj") or module.endswith(".down_proj"):
+                return row
+            if module.endswith(".gate_up_proj"):
+                return col
+            return loader.Cut()
+
+        # the checkpoint is a stream: every tensor is cut for this rank as it arrives and only the piece is kept
         for name, tensor in weights:
             route = loader.route_70b(name, cfg.num_hidden_layers)
             if route is None:
@@ -245,63 +262,63 @@ class HymetaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only
                 if tensor.dtype not in (torch.bfloat16, torch.float16, torch.float32):
                     raise ValueError(f"{name}: quantised experts are not supported, expected a floating-point weight")
                 layer = loader._layer_of(name)
-                experts.setdefault(layer, {}).setdefault(route.expert_id, {})[proj_of[route.shard_id]] = tensor.to(torch.bfloat16)
+                cut = row if route.shard_id == "w2" else col          # experts are cut along their intermediate size
+                piece = loader.own(loader.cut_leaf("weight", tensor, cut), dev).to(torch.bfloat16)
+                experts.setdefault(layer, {}).setdefault(route.expert_id, {})[proj_of[route.shard_id]] = piece
                 continue
             module, _, leaf = route.param.rpartition(".")
             if "proj" in module and "norm" not in module:
-                parts.setdefault(module, {}).setdefault(route.shard_id, {})[leaf] = tensor
+                piece = loader.cut_leaf(leaf, tensor, cut_of(module, route.shard_id), q["bits"], q["group_size"])
+                if piece is not None:
+                    parts.setdefault(module, {}).setdefault(route.shard_id, {})[leaf] = loader.own(piece, dev)
+            elif module.endswith(".attn.norm1") or module.endswith(".attn.norm2"):
+                plain[route.param] = loader.own(tensor[hs], dev)        # the group norms act on this rank's head columns
             else:
-                plain[route.param] = tensor
+                plain[route.param] = tensor.to(dev)
 
         def lin(module: str, shard=None) -> Dict[str, torch.Tensor]:
-            return parts[module][shard]
+            return parts[module].pop(shard)
 
         def make(t: Dict[str, torch.Tensor]) -> HymetaLinear:
             return loader.make_linear(t, q["bits"], q["group_size"], q["zero_offset"], device=dev)
 
         def mlp(prefix: str, reduce_results: bool = True) -> HymetaMLP:
-            gate_up = loader.shard_gate_up(lin(f"{prefix}.gate_up_proj", 0), lin(f"{prefix}.gate_up_proj", 1),
-                                           m.tp_size, m.tp_rank, q["bits"])
-            down = loader.shard_row_parallel(lin(f"{prefix}.down_proj"), m.tp_size, m.tp_rank, q["bits"], q["group_size"])
-            return HymetaMLP(make(gate_up), make(down), tp_group=m.tp_group, reduce_results=reduce_results)
+            gate_up = loader.concat_out_features([lin(f"{prefix}.gate_up_proj", 0), lin(f"{prefix}.gate_up_proj", 1)])
+            return HymetaMLP(make(gate_up), make(lin(f"{prefix}.down_proj")), tp_group=m.tp_group, reduce_results=reduce_results)
 
-        H, KVH, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        sh = m.shard
-        hs = slice(sh.head_start * D, (sh.head_start + sh.num_heads) * D)
-        m.embeddings = plain["model.embeddings.weight"].to(torch.bfloat16).to(dev)
-        m.norm = HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain["model.norm.weight"].to(dev))
-        self.lm_head = plain["lm_head.weight"].float().to(dev)
+        m.embeddings = plain["model.embeddings.weight"].to(torch.bfloat16)
+        m.norm = HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain["model.norm.weight"])
+        self.lm_head = plain["lm_head.weight"].float()
         if m.use_lower_bound:
-            lb = plain["model.lower_bounds"].float().to(dev).softmax(0)
+            lb = plain["model.lower_bounds"].float().softmax(0)
             m.lower_bounds = (lb.cumsum(0) - lb[0]).contiguous()
         if m.num_meta_tokens > 0:
-            m.meta_tokens = plain["model.meta_tokens"].to(torch.bfloat16).to(dev).contiguous()
+            m.meta_tokens = plain["model.meta_tokens"].to(torch.bfloat16).contiguous()
         m.layers = torch.nn.ModuleList()
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}"
 
             def qkv(branch: str) -> HymetaLinear:
-                fused, _ = loader.shard_qkv(lin(f"{p}.attn.{branch}.qkv_proj", "q"), lin(f"{p}.attn.{branch}.qkv_proj", "k"),
-                                            lin(f"{p}.attn.{branch}.qkv_proj", "v"), H, KVH, D, m.tp_size, m.tp_rank, q["bits"])
-                return make(fused)
+                return make(loader.concat_out_features([lin(f"{p}.attn.{branch}.qkv_proj", s) for s in ("q", "k", "v")]))
 
             vanilla = MetaFlashAttention(cfg.hidden_size, H, KVH, qkv("vanilla_attn"), m.cos_sin_cache, _layer_window(cfg, i),
                                          num_meta_tokens=m.num_meta_tokens, shard=sh, attn=m.attn_layers[i])
             linear = HLinearAttention(cfg.hidden_size, H, KVH, qkv("linear_attn"), i, num_meta_tokens=m.num_meta_tokens, shard=sh)
-            out_proj = make(loader.shard_row_parallel(lin(f"{p}.attn.out_proj"), m.tp_size, m.tp_rank, q["bits"], q["group_size"]))
-            attn = IntraHybridAttention(vanilla, linear, out_proj, plain[f"{p}.attn.norm1.weight"][hs].to(dev),
-                                        plain[f"{p}.attn.norm2.weight"][hs].to(dev), cfg.norm_eps, tp_group=m.tp_group)
+            attn = IntraHybridAttention(vanilla, linear, make(lin(f"{p}.attn.out_proj")), plain[f"{p}.attn.norm1.weight"],
+                                        plain[f"{p}.attn.norm2.weight"], cfg.norm_eps, tp_group=m.tp_group)
             n_experts = _layer_experts(cfg, i)
             if n_experts == 1:
                 ffn = mlp(f"{p}.mlp")
             else:
-                w13, w2 = loader.stack_experts([experts[i][e] for e in range(n_experts)], m.tp_size, m.tp_rank)
+                mine = experts.pop(i)
+                w13, w2 = loader.stack_experts([mine[e] for e in range(n_experts)])       # already this rank's slices
+                del mine
                 # the shared expert's partial sums ride in the experts' all-reduce
                 shared = mlp(f"{p}.shared_mlp", reduce_results=False) if _shared_intermediate(cfg, i) > 0 else None
-                ffn = HymetaMoE(plain[f"{p}.block_sparse_moe.gate.weight"].to(torch.bfloat16).to(dev), w13.to(dev), w2.to(dev),
+                ffn = HymetaMoE(plain[f"{p}.block_sparse_moe.gate.weight"].to(torch.bfloat16), w13, w2,
                                 top_k=cfg.num_experts_per_topk, renormalize=False, shared_mlp=shared, group=m.tp_group)
-            m.layers.append(HybridBlock(HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.attn_norm.weight"].to(dev)), attn,
-                                        HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.mlp_norm.weight"].to(dev)), ffn))
+            m.layers.append(HybridBlock(HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.attn_norm.weight"]), attn,
+                                        HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.mlp_norm.weight"]), ffn))
         if dev.type == "cuda":
             m.prepare_meta_caches()
         return loaded

@@ -44,11 +44,18 @@ def shard_heads(total_heads: int, total_kv_heads: int, tp_size: int, tp_rank: in
     return HeadShard(tp_size, tp_rank, h_local, kv_local, tp_rank * h_local, kv_start)
 
 
+# Rehearsal switch: run the collectives over a ONE-rank group too (a multi-GPU step exercised on one GPU, graph
+# capture of the collective calls included).  Off in serving: a one-rank all-reduce is pure overhead.
+SINGLE_RANK_COLLECTIVES = False
+
+
 def _active(group: Optional[dist.ProcessGroup]) -> bool:
     """``group is None`` means "no tensor parallelism" and is a strict no-op, whatever process group
     the program holds for other purposes (replicas, data or pipeline parallelism): a collective only
     runs over a group that was passed explicitly (``dist.group.WORLD`` for the whole job)."""
-    return group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if group is None or not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or SINGLE_RANK_COLLECTIVES
 
 
 def all_reduce_sum(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
