@@ -203,7 +203,9 @@ class DecodeRunner:
         return self.model(self.input_ids, self.positions, attn_metadata=self.md, kv_caches=self.kv,
                           seqlen_agnostic_capture_inputs=self.capture_inputs)
 
-    def capture(self):
+    def capture(self, before_capture=None):
+        """``before_capture``: called after the eager warm-up, right before recording starts (the tensor-parallel mode
+        waits there until the process group's watchdog holds no eager work)."""
         for _ in range(2):                       # sizes every workspace, loads every kernel
             self.eager_step()
         torch.cuda.synchronize()
@@ -211,6 +213,8 @@ class DecodeRunner:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
             self.eager_step()
+            if before_capture is not None:
+                before_capture()
             with torch.cuda.graph(self.graph, stream=side):
                 self.out = self.eager_step()
         torch.cuda.synchronize()

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import json
 import os
+import sys
 import time
 
 import torch
@@ -148,6 +149,20 @@ def step_bytes_70b(cfg, quant, tp, batch, ctx, hit):
     return int(sum(parts.values())), {k: int(v) for k, v in parts.items()}
 
 
+def settle():
+    """Let the process group's watchdog thread retire every eager collective before a stream capture starts.  The
+    watchdog polls the end events of the eager work it still holds; a poll that lands while the group's communication
+    stream is being captured is refused by HIP (hipErrorCapturedEvent) and takes the process down.  The watchdog wakes
+    every 100 ms; the event cache is switched off in ``tp_main`` so that eager work never holds an event a capture used."""
+    torch.cuda.synchronize()
+    time.sleep(1.0)
+
+
+def note(rank, msg):
+    if rank == 0:
+        print(f"[bench_tp] {msg}", file=sys.stderr, flush=True)
+
+
 def collectives_alone(cfg, batch, group, dev, reps=5):
     """ms of the step's collectives replayed alone from one graph (per layer: the [B, 2] fp32 statistics, the out_proj
     output and the feed-forward output, [B, hidden] bf16 each), back to back with no compute between them."""
@@ -161,9 +176,10 @@ def collectives_alone(cfg, batch, group, dev, reps=5):
             dist.all_reduce(y, group=group)
 
     run()
-    torch.cuda.synchronize()
     graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
     with torch.cuda.stream(side):
+        run()
+        settle()
         with torch.cuda.graph(graph, stream=side):
             run()
     graph.replay()
@@ -204,6 +220,7 @@ def tp_main(args):
         raise SystemExit("bench.py needs a GPU per rank (the HIP kernels are the product path; there is no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")      # see settle()
     dist.init_process_group(backend=args.dist_backend, device_id=dev if args.dist_backend == "nccl" else None)
     from vllm_hymeta import hip_ops, parallel  # noqa: F401  (fails loudly if the HIP library is missing)
 
@@ -214,21 +231,25 @@ def tp_main(args):
         parallel.SINGLE_RANK_COLLECTIVES = True      # one-GPU rehearsal: keep the collectives in the step
 
     batch, ctx, total = args.batch, args.ctx if args.ctx_given else 32768, args.warmup + args.steps
+    note(rank, f"{world} ranks: tp{tp} x {replicas}; building the model")
     model, cfg = build_model_70b(dev, args.quant, batch, tp_group, args.tp_layers)
     runner = B1.DecodeRunner(model, batch, ctx, total + 8, dev, seed=rank // tp)
     hit = experts_hit(model, runner)
+    note(rank, f"model built ({torch.cuda.memory_allocated(dev) / 2 ** 30:.1f} GiB allocated), experts hit {hit}")
     if args.tp_eager:
         for _ in range(2):
             runner.eager_step()
         stepper = EagerRunner(runner)
     else:
-        runner.capture()
+        runner.capture(before_capture=settle)
         stepper = runner
     torch.cuda.synchronize()
+    note(rank, "step ready; timing")
     elapsed, gpu_ms = B1.timed_steps(stepper, args.warmup, args.steps, dist=dist)
     t = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, gpu_ms = float(t[0]), float(t[1])
+    note(rank, f"timed: {gpu_ms:.3f} ms/step; timing the collectives alone")
     coll_ms = collectives_alone(cfg, batch, tp_group, dev)
     c = torch.tensor([coll_ms], dtype=torch.float64, device=dev)
     dist.all_reduce(c, op=dist.ReduceOp.MAX)

@@ -14,13 +14,17 @@ pytestmark = pytest.mark.gpu
     (1, 3584, 4608, True, 0),          # 7B qkv projection, one token
     (7, 3584, 3584, False, 0),
     (16, 512, 64, True, 3),            # slices that do not divide the k-steps evenly
-    (17, 4736, 3584, False, 0),        # 70B TP=4 down projection: K not a multiple of 128
+    (17, 4736, 3584, False, 0),        # 70B TP=4 down projection: K = 18.5 chunks of 256 (partial last chunk)
+    (64, 896, 3584, True, 0),          # 70B TP=4 out_proj: 3.5 chunks, K slices that end inside a chunk
+    (64, 3584, 9472, False, 0),        # 70B TP=4 gate_up: 148 column groups of 64 -> tiles of two widths... one width here
+    (40, 320, 4160, True, 0),          # 65 groups < 256 workgroups, 1.25 chunks
+    (64, 3584, 18944, False, 0),       # 296 groups: 256 tiles, 40 of two fragments per wave and 216 of one
     (33, 18944, 3584, False, 0),       # 7B down projection: few column tiles, deep K
     (64, 3584, 1024, True, 5),
     (64, 1024, 4096, True, 1),
-    # the weight-streaming kernel (library's choice, K a multiple of 256): whole tiles, K slices + the reduce launch
+    # the weight-streaming kernel (library's choice, K a multiple of 64): whole tiles of two widths, K slices + the reduce launch
     (64, 3584, 4608, True, 0),         # 7B qkv at the bench batch: 128-column tiles, K slices
-    (48, 3584, 37888, False, 0),       # 7B gate_up: 148 whole tiles of 256 columns, rows past M masked
+    (48, 3584, 37888, False, 0),       # 7B gate_up: 592 groups -> 256 tiles, 80 of 192 columns and 176 of 128; rows past M masked
     (64, 18944, 3584, True, 0),        # 7B down projection: deep K in slices
     (5, 512, 320, True, 0),            # 64-column tiles (N not a multiple of 128), two chunks
     (20, 256, 64, False, 0),           # one tile, one chunk

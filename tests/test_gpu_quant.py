@@ -126,7 +126,8 @@ def test_gptq_linear_large_m_uses_expanded_weights():
         assert_bf16_close(out.cpu(), ref, f"gptq linear M={M}", rel=8e-3)
 
 
-@pytest.mark.parametrize("M,K,N", [(17, 3584, 4608), (33, 3584, 37888), (64, 18944, 3584), (64, 3584, 3584), (40, 512, 320)])
+@pytest.mark.parametrize("M,K,N", [(17, 3584, 4608), (33, 3584, 37888), (64, 18944, 3584), (64, 3584, 3584), (40, 512, 320),
+                                   (64, 4736, 3584), (24, 896, 3584), (64, 3584, 9472)])     # the last three: 70B TP=4 shards
 def test_w8a8_streaming_kernel_matches_the_library_path_exactly(M, K, N):
     """17 to 64 rows run on the weight-streaming int8 kernel (whole tiles or K slices + the reduce launch); the int32 sums
     are exact, so the result equals quantise -> library int8 GEMM -> scale bit for bit, and the oracle within tolerance."""

@@ -14,6 +14,8 @@ from vllm_hymeta import hip_ops  # noqa: E402
 dev = torch.device("cuda")
 SHAPES = [("qkv", 3584, 4608), ("o", 3584, 3584), ("gate_up", 3584, 37888), ("down", 18944, 3584)]
 ROWS = [int(r) for r in os.environ.get("ROWS", "1,16,64").split(",")]
+if os.environ.get("SHAPES"):
+    SHAPES = [sh for sh in SHAPES if sh[0] in os.environ["SHAPES"].split(",")]
 for M in ROWS:
     for name, K, N in SHAPES:
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)

@@ -107,4 +107,11 @@ inline int launch_status() {
   return hipGetLastError() == hipSuccess ? HYMETA_OK : HYMETA_ERR_LAUNCH;
 }
 
+// The W8A8 output scaling, written once so that every kernel that applies it rounds the same way whatever the
+// compiler would contract: (acc * x_scale) rounded, then one fused multiply-add with the weight scale and the bias
+// (bias 0 without one: the fused form then equals the rounded product).
+__device__ __forceinline__ float w8a8_scaled(int acc, float x_scale, float w_scale, float bias) {
+  return __builtin_fmaf(static_cast<float>(acc) * x_scale, w_scale, bias);
+}
+
 }  // namespace hymeta

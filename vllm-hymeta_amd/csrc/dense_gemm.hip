@@ -185,7 +185,7 @@ extern "C" int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream
       sa.x = static_cast<const char*>(a.x), sa.w = static_cast<const char*>(a.weight);
       sa.bias = static_cast<const uint16_t*>(a.bias), sa.out = static_cast<uint16_t*>(a.out);
       sa.slabs = have_ws ? static_cast<char*>(a.workspace) + kTicketBytes : nullptr;
-      sa.M = a.M, sa.N = a.N;
+      sa.M = a.M, sa.N = a.N, sa.k_bytes = a.K * 2;
       sa.x_stride_bytes = a.x_stride_m * 2, sa.w_stride_bytes = a.w_stride_n * 2, sa.out_stride = a.out_stride_m;
       return stream_gemm_launch<false>(sa, plan, begin_launches(stream));
     }

@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256) void w8a8_scale_out_kernel(const int32_t* __re
   }
   float y[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) y[i] = static_cast<float>(v[i]) * xs * ws[i] + b[i];
+  for (int i = 0; i < 4; ++i) y[i] = w8a8_scaled(v[i], xs, ws[i], b[i]);
   *reinterpret_cast<u32x2*>(out + m * out_stride_m + col) = u32x2{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
 }
 
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(hymeta_w8a8_gemm_args a,
     const float xs = a.x_scale[grow];
     float y[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = static_cast<float>(sum[j][i]) * xs * ws[i] + bias[i];
+    for (int i = 0; i < 4; ++i) y[i] = w8a8_scaled(sum[j][i], xs, ws[i], bias[i]);
     const u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
     *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(grow) * a.out_stride_m + col) = o;
   }
@@ -1092,7 +1092,7 @@ extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream
       sa.bias = static_cast<const uint16_t*>(a.bias), sa.out = static_cast<uint16_t*>(a.out);
       sa.x_scale = a.x_scale, sa.w_scale = a.w_scale;
       sa.slabs = have_ws ? static_cast<char*>(a.workspace) + kTicketBytes : nullptr;
-      sa.M = a.M, sa.N = a.N;
+      sa.M = a.M, sa.N = a.N, sa.k_bytes = a.K;
       sa.x_stride_bytes = a.K, sa.w_stride_bytes = a.K, sa.out_stride = a.out_stride_m;
       return stream_gemm_launch<true>(sa, plan, s);
     }

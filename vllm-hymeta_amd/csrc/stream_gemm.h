@@ -14,19 +14,21 @@ struct StreamArgs {
   const float* w_scale;   // W8A8: fp32 [N]
   char* slabs;            // [splits][M][N] 4-byte partial sums (splits > 1)
   int M, N;
+  int k_bytes;            // bytes of one row of x / W that hold K (a multiple of 128)
   int64_t x_stride_bytes, w_stride_bytes, out_stride;
-  int tiles, chunks, splits;    // filled from the plan
+  int tiles, big, chunks, splits;    // filled from the plan
 };
 
 struct StreamPlan {
-  int nf;        // 16-column fragments per wave: a workgroup's tile is 64 nf columns
+  int nf;        // 16-column fragments per wave of the wider tiles: such a tile is 64 nf columns
+  int big;       // tiles [0, big) have that width, tiles [big, tiles) one fragment per wave less
   int tiles, chunks;   // chunks: 512-byte pieces of a weight row
   int splits;          // K slices per tile (1: the workgroup writes the tile itself)
   int ring;      // pairs of k-steps each wave keeps in flight (2 or 4)
 };
 
-// Whether the streaming kernel takes the shape (M <= 64 rows, K a multiple of 512 bytes, N of 64 columns), and how
-// it is cut.  Without a workspace every workgroup owns whole tiles (no slabs).
+// Whether the streaming kernel takes the shape (M <= 64 rows, K a multiple of 128 bytes and at least 512, N of 64 columns), and how
+// it is cut (one workgroup per compute unit where the shape allows).  Without a workspace every workgroup owns whole tiles (no slabs).
 bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* plan);
 // Slab bytes of that plan (0 without K slices); no ticket counters are used.
 size_t stream_gemm_workspace_bytes(int M, int N, const StreamPlan& plan);

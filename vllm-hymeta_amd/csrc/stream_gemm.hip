@@ -50,14 +50,14 @@ __device__ __forceinline__ typename Acc<I8>::type mma(const u32x4& a, const u32x
   }
 }
 
-// MT: 16-row fragments (rows = 16 MT); NF: 16-column fragments per wave (tile = 64 NF columns); R: ring depth.
+// One workgroup's work: the tile of 64 NF columns that starts at column group ``group0`` (64 columns per group), K slice
+// ``split``.  MT: 16-row fragments (rows = 16 MT); NF: 16-column fragments per wave; R: ring depth.
 template <int MT, int NF, int R, bool I8, bool NT>
-__global__ __launch_bounds__(256, ((NF == 4 || MT * NF >= 8) ? 1 : 2)) void stream_gemm_kernel(StreamArgs a) {
+__device__ __forceinline__ void stream_tile(const StreamArgs& a, char* smem, const int group0, const int split) {
   typedef typename Acc<I8>::type acc_t;
   constexpr int kRowsT = 16 * MT;
   constexpr int kTileCols = 64 * NF;
   constexpr int kPitch = kTileCols + 4;          // floats per row of the epilogue image
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kBufBytes = kRowsT * kChunkBytes;
   constexpr int kWaveImg = 2 * NF * 2048;          // a wave's two weight images (one pair of k-steps each)
 
@@ -66,9 +66,11 @@ __global__ __launch_bounds__(256, ((NF == 4 || MT * NF >= 8) ? 1 : 2)) void stre
   const int lane = tid & 63;
   const int n = lane & 15, cq = lane >> 4;
   char* wimg = smem + 2 * kBufBytes + wave * kWaveImg;
-  const int t = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
   const int c_lo = static_cast<int>(static_cast<int64_t>(split) * a.chunks / a.splits);
   const int c_hi = static_cast<int>(static_cast<int64_t>(split + 1) * a.chunks / a.splits);
+  // The last chunk of a row may be partial (K a multiple of 128 bytes, not of 512): x is staged as zeros past the
+  // end of the row and the weight loads of those k-steps re-read the row's last whole line, so they add nothing.
+  const int piece_off = (tid & (kPieces - 1)) * 16;      // this thread's 16-byte piece inside a chunk (the same for every j)
 
   // staging geometry: 16-byte piece idx = j * 256 + tid of the [rows][32 pieces] chunk image
   constexpr int kStage = kRowsT * kPieces / 256;   // pieces per thread
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256, ((NF == 4 || MT * NF >= 8) ? 1 : 2)) void stre
 
   {
     const int nsteps = (c_hi - c_lo) * kChunkSteps;
-    const int col0 = t * kTileCols + wave * 16 * NF;
+    const int col0 = group0 * 64 + wave * 16 * NF;
 
     // weight loads: group i = 16 rows, sub j = its rows 8j .. 8j+7; lane = (row l / 8, piece l % 8) of a 128-byte line.
     // The lane's piece is XOR-ed with the row (swz) so that the lane-linear LDS image serves conflict-free fragment reads.
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256, ((NF == 4 || MT * NF >= 8) ? 1 : 2)) void stre
 
     // ring of R slots, each a PAIR of k-steps = one 128-byte line of each of the wave's 16 NF rows
     u32x4 ring[R][2 * NF];
-    const int npairs = nsteps / 2;
+    const int npairs = min(nsteps / 2, (a.k_bytes - c_lo * kChunkBytes) / 128);     // whole lines of this slice
     auto issue = [&](int slot, int pair) {
       const int off = 128 * min(pair, npairs - 1);
 #pragma unroll
@@ -124,9 +126,10 @@ __global__ __launch_bounds__(256, ((NF == 4 || MT * NF >= 8) ? 1 : 2)) void stre
 
     u32x4 xs[kStage];
     auto stage_load = [&](int c) {
-      const int64_t off = static_cast<int64_t>(min(c, c_hi - 1)) * kChunkBytes;
+      const int off = min(c, c_hi - 1) * kChunkBytes;
+      const bool inside = off + piece_off < a.k_bytes;
 #pragma unroll
-      for (int j = 0; j < kStage; ++j) xs[j] = ld16g(xsrc[j] + off);
+      for (int j = 0; j < kStage; ++j) xs[j] = inside ? ld16g(xsrc[j] + off) : u32x4{0, 0, 0, 0};
     };
     auto stage_store = [&](char* buf) {
 #pragma unroll
@@ -191,28 +194,42 @@ __global__ __launch_bounds__(256, ((NF == 4 || MT * NF >= 8) ? 1 : 2)) void stre
       const int idx = j * 256 + tid;
       const int row = idx / (kTileCols / 4), c4 = idx % (kTileCols / 4);
       if (row >= a.M) continue;
-      const int col = t * kTileCols + 4 * c4;
+      const int col = group0 * 64 + 4 * c4;
       const acc_t sum = *reinterpret_cast<const acc_t*>(img + row * kPitch + 4 * c4);
       if (a.splits > 1) {
         *reinterpret_cast<acc_t*>(a.slabs + ((static_cast<int64_t>(split) * a.M + row) * a.N + col) * 4) = sum;
         continue;
+      }
+      f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias != nullptr) {
+        const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + col);
+        b = f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
       }
       f32x4 y;
       if constexpr (I8) {
         const float xs_ = a.x_scale[row];
         const f32x4 ws = *reinterpret_cast<const f32x4*>(a.w_scale + col);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = static_cast<float>(sum[e]) * xs_ * ws[e];
+        for (int e = 0; e < 4; ++e) y[e] = w8a8_scaled(sum[e], xs_, ws[e], b[e]);
       } else {
-        y = sum;
-      }
-      if (a.bias != nullptr) {
-        const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + col);
-        y += f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+        y = sum + b;
       }
       const u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
       *reinterpret_cast<u32x2*>(a.out + static_cast<int64_t>(row) * a.out_stride + col) = o;
     }
+  }
+}
+
+// Tiles [0, big) are 64 NFHI columns wide, the others 64 (NFHI - 1): with the two widths a matrix of any multiple of 64
+// columns is cut into a chosen number of workgroups (one per compute unit) whose loads differ by one fragment per wave.
+template <int MT, int NFHI, int R, bool I8, bool NT>
+__global__ __launch_bounds__(256, ((NFHI == 4 || MT * NFHI >= 8) ? 1 : 2)) void stream_gemm_kernel(StreamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
+  if (t < a.big) {
+    stream_tile<MT, NFHI, R, I8, NT>(a, smem, t * NFHI, split);
+  } else if constexpr (NFHI > 1) {
+    stream_tile<MT, NFHI - 1, R, I8, NT>(a, smem, a.big * NFHI + (t - a.big) * (NFHI - 1), split);
   }
 }
 
@@ -227,18 +244,19 @@ __global__ __launch_bounds__(256) void stream_gemm_reduce_kernel(StreamArgs a) {
   acc_t sum = acc_t{0, 0, 0, 0};
   for (int sp = 0; sp < a.splits; ++sp)
     sum += *reinterpret_cast<const acc_t*>(a.slabs + ((static_cast<int64_t>(sp) * a.M + row) * a.N + col) * 4);
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias != nullptr) {
+    const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + col);
+    b = f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+  }
   f32x4 y;
   if constexpr (I8) {
     const float xs_ = a.x_scale[row];
     const f32x4 ws = *reinterpret_cast<const f32x4*>(a.w_scale + col);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) y[e] = static_cast<float>(sum[e]) * xs_ * ws[e];
+    for (int e = 0; e < 4; ++e) y[e] = w8a8_scaled(sum[e], xs_, ws[e], b[e]);
   } else {
-    y = sum;
-  }
-  if (a.bias != nullptr) {
-    const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + col);
-    y += f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+    y = sum + b;
   }
   const u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
   *reinterpret_cast<u32x2*>(a.out + static_cast<int64_t>(row) * a.out_stride + col) = o;
@@ -268,35 +286,49 @@ int launch_stream(const StreamArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// Tuning overrides, read once: HYMETA_STREAM_NF (1, 2 or 4), HYMETA_STREAM_WGS (workgroups of a split launch).
+// Tuning overrides, read once: HYMETA_STREAM_NF (uniform tile width, 1..4), HYMETA_STREAM_WGS (workgroups to aim for),
+// HYMETA_STREAM_SPLITS (K slices), HYMETA_STREAM_RING (2 or 4).
 static int tune(const char* name) {
   const char* e = getenv(name);
   return e == nullptr ? 0 : atoi(e);
 }
 
 bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* p) {
-  if (M <= 0 || M > 64 || K_bytes % kChunkBytes != 0 || N % 64 != 0) return false;
+  if (M <= 0 || M > 64 || K_bytes % 128 != 0 || K_bytes < kChunkBytes || N % 64 != 0) return false;
   static const int nf_forced = tune("HYMETA_STREAM_NF"), splits_forced = tune("HYMETA_STREAM_SPLITS");
-  static const int ring_forced = tune("HYMETA_STREAM_RING");
-  const int chunks = K_bytes / kChunkBytes;
-  constexpr int kWant = 144;     // workgroups that draw what HBM delivers (measured: 148 whole tiles of the 7B gate_up matrix)
-  // widest tile that, cut into K slices of at least two chunks, still gives that many workgroups
-  int nf = 4;
-  while (nf > 1 && (N % (64 * nf) != 0 || static_cast<int64_t>(N / (64 * nf)) * (have_workspace ? chunks / 2 : 1) < kWant)) nf >>= 1;
-  if (nf_forced > 0) nf = nf_forced;
-  if (N % (64 * nf) != 0) return false;
-  const int tiles = N / (64 * nf);
-  int splits = 1;
-  if (have_workspace) {
-    splits = (kWant + tiles - 1) / tiles;
-    if (splits_forced > 0) splits = splits_forced;
-    if (splits > chunks) splits = chunks;
-    if (splits > kMaxSplits) splits = kMaxSplits;
-    if (splits < 1) splits = 1;
+  static const int ring_forced = tune("HYMETA_STREAM_RING"), want_forced = tune("HYMETA_STREAM_WGS");
+  const int chunks = (K_bytes + kChunkBytes - 1) / kChunkBytes;
+  const int groups = N / 64;
+  // One workgroup per compute unit draws the most: a compute unit pulls 29-35 GB/s of weights with this kernel, HBM
+  // delivers what about 190 of them ask for, and a second workgroup on a unit only lengthens the launch.
+  const int want = want_forced > 0 ? want_forced : 256;
+  int tiles, nf_lo, big;
+  if (nf_forced > 0) {                       // uniform tiles of the forced width
+    if (groups % nf_forced != 0) return false;
+    tiles = groups / nf_forced, nf_lo = nf_forced, big = 0;
+  } else if (groups >= want) {               // wide matrix: `want` tiles (more when they would pass 256 columns), two widths
+    tiles = want > (groups + 3) / 4 ? want : (groups + 3) / 4;
+    nf_lo = groups / tiles, big = groups - nf_lo * tiles;
+  } else {
+    // narrow matrix: K slices make up the count.  Tiles of 128 columns for the large ones (x is re-read once per
+    // tile, the slabs grow with the slices); 64 columns for the small ones, whose time is mostly fixed cost and
+    // which then need the fewest slices.  Measured on the 7B shapes at 16 and 64 rows.
+    int nf = static_cast<int64_t>(N) * K_bytes >= (64ll << 20) && groups % 2 == 0 ? 2 : 1;
+    if (!have_workspace) nf = 1;
+    tiles = groups / nf, nf_lo = nf, big = 0;
   }
-  p->nf = nf, p->tiles = tiles, p->chunks = chunks, p->splits = splits;
+  int splits = 1;
+  if (have_workspace && tiles < want) splits = want / tiles;
+  if (splits > (chunks + 1) / 2) splits = (chunks + 1) / 2;      // slices of at least two chunks
+  if (have_workspace && splits_forced > 0) splits = splits_forced;
+  if (splits > chunks) splits = chunks;
+  if (splits > kMaxSplits) splits = kMaxSplits;
+  if (splits < 1) splits = 1;
+  // the kernel is instantiated on the wider of the two widths; `big` counts the tiles that have it
+  p->nf = big > 0 ? nf_lo + 1 : nf_lo, p->big = big > 0 ? big : tiles;
+  p->tiles = tiles, p->chunks = chunks, p->splits = splits;
   p->ring = ring_forced == 4 || ring_forced == 2 ? ring_forced : 2;
-  return true;
+  return p->nf <= 4;
 }
 
 size_t stream_gemm_workspace_bytes(int M, int N, const StreamPlan& p) {
@@ -309,13 +341,14 @@ size_t stream_gemm_workspace_bound(int M, int N) {
 
 template <bool I8>
 int stream_gemm_launch(StreamArgs a, const StreamPlan& p, hipStream_t s) {
-  a.tiles = p.tiles, a.chunks = p.chunks, a.splits = p.splits;
+  a.tiles = p.tiles, a.big = p.big, a.chunks = p.chunks, a.splits = p.splits;
+  if (a.k_bytes <= 0 || (a.k_bytes + kChunkBytes - 1) / kChunkBytes != p.chunks) return HYMETA_ERR_INVALID_ARG;
   const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
 #define HYMETA_STREAM_CASE(MT_, NF_) \
   if (mt == MT_ && p.nf == NF_) return p.ring == 4 ? launch_stream<MT_, NF_, I8, 4>(a, s) : launch_stream<MT_, NF_, I8, 2>(a, s);
-  HYMETA_STREAM_CASE(1, 1) HYMETA_STREAM_CASE(1, 2) HYMETA_STREAM_CASE(1, 4)
-  HYMETA_STREAM_CASE(2, 1) HYMETA_STREAM_CASE(2, 2) HYMETA_STREAM_CASE(2, 4)
-  HYMETA_STREAM_CASE(4, 1) HYMETA_STREAM_CASE(4, 2) HYMETA_STREAM_CASE(4, 4)
+  HYMETA_STREAM_CASE(1, 1) HYMETA_STREAM_CASE(1, 2) HYMETA_STREAM_CASE(1, 3) HYMETA_STREAM_CASE(1, 4)
+  HYMETA_STREAM_CASE(2, 1) HYMETA_STREAM_CASE(2, 2) HYMETA_STREAM_CASE(2, 3) HYMETA_STREAM_CASE(2, 4)
+  HYMETA_STREAM_CASE(4, 1) HYMETA_STREAM_CASE(4, 2) HYMETA_STREAM_CASE(4, 3) HYMETA_STREAM_CASE(4, 4)
 #undef HYMETA_STREAM_CASE
   return HYMETA_ERR_UNSUPPORTED;
 }
