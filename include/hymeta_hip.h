@@ -610,6 +610,17 @@ int hymeta_bf16_gemm_split_k(int32_t M, int32_t K, int32_t N);
 size_t hymeta_bf16_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream);
 
+/* The gate/up projection of a gated MLP with its activation in the GEMM's epilogue, for decode-sized batches:
+ * weight = [gate rows | up rows] (N rows in all, the fused gate_up_proj), out bf16 [M, N / 2] =
+ * silu(x gate^T) * (x up^T), both factors rounded to bf16 before the product -- the arithmetic of
+ * hymeta_bf16_gemm followed by hymeta_silu_and_mul (the same bits whenever that call sums K in one slice),
+ * in one launch and without the [M, N] intermediate.
+ * Replaces MergedColumnParallelLinear + SiluAndMul in the MLP forward
+ * (vllm_hymeta/model_for_7B/modeling_gla_swa.py:108-121, vllm_hymeta/models/modeling_hymeta.py:262-271).
+ * bias must be NULL, the workspace fields are ignored.  Takes M <= 64, K % 64 == 0, N % 128 == 0;
+ * other shapes are HYMETA_ERR_UNSUPPORTED: run the two calls. */
+int hymeta_bf16_gemm_silu_mul(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * W8A8 int8 linear: per-output-channel int8 weights, dynamic per-token int8
  * activations (compressed-tensors "W8A8" as written by hf_model/quant_w8a8.py:121-132
@@ -640,6 +651,40 @@ int hymeta_w8a8_gemm_split_k(int32_t M, int32_t K, int32_t N);
 size_t hymeta_w8a8_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 
 int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream);
+
+/* W8A8 form of hymeta_bf16_gemm_silu_mul (same layout, same rule: equals hymeta_w8a8_gemm followed by
+ * hymeta_silu_and_mul bit for bit).  bias must be NULL; M <= 64, K % 128 == 0, N % 128 == 0. */
+int hymeta_w8a8_gemm_silu_mul(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K-sliced linears whose slice sum is left to the consumer.
+ * A decode-sized linear with few output columns (o_proj / out_proj / down_proj) is cut along K so that every
+ * compute unit streams weights; its slices' partial sums then have to be added.  The *_deferred calls stop
+ * before that sum and describe the partial sums; hymeta_add_rmsnorm_partials -- the fused residual add + RMS
+ * norm that follows those projections in the decoder block (model_for_7B/modeling_gla_swa.py:294-302,
+ * models/modeling_hymeta.py:1024-1039) -- adds them as it reads its input, which saves the reduce launch and
+ * one pass over the output.  Values are those of the plain calls: slices added in slice order, bias (and the
+ * W8A8 scales) applied, the sum rounded to bf16 before the residual add.
+ * The partial sums live in the GEMM call's workspace: consume them before the next call that uses it.
+ * ---------------------------------------------------------------------- */
+typedef struct hymeta_gemm_partials {
+  const void* slabs;     /* [splits][M][N] fp32 (bf16 linear) or int32 (W8A8) */
+  int32_t splits;        /* 0: the call wrote `out` itself (no K slices): nothing is deferred */
+  int32_t is_int32;
+  const float* x_scale;  /* W8A8: fp32 [M] activation scales (the args' x_scale buffer) */
+  const float* w_scale;  /* W8A8: fp32 [N] */
+  const void* bias;      /* bf16 [N] or NULL */
+  int32_t M, N;
+} hymeta_gemm_partials;
+
+int hymeta_bf16_gemm_deferred(const hymeta_bf16_gemm_args* args, hymeta_gemm_partials* partials, hymeta_stream_t stream);
+int hymeta_w8a8_gemm_deferred(const hymeta_w8a8_gemm_args* args, hymeta_gemm_partials* partials, hymeta_stream_t stream);
+/* out bf16 [M, N] = the linear's result (what the plain call would have written). */
+int hymeta_gemm_partials_reduce(const hymeta_gemm_partials* partials, void* out, int64_t out_stride_m, hymeta_stream_t stream);
+/* hymeta_add_rmsnorm with x = the linear's result taken from its partial sums (args->x is ignored; args->residual
+ * must be given; num_tokens == M, hidden == N). */
+int hymeta_add_rmsnorm_partials(const hymeta_add_rmsnorm_args* args, const hymeta_gemm_partials* partials, hymeta_stream_t stream);
+
 
 /* The two ends of the same linear for prefill-sized M, where the host side puts a library int8
  * GEMM (exact int32 sums) between them instead of the fused kernel, the choice vLLM's scaled_mm

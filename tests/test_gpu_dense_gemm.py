@@ -77,3 +77,83 @@ def test_bf16_gemm_strided_views_and_linear_dispatch():
             assert_bf16_close(lin(xin).cpu(), ref, f"linear {tuple(wt.shape)}, {xin.shape[0]} rows")
     with pytest.raises(Exception):
         hip_ops.bf16_gemm(big, w, b)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "w8a8"])
+@pytest.mark.parametrize("M,K,I", [(64, 3584, 18944), (1, 3584, 18944), (33, 3584, 4736), (16, 320, 64), (40, 1024, 8256)])
+def test_gate_up_projection_with_the_activation_in_its_epilogue(kind, M, K, I):
+    """7B / 70B TP=4 gate_up shapes and small ones (one tile; two tile widths): the fused launch gives the bits of the
+    linear followed by silu_and_mul (where that linear sums in the same order), and matches the fp64 restatement within the bf16 tolerance."""
+    from oracle.quant import w8a8_gemm_ref
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta.linear import HymetaLinear
+
+    g_ = gen(M + K + I)
+    x = randn_bf16(g_, M, K)
+    if kind == "bf16":
+        w = randn_bf16(g_, 2 * I, K, scale=K ** -0.5)
+        lin = HymetaLinear.from_weight(w.cuda())
+        y = (x.double() @ w.double().t()) if M * K * I < 1e9 else (x.float() @ w.float().t()).double()
+    else:
+        if K % 128:
+            pytest.skip("int8 rows of K bytes: K must be a multiple of 128")
+        wq = torch.randint(-127, 128, (2 * I, K), generator=g_, dtype=torch.int8)
+        ws = torch.rand(2 * I, generator=g_) * 0.02 + 0.001
+        lin = HymetaLinear.from_w8a8(wq.cuda(), ws.cuda())
+        y = w8a8_gemm_ref(x, wq, ws, None)
+    xd = x.cuda()
+    assert hip_ops.gemm_silu_mul_supported(xd, lin.weight if kind == "bf16" else lin.qweight)
+    fused = lin.forward_silu_mul(xd)
+    two_step = hip_ops.silu_and_mul(lin(xd))
+    torch.cuda.synchronize()
+    assert fused.shape == (M, I)
+    if I == 18944 or kind == "w8a8":
+        # the plain linear runs these shapes without K slices (or sums exact integers): the same bits
+        assert torch.equal(fused, two_step)
+    else:
+        # K slices change the order of the fp32 sums: a factor may round to the neighbouring bf16 value
+        assert_bf16_ulp(fused, two_step, "fused vs linear + silu_and_mul", ulps=4)
+    yb = y.to(torch.bfloat16).double()
+    ref = torch.nn.functional.silu(yb[:, :I]) * yb[:, I:]
+    assert_bf16_close(fused.cpu(), ref, f"gated {kind} M={M} K={K} I={I}", rel=2e-2, frac=2.0 ** -6)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "w8a8"])
+@pytest.mark.parametrize("M,K,N,bias", [(64, 3584, 3584, False), (33, 18944, 3584, True), (17, 896, 3584, False)])
+def test_k_slice_sum_left_to_the_fused_add_rmsnorm(kind, M, K, N, bias):
+    """o_proj / down_proj shapes: the linear stops at its K slices' partial sums and the residual add + RMS norm adds
+    them while reading; normed output, updated residual and the materialised linear equal the plain calls bit for bit."""
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta.linear import HymetaLinear
+
+    g_ = gen(M + K + N)
+    x = randn_bf16(g_, M, K).cuda()
+    b = randn_bf16(g_, N).cuda() if bias else None
+    if kind == "bf16":
+        lin = HymetaLinear.from_weight(randn_bf16(g_, N, K, scale=K ** -0.5).cuda(), b)
+    else:
+        if K % 128:
+            pytest.skip("int8 rows of K bytes: K must be a multiple of 128")
+        lin = HymetaLinear.from_w8a8(torch.randint(-127, 128, (N, K), generator=g_, dtype=torch.int8).cuda(),
+                                     (torch.rand(N, generator=g_) * 0.02 + 0.001).cuda(), b)
+    w = (1 + 0.1 * torch.randn(N, generator=g_)).to(torch.bfloat16).cuda()
+    res = randn_bf16(g_, M, N).cuda()
+    y = lin(x)
+    r1 = res.clone()
+    out1 = hip_ops.add_rmsnorm(y, w, 1e-6, residual=r1)
+    part = lin(x, defer=True)
+    if kind == "w8a8" and K < 1024:
+        # two chunks of int8 K: one slice, nothing to defer -- the call returns the finished tensor
+        assert torch.equal(part, y)
+        return
+    assert isinstance(part, hip_ops.PartialSums) and part.shape == (M, N), "these shapes are cut into K slices"
+    r2 = res.clone()
+    out2 = hip_ops.add_rmsnorm(part, w, 1e-6, residual=r2)
+    again = lin(x, defer=True).tensor()
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out2) and torch.equal(r1, r2) and torch.equal(again, y)
+    # partial sums overwritten by the next linear of the kind are refused, not read
+    stale = lin(x, defer=True)
+    lin(x)
+    with pytest.raises(ValueError):
+        hip_ops.add_rmsnorm(stale, w, 1e-6, residual=r2)

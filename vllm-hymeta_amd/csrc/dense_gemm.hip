@@ -163,8 +163,9 @@ extern "C" size_t hymeta_bf16_gemm_workspace_bytes(int32_t M, int32_t N, int32_t
   return counters + static_cast<size_t>(split_k) * M * N * sizeof(float);
 }
 
-extern "C" int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream) {
+static int bf16_gemm_impl(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream, hymeta_gemm_partials* deferred) {
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (deferred != nullptr) *deferred = hymeta_gemm_partials{};
   const hymeta_bf16_gemm_args& a = *args;
   if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;
@@ -187,7 +188,11 @@ extern "C" int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream
       sa.slabs = have_ws ? static_cast<char*>(a.workspace) + kTicketBytes : nullptr;
       sa.M = a.M, sa.N = a.N, sa.k_bytes = a.K * 2;
       sa.x_stride_bytes = a.x_stride_m * 2, sa.w_stride_bytes = a.w_stride_n * 2, sa.out_stride = a.out_stride_m;
-      return stream_gemm_launch<false>(sa, plan, begin_launches(stream));
+      if (deferred != nullptr && plan.splits > 1) {
+        deferred->slabs = sa.slabs, deferred->splits = plan.splits, deferred->bias = a.bias;
+        deferred->M = a.M, deferred->N = a.N;
+      }
+      return stream_gemm_launch<false>(sa, plan, begin_launches(stream), deferred != nullptr);
     }
   }
   const int ksteps = a.K / 32;
@@ -210,4 +215,37 @@ extern "C" int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream
   else if (mt == 2) hipLaunchKernelGGL((bf16_skinny_gemm_kernel<2>), grid, block, lds, s, a, splits, sps, slabs, counters);
   else hipLaunchKernelGGL((bf16_skinny_gemm_kernel<4>), grid, block, lds, s, a, splits, sps, slabs, counters);
   return launch_status();
+}
+
+extern "C" int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream) {
+  return bf16_gemm_impl(args, stream, nullptr);
+}
+
+extern "C" int hymeta_bf16_gemm_deferred(const hymeta_bf16_gemm_args* args, hymeta_gemm_partials* partials,
+                                         hymeta_stream_t stream) {
+  if (partials == nullptr) return HYMETA_ERR_INVALID_ARG;
+  return bf16_gemm_impl(args, stream, partials);
+}
+
+// Gate/up projection with the activation in the epilogue: out [M, N / 2] = silu(x gate^T) * (x up^T), weight = [gate rows |
+// up rows].  Only the shapes the streaming kernel takes whole (no K slices); others are HYMETA_ERR_UNSUPPORTED and the
+// caller runs hymeta_bf16_gemm + hymeta_silu_and_mul, which give the same bits.
+extern "C" int hymeta_bf16_gemm_silu_mul(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream) {
+  using namespace hymeta;
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_bf16_gemm_args& a = *args;
+  if (a.M < 0 || a.K <= 0 || a.N <= 0 || a.bias != nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (a.M == 0) return HYMETA_OK;
+  if (!a.x || !a.weight || !a.out) return HYMETA_ERR_INVALID_ARG;
+  if ((a.x_stride_m | a.w_stride_n | a.out_stride_m) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.weight) | reinterpret_cast<uintptr_t>(a.out)) % 16 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  StreamPlan plan;
+  if (a.K > (1 << 28) || !stream_gemm_plan_gated(a.M, a.K * 2, a.N, &plan)) return HYMETA_ERR_UNSUPPORTED;
+  StreamArgs sa = {};
+  sa.x = static_cast<const char*>(a.x), sa.w = static_cast<const char*>(a.weight);
+  sa.out = static_cast<uint16_t*>(a.out);
+  sa.M = a.M, sa.N = a.N, sa.k_bytes = a.K * 2, sa.gated = 1;
+  sa.x_stride_bytes = a.x_stride_m * 2, sa.w_stride_bytes = a.w_stride_n * 2, sa.out_stride = a.out_stride_m;
+  return stream_gemm_launch<false>(sa, plan, begin_launches(stream));
 }

@@ -152,9 +152,99 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(hymeta_add_rmsnorm_arg
   }
 }
 
+// add_rmsnorm_kernel<true> whose x is a K-sliced linear's result still in partial sums: slices added in slice order,
+// W8A8 scales and the bias applied, the sum rounded to bf16 -- the bits the linear's own reduce launch would have
+// written -- then z = bf16(x + residual) as above.
+template <bool I8>
+__global__ __launch_bounds__(256) void add_rmsnorm_partials_kernel(hymeta_add_rmsnorm_args a, hymeta_gemm_partials p) {
+  __shared__ float s_red[4];
+  const int64_t t = blockIdx.x;
+  uint16_t* res = reinterpret_cast<uint16_t*>(a.residual) + t * a.residual_stride_t;
+  const uint16_t* w = reinterpret_cast<const uint16_t*>(a.weight);
+  const uint16_t* bias = static_cast<const uint16_t*>(p.bias);
+  uint16_t* out = reinterpret_cast<uint16_t*>(a.out) + t * a.out_stride_t;
+  const int chunks = a.hidden / 8;
+  const int64_t slab = static_cast<int64_t>(p.M) * p.N;
+  const float xs = I8 ? p.x_scale[t] : 0.f;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+    float x[8];
+    if constexpr (I8) {
+      const int32_t* src = static_cast<const int32_t*>(p.slabs) + t * p.N + 8 * c;
+      int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int sp = 0; sp < p.splits; ++sp) {
+        const u32x4 lo = ld16(src + sp * slab), hi = ld16(src + sp * slab + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += static_cast<int>(lo[e]), acc[4 + e] += static_cast<int>(hi[e]);
+      }
+      float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (bias != nullptr) {
+        const u32x4 bw = ld16(bias + 8 * c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[2 * i] = lo_bf(bw[i]), b[2 * i + 1] = hi_bf(bw[i]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = w8a8_scaled(acc[e], xs, p.w_scale[8 * c + e], b[e]);
+    } else {
+      const float* src = static_cast<const float*>(p.slabs) + t * p.N + 8 * c;
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      for (int sp = 0; sp < p.splits; ++sp) {
+        lo += *reinterpret_cast<const f32x4*>(src + sp * slab);
+        hi += *reinterpret_cast<const f32x4*>(src + sp * slab + 4);
+      }
+      if (bias != nullptr) {
+        const u32x4 bw = ld16(bias + 8 * c);
+        lo += f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+        hi += f32x4{lo_bf(bw[2]), hi_bf(bw[2]), lo_bf(bw[3]), hi_bf(bw[3])};
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = lo[e], x[4 + e] = hi[e];
+    }
+    const u32x4 r = ld16(res + 8 * c);
+    u32x4 z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      z[i] = pack_bf16x2(bf16_round(x[2 * i]) + lo_bf(r[i]), bf16_round(x[2 * i + 1]) + hi_bf(r[i]));
+    st16(res + 8 * c, z);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float z0 = lo_bf(z[i]), z1 = hi_bf(z[i]);
+      ss += z0 * z0 + z1 * z1;
+    }
+  }
+  const float rs = rsqrtf(block_sum_256(ss, s_red) / a.hidden + a.eps);
+  for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+    const u32x4 z = ld16(res + 8 * c), wv = ld16(w + 8 * c);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      o[i] = pack_bf16x2(bf16_round(lo_bf(z[i]) * rs) * lo_bf(wv[i]), bf16_round(hi_bf(z[i]) * rs) * hi_bf(wv[i]));
+    st16(out + 8 * c, o);
+  }
+}
+
 }  // namespace hymeta
 
 using namespace hymeta;
+
+extern "C" int hymeta_add_rmsnorm_partials(const hymeta_add_rmsnorm_args* args, const hymeta_gemm_partials* partials,
+                                           hymeta_stream_t stream) {
+  if (args == nullptr || partials == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_add_rmsnorm_args& a = *args;
+  const hymeta_gemm_partials& p = *partials;
+  if (a.num_tokens < 0 || a.hidden <= 0 || p.splits < 1 || !p.slabs) return HYMETA_ERR_INVALID_ARG;
+  if (a.num_tokens != p.M || a.hidden != p.N) return HYMETA_ERR_INVALID_ARG;
+  if (a.num_tokens == 0) return HYMETA_OK;
+  if (!a.residual || !a.weight || !a.out) return HYMETA_ERR_INVALID_ARG;
+  if (p.is_int32 && (!p.x_scale || !p.w_scale)) return HYMETA_ERR_INVALID_ARG;
+  if (a.hidden % 8 != 0 || (a.out_stride_t | a.residual_stride_t) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(p.slabs) | reinterpret_cast<uintptr_t>(a.residual) | reinterpret_cast<uintptr_t>(a.weight) |
+       reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(p.bias)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  hipStream_t s = begin_launches(stream);
+  if (p.is_int32) hipLaunchKernelGGL((add_rmsnorm_partials_kernel<true>), dim3(a.num_tokens), dim3(256), 0, s, a, p);
+  else hipLaunchKernelGGL((add_rmsnorm_partials_kernel<false>), dim3(a.num_tokens), dim3(256), 0, s, a, p);
+  return launch_status();
+}
 
 extern "C" int hymeta_rope_neox(const hymeta_rope_args* args, hymeta_stream_t stream) {
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;

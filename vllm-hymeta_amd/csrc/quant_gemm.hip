@@ -1064,8 +1064,9 @@ extern "C" size_t hymeta_w8a8_gemm_workspace_bytes(int32_t M, int32_t N, int32_t
   return kTicketBytes + static_cast<size_t>(split_k) * M * N * sizeof(int);
 }
 
-extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream) {
+static int w8a8_gemm_impl(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream, hymeta_gemm_partials* deferred) {
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (deferred != nullptr) *deferred = hymeta_gemm_partials{};
   const hymeta_w8a8_gemm_args& a = *args;
   if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;
@@ -1094,7 +1095,12 @@ extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream
       sa.slabs = have_ws ? static_cast<char*>(a.workspace) + kTicketBytes : nullptr;
       sa.M = a.M, sa.N = a.N, sa.k_bytes = a.K;
       sa.x_stride_bytes = a.K, sa.w_stride_bytes = a.K, sa.out_stride = a.out_stride_m;
-      return stream_gemm_launch<true>(sa, plan, s);
+      if (deferred != nullptr && plan.splits > 1) {
+        deferred->slabs = sa.slabs, deferred->splits = plan.splits, deferred->is_int32 = 1, deferred->bias = a.bias;
+        deferred->x_scale = a.x_scale, deferred->w_scale = a.w_scale;
+        deferred->M = a.M, deferred->N = a.N;
+      }
+      return stream_gemm_launch<true>(sa, plan, s, deferred != nullptr);
     }
   }
   const int ksteps = a.K / 64;
@@ -1146,4 +1152,42 @@ extern "C" int hymeta_w8a8_scale_out(const int32_t* acc, const float* x_scale, c
                      acc, x_scale, w_scale, static_cast<const uint16_t*>(bias), static_cast<uint16_t*>(out), M, N, acc_stride_m,
                      out_stride_m);
   return launch_status();
+}
+
+extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream) {
+  return w8a8_gemm_impl(args, stream, nullptr);
+}
+
+extern "C" int hymeta_w8a8_gemm_deferred(const hymeta_w8a8_gemm_args* args, hymeta_gemm_partials* partials,
+                                         hymeta_stream_t stream) {
+  if (partials == nullptr) return HYMETA_ERR_INVALID_ARG;
+  return w8a8_gemm_impl(args, stream, partials);
+}
+
+// W8A8 gate/up projection with the activation in the epilogue (see hymeta_bf16_gemm_silu_mul): quantises x per row, then
+// out [M, N / 2] = silu(gate) * up from the int8 sums.  Shapes the streaming kernel does not take whole are
+// HYMETA_ERR_UNSUPPORTED (the caller runs hymeta_w8a8_gemm + hymeta_silu_and_mul: same bits).
+extern "C" int hymeta_w8a8_gemm_silu_mul(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream) {
+  using namespace hymeta;
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_w8a8_gemm_args& a = *args;
+  if (a.M < 0 || a.K <= 0 || a.N <= 0 || a.bias != nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (a.M == 0) return HYMETA_OK;
+  if (!a.x || !a.qweight || !a.w_scale || !a.out || !a.xq || !a.x_scale) return HYMETA_ERR_INVALID_ARG;
+  if (a.K % 64 != 0 || (a.x_stride_m | a.out_stride_m) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.qweight) | reinterpret_cast<uintptr_t>(a.out) |
+       reinterpret_cast<uintptr_t>(a.xq) | reinterpret_cast<uintptr_t>(a.w_scale)) % 16 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  StreamPlan plan;
+  if (!stream_gemm_plan_gated(a.M, a.K, a.N, &plan)) return HYMETA_ERR_UNSUPPORTED;
+  hipStream_t s = begin_launches(stream);
+  hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
+  if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+  StreamArgs sa = {};
+  sa.x = reinterpret_cast<const char*>(a.xq), sa.w = reinterpret_cast<const char*>(a.qweight);
+  sa.out = static_cast<uint16_t*>(a.out);
+  sa.x_scale = a.x_scale, sa.w_scale = a.w_scale;
+  sa.M = a.M, sa.N = a.N, sa.k_bytes = a.K, sa.gated = 1;
+  sa.x_stride_bytes = a.K, sa.w_stride_bytes = a.K, sa.out_stride = a.out_stride_m;
+  return stream_gemm_launch<true>(sa, plan, s);
 }

@@ -16,6 +16,8 @@ struct StreamArgs {
   int M, N;
   int k_bytes;            // bytes of one row of x / W that hold K (a multiple of 128)
   int64_t x_stride_bytes, w_stride_bytes, out_stride;
+  int gated;              // 1: W = [gate rows | up rows] (N / 2 each), out [M, N / 2] = bf16(silu(bf16(x gate^T)) * bf16(x up^T));
+                          // no bias, no K slices
   int tiles, big, chunks, splits;    // filled from the plan
 };
 
@@ -30,11 +32,14 @@ struct StreamPlan {
 // Whether the streaming kernel takes the shape (M <= 64 rows, K a multiple of 128 bytes and at least 512, N of 64 columns), and how
 // it is cut (one workgroup per compute unit where the shape allows).  Without a workspace every workgroup owns whole tiles (no slabs).
 bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* plan);
+// Gated form (see StreamArgs::gated): N counts the gate and the up rows together and must be a multiple of 128.
+bool stream_gemm_plan_gated(int M, int K_bytes, int N, StreamPlan* plan);
 // Slab bytes of that plan (0 without K slices); no ticket counters are used.
 size_t stream_gemm_workspace_bytes(int M, int N, const StreamPlan& plan);
 // A bound on stream_gemm_workspace_bytes over every plan the library may choose for (M, N).
 size_t stream_gemm_workspace_bound(int M, int N);
+// defer_reduce: with K slices, stop after the slabs are written (the caller hands them to a consumer that sums them).
 template <bool I8>
-int stream_gemm_launch(StreamArgs args, const StreamPlan& plan, hipStream_t stream);
+int stream_gemm_launch(StreamArgs args, const StreamPlan& plan, hipStream_t stream, bool defer_reduce = false);
 
 }  // namespace hymeta

@@ -90,7 +90,12 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, char* smem, con
 
   {
     const int nsteps = (c_hi - c_lo) * kChunkSteps;
+    // plain: the wave's 16 NF weight rows are consecutive output columns.  Gated: fragment i holds 8 gate rows and the
+    // 8 up rows of the same output columns (rows 8 j .. 8 j + 7 of a fragment are sub-load j), so that a lane's
+    // neighbour 8 columns on holds the other factor and the product is formed in the epilogue image.
     const int col0 = group0 * 64 + wave * 16 * NF;
+    const int ocol0 = group0 * 32 + wave * 8 * NF;           // gated: first output column of the wave
+    const int up0 = a.N / 2;
 
     // weight loads: group i = 16 rows, sub j = its rows 8j .. 8j+7; lane = (row l / 8, piece l % 8) of a 128-byte line.
     // The lane's piece is XOR-ed with the row (swz) so that the lane-linear LDS image serves conflict-free fragment reads.
@@ -100,7 +105,8 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, char* smem, con
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int r = 8 * j + (lane >> 3);
-        wl[i][j] = a.w + static_cast<int64_t>(col0 + 16 * i + r) * a.w_stride_bytes + static_cast<int64_t>(c_lo) * kChunkBytes +
+        const int wrow = a.gated ? (j ? up0 : 0) + ocol0 + 8 * i + (lane >> 3) : col0 + 16 * i + r;
+        wl[i][j] = a.w + static_cast<int64_t>(wrow) * a.w_stride_bytes + static_cast<int64_t>(c_lo) * kChunkBytes +
                    (((lane & 7) ^ ((r >> 1) & 7)) * 16);
       }
 
@@ -188,6 +194,39 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, char* smem, con
           img[(16 * mt + 4 * cq + r) * kPitch + wave * 16 * NF + 16 * i + n] = v;
         }
     __syncthreads();
+    if (a.gated) {
+      // image column 16 f + n of fragment f: n < 8 the gate of output column 8 f + n, n >= 8 the up factor of 8 f + n - 8
+      for (int idx = tid; idx < kRowsT * 8 * NF; idx += 256) {
+        const int row = idx / (8 * NF), v = idx % (8 * NF);     // v: 4-column vector of the tile's 32 NF output columns
+        if (row >= a.M) continue;
+        const int f = v >> 1, within = 4 * (v & 1);
+        const acc_t g4 = *reinterpret_cast<const acc_t*>(img + row * kPitch + 16 * f + within);
+        const acc_t u4 = *reinterpret_cast<const acc_t*>(img + row * kPitch + 16 * f + 8 + within);
+        const int ocol = group0 * 32 + 8 * f + within;
+        float g[4], u[4];
+        if constexpr (I8) {
+          const float xs_ = a.x_scale[row];
+          const f32x4 wg = *reinterpret_cast<const f32x4*>(a.w_scale + ocol);
+          const f32x4 wu = *reinterpret_cast<const f32x4*>(a.w_scale + up0 + ocol);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = w8a8_scaled(g4[e], xs_, wg[e], 0.f), u[e] = w8a8_scaled(u4[e], xs_, wu[e], 0.f);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = g4[e], u[e] = u4[e];
+        }
+        // both factors rounded to bf16 first, as the two-kernel form (linear, then silu_and_mul) holds them
+        const uint32_t gp[2] = {pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3])};
+        const uint32_t up[2] = {pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3])};
+        u32x2 o;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float g0 = lo_bf(gp[e]), g1 = hi_bf(gp[e]);
+          o[e] = pack_bf16x2(g0 * sigmoidf(g0) * lo_bf(up[e]), g1 * sigmoidf(g1) * hi_bf(up[e]));
+        }
+        *reinterpret_cast<u32x2*>(a.out + static_cast<int64_t>(row) * a.out_stride + ocol) = o;
+      }
+      return;
+    }
     constexpr int kVecs = kRowsT * kTileCols / 4 / 256;      // 4-column vectors per thread
 #pragma unroll
     for (int j = 0; j < kVecs; ++j) {
@@ -263,7 +302,7 @@ __global__ __launch_bounds__(256) void stream_gemm_reduce_kernel(StreamArgs a) {
 }
 
 template <int MT, int NF, bool I8, int RING>
-int launch_stream(const StreamArgs& a, hipStream_t s) {
+int launch_stream(const StreamArgs& a, hipStream_t s, bool defer_reduce) {
   constexpr int R = RING;     // pairs of k-steps in flight per wave
   constexpr size_t img = static_cast<size_t>(16 * MT) * (64 * NF + 4) * 4;                 // epilogue image
   constexpr size_t stream = 2u * 16 * MT * kChunkBytes + 4u * 2 * NF * 2048;                  // x chunks + the waves' weight images
@@ -276,7 +315,7 @@ int launch_stream(const StreamArgs& a, hipStream_t s) {
     configured = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.tiles * a.splits), dim3(256), lds, s, a);
-  if (a.splits > 1) {
+  if (a.splits > 1 && !defer_reduce) {
     if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
     const int64_t threads = static_cast<int64_t>(a.M) * (a.N / 4);
     hipLaunchKernelGGL(stream_gemm_reduce_kernel<I8>, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, s, a);
@@ -331,6 +370,10 @@ bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan
   return p->nf <= 4;
 }
 
+bool stream_gemm_plan_gated(int M, int K_bytes, int N, StreamPlan* p) {
+  return N % 128 == 0 && stream_gemm_plan(M, K_bytes, N, false, p) && p->splits == 1;
+}
+
 size_t stream_gemm_workspace_bytes(int M, int N, const StreamPlan& p) {
   return p.splits > 1 ? static_cast<size_t>(p.splits) * M * N * 4 : 0;
 }
@@ -340,12 +383,13 @@ size_t stream_gemm_workspace_bound(int M, int N) {
 }
 
 template <bool I8>
-int stream_gemm_launch(StreamArgs a, const StreamPlan& p, hipStream_t s) {
+int stream_gemm_launch(StreamArgs a, const StreamPlan& p, hipStream_t s, bool defer_reduce) {
   a.tiles = p.tiles, a.big = p.big, a.chunks = p.chunks, a.splits = p.splits;
   if (a.k_bytes <= 0 || (a.k_bytes + kChunkBytes - 1) / kChunkBytes != p.chunks) return HYMETA_ERR_INVALID_ARG;
+  if (a.gated && (p.splits != 1 || a.bias != nullptr || a.N % 128 != 0)) return HYMETA_ERR_INVALID_ARG;
   const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
 #define HYMETA_STREAM_CASE(MT_, NF_) \
-  if (mt == MT_ && p.nf == NF_) return p.ring == 4 ? launch_stream<MT_, NF_, I8, 4>(a, s) : launch_stream<MT_, NF_, I8, 2>(a, s);
+  if (mt == MT_ && p.nf == NF_) return p.ring == 4 ? launch_stream<MT_, NF_, I8, 4>(a, s, defer_reduce) : launch_stream<MT_, NF_, I8, 2>(a, s, defer_reduce);
   HYMETA_STREAM_CASE(1, 1) HYMETA_STREAM_CASE(1, 2) HYMETA_STREAM_CASE(1, 3) HYMETA_STREAM_CASE(1, 4)
   HYMETA_STREAM_CASE(2, 1) HYMETA_STREAM_CASE(2, 2) HYMETA_STREAM_CASE(2, 3) HYMETA_STREAM_CASE(2, 4)
   HYMETA_STREAM_CASE(4, 1) HYMETA_STREAM_CASE(4, 2) HYMETA_STREAM_CASE(4, 3) HYMETA_STREAM_CASE(4, 4)
@@ -353,7 +397,28 @@ int stream_gemm_launch(StreamArgs a, const StreamPlan& p, hipStream_t s) {
   return HYMETA_ERR_UNSUPPORTED;
 }
 
-template int stream_gemm_launch<false>(StreamArgs, const StreamPlan&, hipStream_t);
-template int stream_gemm_launch<true>(StreamArgs, const StreamPlan&, hipStream_t);
+template int stream_gemm_launch<false>(StreamArgs, const StreamPlan&, hipStream_t, bool);
+template int stream_gemm_launch<true>(StreamArgs, const StreamPlan&, hipStream_t, bool);
 
 }  // namespace hymeta
+
+extern "C" int hymeta_gemm_partials_reduce(const hymeta_gemm_partials* partials, void* out, int64_t out_stride_m,
+                                           hymeta_stream_t stream) {
+  using namespace hymeta;
+  if (partials == nullptr || out == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_gemm_partials& p = *partials;
+  if (p.splits < 1 || p.M <= 0 || p.N <= 0 || p.N % 4 != 0 || !p.slabs) return HYMETA_ERR_INVALID_ARG;
+  if (p.is_int32 && (!p.x_scale || !p.w_scale)) return HYMETA_ERR_INVALID_ARG;
+  if (out_stride_m % 4 != 0 || reinterpret_cast<uintptr_t>(out) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  StreamArgs a = {};
+  a.slabs = const_cast<char*>(static_cast<const char*>(p.slabs));
+  a.bias = static_cast<const uint16_t*>(p.bias), a.out = static_cast<uint16_t*>(out);
+  a.x_scale = p.x_scale, a.w_scale = p.w_scale;
+  a.M = p.M, a.N = p.N, a.splits = p.splits, a.out_stride = out_stride_m;
+  const int64_t threads = static_cast<int64_t>(a.M) * (a.N / 4);
+  const dim3 grid(static_cast<unsigned>((threads + 255) / 256));
+  hipStream_t s = begin_launches(stream);
+  if (p.is_int32) hipLaunchKernelGGL(stream_gemm_reduce_kernel<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(stream_gemm_reduce_kernel<false>, grid, dim3(256), 0, s, a);
+  return launch_status();
+}

@@ -188,6 +188,13 @@ class W8A8GemmArgs(C.Structure):
     ]
 
 
+class GemmPartials(C.Structure):
+    _fields_ = [
+        ("slabs", _ptr), ("splits", _i32), ("is_int32", _i32), ("x_scale", _ptr), ("w_scale", _ptr), ("bias", _ptr),
+        ("M", _i32), ("N", _i32),
+    ]
+
+
 class MoeRouteArgs(C.Structure):
     _fields_ = [
         ("router_logits", _ptr), ("topk_ids", _ptr), ("topk_weights", _ptr), ("counts", _ptr), ("cursors", _ptr),
@@ -243,9 +250,15 @@ _SIGNATURES = {
     "hymeta_gptq_gemm": (C.c_int, [C.POINTER(GptqGemmArgs), _ptr]),
     "hymeta_gptq_dequant": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "hymeta_bf16_gemm": (C.c_int, [C.POINTER(Bf16GemmArgs), _ptr]),
+    "hymeta_bf16_gemm_silu_mul": (C.c_int, [C.POINTER(Bf16GemmArgs), _ptr]),
+    "hymeta_bf16_gemm_deferred": (C.c_int, [C.POINTER(Bf16GemmArgs), C.POINTER(GemmPartials), _ptr]),
+    "hymeta_w8a8_gemm_deferred": (C.c_int, [C.POINTER(W8A8GemmArgs), C.POINTER(GemmPartials), _ptr]),
+    "hymeta_gemm_partials_reduce": (C.c_int, [C.POINTER(GemmPartials), _ptr, _i64, _ptr]),
+    "hymeta_add_rmsnorm_partials": (C.c_int, [C.POINTER(AddRmsNormArgs), C.POINTER(GemmPartials), _ptr]),
     "hymeta_bf16_gemm_split_k": (C.c_int, [_i32, _i32, _i32]),
     "hymeta_bf16_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "hymeta_w8a8_gemm": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),
+    "hymeta_w8a8_gemm_silu_mul": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),
     "hymeta_moe_route": (C.c_int, [C.POINTER(MoeRouteArgs), _ptr]),
     "hymeta_moe_gemm": (C.c_int, [C.POINTER(MoeGemmArgs), _ptr]),
     "hymeta_silu_and_mul": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),

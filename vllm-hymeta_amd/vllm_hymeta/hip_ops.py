@@ -260,10 +260,10 @@ _TICKETED = ("gptq_gemm", "bf16_gemm", "w8a8_gemm")     # workspaces that start 
 
 
 class _Workspace:
-    __slots__ = ("buf", "eager_clean", "captures")
+    __slots__ = ("buf", "eager_clean", "captures", "uses")
 
     def __init__(self, buf, eager_clean):
-        self.buf, self.eager_clean, self.captures = buf, eager_clean, set()
+        self.buf, self.eager_clean, self.captures, self.uses = buf, eager_clean, set(), 0
 
 
 def _capture_id(stream) -> int:
@@ -305,7 +305,42 @@ def _workspace(device: torch.device, nbytes: int, tag: str = "paged_decode") -> 
         elif cid == 0 and not ws.eager_clean:
             ws.buf[: _C.GEMM_TICKET_BYTES].zero_()
             ws.eager_clean = True
+    ws.uses += 1
     return ws.buf
+
+
+class PartialSums:
+    """Result of a K-sliced linear whose slice sum is left to its consumer (``bf16_gemm`` / ``w8a8_gemm`` with
+    ``defer=True``): ``add_rmsnorm`` takes it in place of ``x`` and adds the slices while it reads them, ``tensor()``
+    runs the linear's own reduce launch.  The partial sums live in the linear's workspace: they must be consumed
+    before the next linear of that kind on the stream (checked)."""
+
+    def __init__(self, desc, shape, device, key, keep):
+        self.desc, self.shape, self.device = desc, shape, device
+        self._key, self._keep = key, keep            # keep: tensors the descriptor points into
+        self._uses = _workspaces[key].uses
+
+    def check_live(self) -> None:
+        ws = _workspaces.get(self._key)
+        _require(ws is not None and ws.uses == self._uses and ws.buf is self._keep[0],
+                 "partial sums were overwritten: another linear used the workspace before they were consumed")
+
+    def tensor(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self.check_live()
+        M, N = self.shape
+        if out is None:
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=self.device)
+        _require(out.shape == (M, N) and out.dtype == torch.bfloat16 and out.stride(1) == 1, "out must be bf16 [M, N]")
+        _C.check(_C.load().hymeta_gemm_partials_reduce(C.byref(self.desc), _p(out), out.stride(0),
+                                                       C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                 "hymeta_gemm_partials_reduce")
+        return out
+
+
+def _partials(desc, M, N, device, tag, *keep):
+    stream = torch.cuda.current_stream(device)
+    key = (device, stream.cuda_stream, tag)
+    return PartialSums(desc, (M, N), device, key, (_workspaces[key].buf,) + keep)
 
 
 def reset_workspace_tickets(device: Optional[torch.device] = None) -> None:
@@ -598,7 +633,22 @@ def hybrid_combine(o_attn: torch.Tensor, o_lin: torch.Tensor, weight1: torch.Ten
 def add_rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, residual: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """RMS norm of the decoder blocks.  With ``residual``: residual <- bf16(x + residual) in place
-    and the norm is taken of that sum (the blocks' ``mlp_norm(hidden, residual)`` call)."""
+    and the norm is taken of that sum (the blocks' ``mlp_norm(hidden, residual)`` call).  ``x`` may be the
+    ``PartialSums`` of a K-sliced linear (needs ``residual``): the slices are added as the input is read."""
+    if isinstance(x, PartialSums):
+        x.check_live()
+        M, N = x.shape
+        _dev(weight, residual, out)
+        _require(residual is not None and residual.shape == (M, N) and residual.dtype == torch.bfloat16 and residual.stride(1) == 1,
+                 "partial sums need a row-contiguous bf16 residual [T, hidden]")
+        _require(weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.numel() == N, "weight must be contiguous bf16 [hidden]")
+        if out is None:
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=residual.device)
+        _require(out.shape == (M, N) and out.dtype == torch.bfloat16 and out.stride(1) == 1, "out must be row-contiguous bf16 [T, hidden]")
+        a = _C.AddRmsNormArgs(x=None, residual=residual.data_ptr(), weight=weight.data_ptr(), out=out.data_ptr(), num_tokens=M,
+                              hidden=N, x_stride_t=0, residual_stride_t=residual.stride(0), out_stride_t=out.stride(0), eps=eps)
+        _C.check(_C.load().hymeta_add_rmsnorm_partials(C.byref(a), C.byref(x.desc), _stream(residual)), "hymeta_add_rmsnorm_partials")
+        return out
     _dev(x, weight, residual, out)
     _require(x.dim() == 2 and x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [T, hidden]")
     _require(weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.numel() == x.shape[1],
@@ -721,8 +771,9 @@ def bf16_gemm_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 
 def bf16_gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-              out: Optional[torch.Tensor] = None, split_k: int = 0) -> torch.Tensor:
-    """x bf16 [M <= 64, K] @ weight bf16 [N, K]^T (+ bias bf16 [N]) -> bf16 [M, N]; ``split_k`` 0: library's choice."""
+              out: Optional[torch.Tensor] = None, split_k: int = 0, defer: bool = False):
+    """x bf16 [M <= 64, K] @ weight bf16 [N, K]^T (+ bias bf16 [N]) -> bf16 [M, N]; ``split_k`` 0: library's choice.
+    ``defer``: when the library cuts K into slices, return their ``PartialSums`` instead of summing them."""
     _dev(x, weight, bias, out)
     M, K = x.shape
     N = weight.shape[0]
@@ -744,13 +795,18 @@ def bf16_gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor
     if nbytes > 0:
         ws = _workspace(x.device, nbytes, "bf16_gemm")
         a.workspace, a.workspace_bytes = _p(ws), ws.numel()
+    if defer and a.split_k == 0 and nbytes > 0:
+        desc = _C.GemmPartials()
+        _C.check(lib.hymeta_bf16_gemm_deferred(C.byref(a), C.byref(desc), _stream(x)), "hymeta_bf16_gemm_deferred")
+        return _partials(desc, M, N, x.device, "bf16_gemm", bias) if desc.splits > 0 else out
     _C.check(lib.hymeta_bf16_gemm(C.byref(a), _stream(x)), "hymeta_bf16_gemm")
     return out
 
 
 def w8a8_gemm(x: torch.Tensor, qweight: torch.Tensor, w_scale: torch.Tensor,
-              bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x bf16 [M,K] -> dynamic per-token int8; qweight int8 [N,K]; w_scale fp32 [N] -> bf16 [M,N]."""
+              bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, defer: bool = False):
+    """x bf16 [M,K] -> dynamic per-token int8; qweight int8 [N,K]; w_scale fp32 [N] -> bf16 [M,N].
+    ``defer``: when the library cuts K into slices, return their ``PartialSums`` instead of summing them."""
     _dev(x, qweight, w_scale, bias, out)
     M, K = x.shape
     N = qweight.shape[0]
@@ -775,7 +831,54 @@ def w8a8_gemm(x: torch.Tensor, qweight: torch.Tensor, w_scale: torch.Tensor,
     a.split_k = 0        # the library chooses the kernel and the decomposition; the workspace bound covers every choice
     ws = _workspace(x.device, int(lib.hymeta_w8a8_gemm_workspace_bytes(M, N, 0)), "w8a8_gemm")
     a.workspace, a.workspace_bytes = _p(ws), ws.numel()
+    if defer:
+        desc = _C.GemmPartials()
+        _C.check(lib.hymeta_w8a8_gemm_deferred(C.byref(a), C.byref(desc), _stream(x)), "hymeta_w8a8_gemm_deferred")
+        return _partials(desc, M, N, x.device, "w8a8_gemm", xs, w_scale, bias) if desc.splits > 0 else out
     _C.check(lib.hymeta_w8a8_gemm(C.byref(a), _stream(x)), "hymeta_w8a8_gemm")
+    return out
+
+
+def gemm_silu_mul_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Shapes the gate/up projection with the activation in its epilogue takes: decode-sized batches of a bf16 or
+    int8 ``[2 I, K]`` weight (gate rows, then up rows)."""
+    esize = 1 if weight.dtype == torch.int8 else 2
+    return (x.dim() == 2 and 0 < x.shape[0] <= BF16_GEMM_MAX_ROWS and x.is_cuda and x.dtype == torch.bfloat16
+            and weight.dtype in (torch.bfloat16, torch.int8) and x.stride(1) == 1 and weight.is_contiguous()
+            and (weight.shape[1] * esize) % 128 == 0 and weight.shape[1] * esize >= 512 and weight.shape[0] % 128 == 0
+            and x.stride(0) % 8 == 0)
+
+
+def gemm_silu_mul(x: torch.Tensor, weight: torch.Tensor, w_scale: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``silu(x gate^T) * (x up^T)`` in one launch: x bf16 [M <= 64, K]; weight [2 I, K] bf16, or int8 with ``w_scale``
+    fp32 [2 I] (dynamic per-token int8 activations) -> bf16 [M, I].  Bit for bit the linear followed by
+    ``silu_and_mul``."""
+    _dev(x, weight, w_scale, out)
+    M, K = x.shape
+    N = weight.shape[0]
+    _require(gemm_silu_mul_supported(x, weight) and weight.shape == (N, K), "shape not covered: run the linear and silu_and_mul")
+    if out is None:
+        out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=x.device)
+    _require(out.shape == (M, N // 2) and out.dtype == torch.bfloat16 and out.stride(1) == 1 and out.stride(0) % 8 == 0,
+             "out must be row-contiguous bf16 [M, I]")
+    lib = _C.load()
+    if weight.dtype == torch.bfloat16:
+        a = _C.Bf16GemmArgs()
+        a.x, a.weight, a.out = _p(x), _p(weight), _p(out)
+        a.M, a.K, a.N = M, K, N
+        a.x_stride_m, a.w_stride_n, a.out_stride_m = x.stride(0), weight.stride(0), out.stride(0)
+        _C.check(lib.hymeta_bf16_gemm_silu_mul(C.byref(a), _stream(x)), "hymeta_bf16_gemm_silu_mul")
+        return out
+    _require(w_scale is not None and w_scale.dtype == torch.float32 and w_scale.is_contiguous() and w_scale.numel() == N,
+             "w_scale must be contiguous fp32 [2 I]")
+    xq = torch.empty(M, K, dtype=torch.int8, device=x.device)
+    xs = torch.empty(M, dtype=torch.float32, device=x.device)
+    a = _C.W8A8GemmArgs()
+    a.x, a.qweight, a.w_scale, a.out, a.xq, a.x_scale = _p(x), _p(weight), _p(w_scale), _p(out), _p(xq), _p(xs)
+    a.M, a.K, a.N = M, K, N
+    a.x_stride_m, a.out_stride_m = x.stride(0), out.stride(0)
+    _C.check(lib.hymeta_w8a8_gemm_silu_mul(C.byref(a), _stream(x)), "hymeta_w8a8_gemm_silu_mul")
     return out
 
 

@@ -55,11 +55,24 @@ class HymetaLinear(torch.nn.Module):
     def from_w8a8(cls, qweight, w_scale, bias=None) -> "HymetaLinear":
         return cls("w8a8", qweight=qweight, w_scale=w_scale, bias=bias)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward_silu_mul(self, x: torch.Tensor) -> torch.Tensor:
+        """``silu(y[:, :I]) * y[:, I:]`` of ``y = self(x)`` for a fused gate/up projection (output rows = gate, then up):
+        decode-sized batches of a bf16 or W8A8 projection run it in the GEMM's epilogue (same bits, one launch, no
+        ``[M, 2 I]`` intermediate)."""
+        if self.bias is None and self.kind in ("bf16", "w8a8"):
+            w = self.weight if self.kind == "bf16" else self.qweight
+            if hip_ops.gemm_silu_mul_supported(x, w):
+                return hip_ops.gemm_silu_mul(x, w, None if self.kind == "bf16" else self.w_scale)
+        return hip_ops.silu_and_mul(self(x))
+
+    def forward(self, x: torch.Tensor, defer: bool = False):
+        """``defer``: the caller passes the result straight to a fused add + RMS norm (``HymetaRMSNorm`` with a
+        residual); a decode-sized bf16 / W8A8 linear whose K is cut into slices then returns their
+        ``hip_ops.PartialSums`` and the norm adds them as it reads its input.  Everything else returns the tensor."""
         if self.kind == "bf16":
             # decode-sized batches: the weight-streaming kernel; prefill-sized ones: a plain library GEMM
             if hip_ops.bf16_gemm_supported(x, self.weight):
-                return hip_ops.bf16_gemm(x, self.weight, self.bias)
+                return hip_ops.bf16_gemm(x, self.weight, self.bias, defer=defer)
             return torch.nn.functional.linear(x, self.weight, self.bias)
         if self.kind == "gptq":
             if x.shape[0] > GPTQ_EXPAND_ROWS:
@@ -76,4 +89,4 @@ class HymetaLinear(torch.nn.Module):
             xq, xs = hip_ops.w8a8_quantize(x)
             acc = torch._int_mm(xq, self.qweight.t())
             return hip_ops.w8a8_scale_out(acc, xs, self.w_scale, bias=self.bias)
-        return hip_ops.w8a8_gemm(x, self.qweight, self.w_scale, bias=self.bias)
+        return hip_ops.w8a8_gemm(x, self.qweight, self.w_scale, bias=self.bias, defer=defer)

@@ -14,6 +14,7 @@ import torch
 
 from .. import _C, hip_ops
 from ..linear import HymetaLinear
+from .. import parallel
 from ..parallel import HeadShard, all_reduce_sum, shard_heads
 
 
@@ -35,8 +36,10 @@ class GatedLinearAttention(torch.nn.Module):
         self.gate_logit_normalizer = float(gate_logit_normalizer)
         self.tp_group = tp_group
 
+    can_defer_out = True     # forward(defer_out=True): o_proj may leave its K slices' sum to the fused add + norm that follows
+
     def forward(self, hidden_states: torch.Tensor, gla_cache: torch.Tensor,
-                state_indices_tensor: torch.Tensor, attn_metadata) -> torch.Tensor:
+                state_indices_tensor: torch.Tensor, attn_metadata, defer_out: bool = False):
         """hidden_states ``[T, hidden]`` (prefill tokens first, then one token per decode sequence);
         ``gla_cache [slots, H_local, D, D]`` of this layer; ``state_indices_tensor`` one slot per
         sequence in batch order.  Returns ``[T, hidden]``."""
@@ -65,5 +68,6 @@ class GatedLinearAttention(torch.nn.Module):
         if T > t_pre:
             hip_ops.gla_decode(q[t_pre:], k[t_pre:], v[t_pre:], gk[t_pre:], gla_cache,
                                state_indices_tensor[n_pre:], out=out[t_pre:], **gate)
-        y = self.o_proj(out.view(T, H * D))
-        return all_reduce_sum(y, self.tp_group)
+        reduce = parallel._active(self.tp_group)
+        y = self.o_proj(out.view(T, H * D), defer=defer_out and not reduce)
+        return all_reduce_sum(y, self.tp_group) if reduce else y

@@ -15,6 +15,7 @@ import torch
 from .. import hip_ops
 from ..linear import HymetaLinear
 from ..models.attention import MetaAttention, bind_kv_cache, current_attn_metadata, forward_context, standalone_prefix
+from .. import parallel
 from ..parallel import HeadShard, all_reduce_sum, shard_heads
 
 
@@ -51,8 +52,10 @@ class SlidingWindowAttention(torch.nn.Module):
             raise ValueError("attention layer and head shard disagree on the head geometry")
         self.attn = attn
 
+    can_defer_out = True     # forward(defer_out=True): o_proj may leave its K slices' sum to the fused add + norm that follows
+
     def forward(self, hidden_states: torch.Tensor, positions: torch.Tensor, kv_cache: Optional[torch.Tensor] = None,
-                attn_metadata=None) -> torch.Tensor:
+                attn_metadata=None, defer_out: bool = False):
         """The attention runs through the registered layer and the opaque op, which read the paged cache bound to
         the layer (numel 0: profiling run) and the step's metadata from the forward context; ``kv_cache
         [2, nblk, bs, Hkv_local, D]`` / ``attn_metadata`` given explicitly are bound / set for the call."""
@@ -70,8 +73,9 @@ class SlidingWindowAttention(torch.nn.Module):
                 out = self.attn(q, k, v)
         else:
             out = self.attn(q, k, v)
-        y = self.o_proj(out)
-        return all_reduce_sum(y, self.tp_group)
+        reduce = parallel._active(self.tp_group)
+        y = self.o_proj(out, defer=defer_out and not reduce)
+        return all_reduce_sum(y, self.tp_group) if reduce else y
 
 
 def swa_attention_layer(shard: HeadShard, head_dim: int, sliding_window: int, prefix: str, cache_config=None) -> MetaAttention:

@@ -31,6 +31,14 @@ class HymetaRMSNorm(torch.nn.Module):
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None
                 ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        if isinstance(x, hip_ops.PartialSums):      # a K-sliced linear's result, summed while it is read
+            if residual is None:
+                x = x.tensor()
+            else:
+                r2 = residual.reshape(-1, residual.shape[-1])
+                if r2.data_ptr() != residual.data_ptr():
+                    raise ValueError("residual must be viewable as [tokens, hidden] without a copy (it is updated in place)")
+                return hip_ops.add_rmsnorm(x, self.weight, self.variance_epsilon, residual=r2).view_as(residual), residual
         x2 = x.reshape(-1, x.shape[-1])
         if residual is None:
             return hip_ops.add_rmsnorm(x2, self.weight, self.variance_epsilon).view_as(x)
@@ -67,9 +75,15 @@ class DecoderBlock(torch.nn.Module):
             # take a private copy when the caller keeps using its tensor
             residual = hidden_states.clone()
             normed = self.attn_norm(hidden_states)
-        attn_out = attn_fn(normed) if attn_fn is not None else self.attn(normed, **attn_kwargs)
+        # the projections that end the attention and the MLP feed a fused add + norm: they may leave their K slices'
+        # sum to it (modules that take the flag; a tensor-parallel one ignores it, its all-reduce needs the sum)
+        attn_out = attn_fn(normed) if attn_fn is not None else (
+            self.attn(normed, defer_out=True, **attn_kwargs) if getattr(self.attn, "can_defer_out", False)
+            else self.attn(normed, **attn_kwargs))
         normed, residual = self.mlp_norm(attn_out, residual)
         if carry_residual:
+            if getattr(self.mlp, "can_defer_out", False):
+                return self.mlp(normed, defer_out=True), residual
             return self.mlp(normed), residual
         return residual + self.mlp(normed), None
 

@@ -194,12 +194,15 @@ class IntraHybridAttention(torch.nn.Module):
         out_linear = out_linear.reshape(meta_hidden.shape[0], -1)
         return all_reduce_sum(self.out_proj(self.combine(out_attn, out_linear)), self.tp_group)
 
+    can_defer_out = True     # forward(defer_out=True): out_proj may leave its K slices' sum to the fused add + norm that follows
+
     def forward(self, hidden_states, positions, kv_cache, hymeta_cache, meta_linear_cache, meta_fattn_cache,
-                state_indices_tensor, attn_metadata=None, lower_bound=None) -> torch.Tensor:
+                state_indices_tensor, attn_metadata=None, lower_bound=None, defer_out: bool = False):
         if attn_metadata is None:
             attn_metadata = current_attn_metadata()
         out_attn = self.vanilla_attn(hidden_states, positions, kv_cache, meta_fattn_cache, attn_metadata)
         out_linear = self.linear_attn(hidden_states, hymeta_cache, meta_linear_cache, state_indices_tensor,
                                       attn_metadata, lower_bound)
-        y = self.out_proj(self.combine(out_attn, out_linear))
-        return all_reduce_sum(y, self.tp_group)
+        reduce = parallel._active(self.tp_group)
+        y = self.out_proj(self.combine(out_attn, out_linear), defer=defer_out and not reduce)
+        return all_reduce_sum(y, self.tp_group) if reduce else y

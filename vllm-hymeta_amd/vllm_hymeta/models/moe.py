@@ -20,6 +20,7 @@ import torch
 
 from .. import hip_ops
 from ..linear import HymetaLinear
+from .. import parallel
 from ..parallel import all_reduce_sum
 
 
@@ -32,9 +33,14 @@ class HymetaMLP(torch.nn.Module):
         self.gate_up_proj, self.down_proj = gate_up_proj, down_proj
         self.tp_group, self.reduce_results = tp_group, reduce_results
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = self.down_proj(hip_ops.silu_and_mul(self.gate_up_proj(x)))
-        return all_reduce_sum(y, self.tp_group) if self.reduce_results else y
+    can_defer_out = True
+
+    def forward(self, x: torch.Tensor, defer_out: bool = False):
+        """``defer_out``: the result goes straight into a fused add + norm, which may sum ``down_proj``'s K slices itself
+        (see ``HymetaLinear.forward``); ignored when an all-reduce follows."""
+        reduce = self.reduce_results and parallel._active(self.tp_group)
+        y = self.down_proj(self.gate_up_proj.forward_silu_mul(x), defer=defer_out and not reduce)
+        return all_reduce_sum(y, self.tp_group) if reduce else y
 
 
 def expert_range(num_experts: int, ep_size: int, ep_rank: int) -> Tuple[int, int]:
