@@ -8,7 +8,7 @@ def main(path, out=None):
     rows = list(csv.DictReader(open(path)))
     lines = ["| kernel | calls | avg us | min us | max us | total ms | % |", "|---|---|---|---|---|---|---|"]
     for r in rows:
-        name = r["Name"]
+        name = r["Name"].replace("(anonymous namespace)::", "")
         name = name.split("(")[0] if name.startswith(("hymeta", "void hymeta")) else name[:60] + "..."
         lines.append("| %s | %s | %.2f | %.2f | %.2f | %.3f | %.2f |" % (
             name.replace("void ", ""), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,

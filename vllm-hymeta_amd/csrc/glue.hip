@@ -172,10 +172,21 @@ __global__ __launch_bounds__(256) void add_rmsnorm_partials_kernel(hymeta_add_rm
     if constexpr (I8) {
       const int32_t* src = static_cast<const int32_t*>(p.slabs) + t * p.N + 8 * c;
       int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int sp = 0; sp < p.splits; ++sp) {
-        const u32x4 lo = ld16(src + sp * slab), hi = ld16(src + sp * slab + 4);
+      // four slices' loads in flight at a time (a loop of dependent load-add pairs would wait out one cache latency
+      // per slice); the adds stay in slice order
+      for (int sp = 0; sp < p.splits; sp += 4) {
+        u32x4 lo[4], hi[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += static_cast<int>(lo[e]), acc[4 + e] += static_cast<int>(hi[e]);
+        for (int i = 0; i < 4; ++i) {
+          const int64_t off = static_cast<int64_t>(min(sp + i, p.splits - 1)) * slab;
+          lo[i] = ld16(src + off), hi[i] = ld16(src + off + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (sp + i < p.splits) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += static_cast<int>(lo[i][e]), acc[4 + e] += static_cast<int>(hi[i][e]);
+          }
       }
       float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (bias != nullptr) {
@@ -188,9 +199,16 @@ __global__ __launch_bounds__(256) void add_rmsnorm_partials_kernel(hymeta_add_rm
     } else {
       const float* src = static_cast<const float*>(p.slabs) + t * p.N + 8 * c;
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      for (int sp = 0; sp < p.splits; ++sp) {
-        lo += *reinterpret_cast<const f32x4*>(src + sp * slab);
-        hi += *reinterpret_cast<const f32x4*>(src + sp * slab + 4);
+      for (int sp = 0; sp < p.splits; sp += 4) {
+        f32x4 l4[4], h4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t off = static_cast<int64_t>(min(sp + i, p.splits - 1)) * slab;
+          l4[i] = *reinterpret_cast<const f32x4*>(src + off), h4[i] = *reinterpret_cast<const f32x4*>(src + off + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (sp + i < p.splits) lo += l4[i], hi += h4[i];
       }
       if (bias != nullptr) {
         const u32x4 bw = ld16(bias + 8 * c);
@@ -299,9 +317,19 @@ __global__ __launch_bounds__(256) void lowrank_gate_kernel(hymeta_lowrank_gate_a
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint16_t* x = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(blockIdx.x) * a.x_stride_t;
   const uint16_t* w0 = reinterpret_cast<const uint16_t*>(a.w0);
+  // the second stage's weights do not depend on the first: fetch this thread's first two rows now, under the first
+  // stage's loads, instead of after the workgroup's reduction
+  const uint16_t* w1 = reinterpret_cast<const uint16_t*>(a.w1);
+  u32x4 w1a[2], w1b[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int o = min(tid + 256 * j, a.out_features - 1);
+    w1a[j] = ld16(w1 + static_cast<int64_t>(o) * R), w1b[j] = ld16(w1 + static_cast<int64_t>(o) * R + 8);
+  }
   float acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll 2
   for (int ch = tid; ch < a.hidden / 8; ch += 256) {
     const u32x4 xv = ld16(x + 8 * ch);
     float xf[8];
@@ -335,10 +363,10 @@ __global__ __launch_bounds__(256) void lowrank_gate_kernel(hymeta_lowrank_gate_a
   float t[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) t[r] = s_t[r];
-  const uint16_t* w1 = reinterpret_cast<const uint16_t*>(a.w1);
   uint16_t* out = reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(blockIdx.x) * a.out_stride_t;
-  for (int o = tid; o < a.out_features; o += 256) {
-    const u32x4 wa = ld16(w1 + static_cast<int64_t>(o) * R), wb = ld16(w1 + static_cast<int64_t>(o) * R + 8);
+  for (int o = tid, j = 0; o < a.out_features; o += 256, ++j) {
+    const u32x4 wa = j < 2 ? w1a[j & 1] : ld16(w1 + static_cast<int64_t>(o) * R);
+    const u32x4 wb = j < 2 ? w1b[j & 1] : ld16(w1 + static_cast<int64_t>(o) * R + 8);
     float y = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

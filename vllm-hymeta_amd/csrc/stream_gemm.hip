@@ -281,8 +281,16 @@ __global__ __launch_bounds__(256) void stream_gemm_reduce_kernel(StreamArgs a) {
   if (idx >= static_cast<int64_t>(a.M) * per_row) return;
   const int row = static_cast<int>(idx / per_row), col = 4 * static_cast<int>(idx % per_row);
   acc_t sum = acc_t{0, 0, 0, 0};
-  for (int sp = 0; sp < a.splits; ++sp)
-    sum += *reinterpret_cast<const acc_t*>(a.slabs + ((static_cast<int64_t>(sp) * a.M + row) * a.N + col) * 4);
+  // four slices' loads in flight at a time; the adds stay in slice order
+  for (int sp = 0; sp < a.splits; sp += 4) {
+    acc_t part[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      part[i] = *reinterpret_cast<const acc_t*>(a.slabs + ((static_cast<int64_t>(min(sp + i, a.splits - 1)) * a.M + row) * a.N + col) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (sp + i < a.splits) sum += part[i];
+  }
   f32x4 b = {0.f, 0.f, 0.f, 0.f};
   if (a.bias != nullptr) {
     const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + col);
