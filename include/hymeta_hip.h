@@ -127,6 +127,13 @@ typedef struct hymeta_gla_decode_args {
   float out_norm_eps;
   int32_t state_heads;      /* heads the state tensor holds: 0 or num_heads = one state per query head (the
                              * reference's layout); num_kv_heads = one state per key/value head, see above */
+  /* The gate in its low-rank form (7B: gk_proj = Linear(hidden, 16) -> Linear(16, Hkv * D, bias),
+   * vllm_hymeta/model_for_7B/gla_attention.py:157-166): with g_w1 given, g is the FIRST linear's output, bf16
+   * [batch, 16] rows g_stride_b apart (g_stride_h unused), and the kernel applies the second linear itself:
+   * g_w1 bf16 [num_kv_heads * head_dim, 16] contiguous, g_bias bf16 [num_kv_heads * head_dim] or NULL, result rounded
+   * to bf16 as the linear's output is.  NULL g_w1: g is the finished gate, as above. */
+  const void* g_w1;
+  const void* g_bias;
 } hymeta_gla_decode_args;
 
 int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stream_t stream);

@@ -114,6 +114,37 @@ def test_gla_decode_fused_7b_gate_and_norm():
     assert_bf16_ulp(sd.cpu(), ref_state, "state (fused 7B gate)", ulps=2)
 
 
+@pytest.mark.parametrize("state_heads", ["kv", "query"])
+def test_gla_decode_low_rank_gate_applied_in_the_kernel(state_heads):
+    """The 7B gate given as its rank-16 input (rows of a wider, strided tensor, as they sit behind the qkv columns): the
+    kernel's second linear reproduces hymeta_lowrank_gate's second stage, so outputs and states equal the run on the
+    materialised gate bit for bit."""
+    from vllm_hymeta import hip_ops, _C
+
+    B, H, Hkv, hidden = 9, 28, 4, 512
+    g_ = gen(6)
+    q, k, v = randn_bf16(g_, B, H, D).cuda(), randn_bf16(g_, B, Hkv, D).cuda(), randn_bf16(g_, B, Hkv, D).cuda()
+    x = randn_bf16(g_, B, hidden).cuda()
+    w0 = randn_bf16(g_, 16, hidden, scale=hidden ** -0.5).cuda()
+    w1, b1 = randn_bf16(g_, Hkv * D, 16, scale=0.5).cuda(), randn_bf16(g_, Hkv * D, scale=0.1).cuda()
+    w = (1 + 0.1 * torch.randn(D, generator=g_)).to(torch.bfloat16).cuda()
+    heads = Hkv if state_heads == "kv" else H
+    state = randn_bf16(g_, B, heads, D, D, scale=0.1).cuda()
+    slot = torch.arange(B, dtype=torch.int32).cuda()
+    kw = dict(gate_mode=_C.GATE_7B, out_norm_weight=w, out_norm_eps=1e-6)
+    gk = hip_ops.lowrank_gate(x, w0, w1, b1).view(B, Hkv, D)
+    s_a = state.clone()
+    out_a = hip_ops.gla_decode(q, k, v, gk, s_a, slot, **kw)
+    # the same rank-16 rows the two-stage kernel forms (an identity second stage exposes them), inside a wider tensor
+    eye = torch.eye(16, dtype=torch.bfloat16, device="cuda")
+    wide = torch.zeros(B, 64, dtype=torch.bfloat16, device="cuda")
+    wide[:, 40:56] = hip_ops.lowrank_gate(x, w0, eye, None)
+    s_b = state.clone()
+    out_b = hip_ops.gla_decode(q, k, v, wide[:, 40:56], s_b, slot, g_w1=w1, g_bias=b1, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b) and torch.equal(s_a, s_b)
+
+
 @pytest.mark.parametrize("first_layer", [True, False])
 def test_gla_decode_fused_70b_gate(first_layer):
     from oracle import gla_decode_step_ref

@@ -48,7 +48,13 @@ def test_7b_checkpoint_loads_per_rank(tp, monkeypatch):
         assert len(m.layers) == 4 and len(model.kv_cache) == 2
         H, Hkv = 4 // tp, 2 // tp
         for i, layer in enumerate(m.layers):
-            assert layer.attn.qkv_proj.weight.shape == ((H + 2 * Hkv) * D, 512)
+            # a GLA layer's qkv projection carries the gate's first linear: 16 more rows, padded to 64
+            gate_rows = 64 if i % 2 == 0 else 0
+            assert layer.attn.qkv_proj.weight.shape == ((H + 2 * Hkv) * D + gate_rows, 512)
+            if gate_rows:
+                assert layer.attn.gate_in_qkv
+                assert torch.equal(layer.attn.qkv_proj.weight[(H + 2 * Hkv) * D:(H + 2 * Hkv) * D + 16], layer.attn.gk_proj0.weight)
+                assert not layer.attn.qkv_proj.weight[(H + 2 * Hkv) * D + 16:].any() and not layer.attn.qkv_proj.bias[(H + 2 * Hkv) * D:].any()
             assert layer.attn.o_proj.weight.shape == (512, H * D)
             assert layer.mlp.gate_up_proj.weight.shape == (2 * 1024 // tp, 512)
             assert layer.mlp.down_proj.weight.shape == (512, 1024 // tp)

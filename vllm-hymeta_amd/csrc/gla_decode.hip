@@ -13,6 +13,28 @@
 
 namespace hymeta {
 
+// The gate given in its low-rank form (7B: gk = W1 (W0 x) + b with a rank of 16): ``g`` then holds the rank-16 row of the
+// token (bf16, the first linear's rounded output) and the second linear is applied here, one output feature per thread, in
+// the arithmetic of hymeta_lowrank_gate's second stage (fma chain in rank order, bias added, rounded to bf16).
+__device__ __forceinline__ float lowrank_gate_value(const hymeta_gla_decode_args& a, int b, int feature) {
+  const uint16_t* t = reinterpret_cast<const uint16_t*>(a.g) + b * a.g_stride_b;
+  const uint16_t* w1 = reinterpret_cast<const uint16_t*>(a.g_w1) + static_cast<int64_t>(feature) * 16;
+  const u32x4 ta = ld16(t), tb = ld16(t + 8), wa = ld16(w1), wb = ld16(w1 + 8);
+  float y = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    y = fmaf(lo_bf(ta[i]), lo_bf(wa[i]), y);
+    y = fmaf(hi_bf(ta[i]), hi_bf(wa[i]), y);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    y = fmaf(lo_bf(tb[i]), lo_bf(wb[i]), y);
+    y = fmaf(hi_bf(tb[i]), hi_bf(wb[i]), y);
+  }
+  if (a.g_bias != nullptr) y += bf2f(reinterpret_cast<const uint16_t*>(a.g_bias)[feature]);
+  return bf16_round(y);
+}
+
 template <typename StateT>
 struct StateIO;
 
@@ -60,7 +82,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     const uint16_t* qp = reinterpret_cast<const uint16_t*>(a.q) + b * a.q_stride_b + h * a.q_stride_h;
     const uint16_t* kp = reinterpret_cast<const uint16_t*>(a.k) + b * a.k_stride_b + kvh * a.k_stride_h;
     float g_raw = 0.f;
-    if (a.g != nullptr) {
+    if (a.g_w1 != nullptr) {
+      g_raw = lowrank_gate_value(a, b, kvh * D + tid);
+    } else if (a.g != nullptr) {
       const int64_t goff = b * a.g_stride_b + kvh * a.g_stride_h + tid;
       g_raw = a.g_dtype == HYMETA_F32 ? reinterpret_cast<const float*>(a.g)[goff]
                                       : bf2f(reinterpret_cast<const uint16_t*>(a.g)[goff]);
@@ -224,7 +248,9 @@ __global__ __launch_bounds__(THREADS) void gla_decode_group_kernel(hymeta_gla_de
   if (tid < D) {
     const uint16_t* kp = reinterpret_cast<const uint16_t*>(a.k) + b * a.k_stride_b + kvh * a.k_stride_h;
     float g_raw = 0.f;
-    if (a.g != nullptr) {
+    if (a.g_w1 != nullptr) {
+      g_raw = lowrank_gate_value(a, b, kvh * D + tid);
+    } else if (a.g != nullptr) {
       const int64_t goff = b * a.g_stride_b + kvh * a.g_stride_h + tid;
       g_raw = a.g_dtype == HYMETA_F32 ? reinterpret_cast<const float*>(a.g)[goff]
                                       : bf2f(reinterpret_cast<const uint16_t*>(a.g)[goff]);
@@ -428,6 +454,10 @@ extern "C" int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stre
   if (a.gate_mode < HYMETA_GATE_NONE || a.gate_mode > HYMETA_GATE_70B_LOWER_BOUND) return HYMETA_ERR_UNSUPPORTED;
   if ((a.gate_mode == HYMETA_GATE_NONE || a.gate_mode == HYMETA_GATE_7B) && !a.g) return HYMETA_ERR_INVALID_ARG;
   if (a.gate_mode == HYMETA_GATE_70B_LOWER_BOUND && !a.lower_bound) return HYMETA_ERR_INVALID_ARG;
+  if (a.g_w1 != nullptr) {      // low-rank gate: g = bf16 [batch, 16] rows, 16-byte loads
+    if (!a.g || a.g_dtype != HYMETA_BF16 || a.g_stride_b % 8 != 0) return HYMETA_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(a.g) | reinterpret_cast<uintptr_t>(a.g_w1)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  }
   // 16-byte vector access on v, out and state rows
   if ((a.v_stride_b | a.v_stride_h | a.state_stride_slot | a.state_stride_h) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a.v) | reinterpret_cast<uintptr_t>(a.state)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;

@@ -374,7 +374,8 @@ bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan
   // the kernel is instantiated on the wider of the two widths; `big` counts the tiles that have it
   p->nf = big > 0 ? nf_lo + 1 : nf_lo, p->big = big > 0 ? big : tiles;
   p->tiles = tiles, p->chunks = chunks, p->splits = splits;
-  p->ring = ring_forced == 4 || ring_forced == 2 ? ring_forced : 2;
+  // bytes in flight per wave = ring x fragments x 2 KB: one-fragment tiles need the deeper ring to cover the memory latency
+  p->ring = ring_forced == 4 || ring_forced == 2 ? ring_forced : (p->nf == 1 ? 4 : 2);
   return p->nf <= 4;
 }
 

@@ -44,7 +44,7 @@ class GlaDecodeArgs(C.Structure):
         ("state_stride_slot", _i64), ("state_stride_h", _i64),
         ("g_dtype", _i32), ("state_dtype", _i32), ("gate_mode", _i32),
         ("scale", _f32), ("gate_normalizer", _f32), ("gate_clamp", _f32), ("out_norm_eps", _f32),
-        ("state_heads", _i32),
+        ("state_heads", _i32), ("g_w1", _ptr), ("g_bias", _ptr),
     ]
 
 

@@ -63,10 +63,15 @@ def gla_decode(
     gate_clamp: float = 0.95,
     out_norm_weight: Optional[torch.Tensor] = None,
     out_norm_eps: float = 1e-6,
+    g_w1: Optional[torch.Tensor] = None,
+    g_bias: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """q [B,H,D]; k, v, g [B,Hkv,D]; state [slots,H,D,D] (one state per query head, the reference's
     layout) or [slots,Hkv,D,D] (one per key/value head; any gate but the 70B lower-bound one), updated
     in place; slot_idx [B] int32.
+
+    Low-rank gate (7B): with ``g_w1`` bf16 [Hkv*D, 16] (and ``g_bias`` bf16 [Hkv*D]) ``g`` is the rank-16 input
+    bf16 [B, 16] and the kernel applies the second linear of the gate projection itself.
 
     Returns out [B,H,D] bf16 (rows of skipped sequences, slot -1, are left as they were).
     """
@@ -76,7 +81,15 @@ def gla_decode(
     _require(q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16,
              "q, k, v must be bfloat16")
     _require(k.shape == (B, Hkv, D) and v.shape == (B, Hkv, D), "k, v must be [B, Hkv, D]")
-    _require(g is None or g.shape == (B, Hkv, D), "g must be [B, Hkv, D]")
+    if g_w1 is not None:
+        _dev(g_w1, g_bias)
+        _require(g is not None and g.shape == (B, 16) and g.dtype == torch.bfloat16 and g.stride(1) == 1 and g.stride(0) % 8 == 0,
+                 "low-rank gate: g must be bf16 [B, 16] with rows a multiple of 8 elements apart")
+        _require(g_w1.dtype == torch.bfloat16 and g_w1.is_contiguous() and g_w1.shape == (Hkv * D, 16), "g_w1 must be contiguous bf16 [Hkv*D, 16]")
+        _require(g_bias is None or (g_bias.dtype == torch.bfloat16 and g_bias.is_contiguous() and g_bias.numel() == Hkv * D),
+                 "g_bias must be contiguous bf16 [Hkv*D]")
+    else:
+        _require(g is None or g.shape == (B, Hkv, D), "g must be [B, Hkv, D]")
     _require(state.dim() == 4 and state.shape[2:] == (D, D) and state.shape[1] in (H, Hkv),
              "state must be [slots, H, D, D] or [slots, Hkv, D, D]")
     _require(state.shape[1] == H or gate_mode != _C.GATE_70B_LOWER_BOUND,
@@ -109,6 +122,7 @@ def gla_decode(
         a.g_stride_b, a.g_stride_h = g.stride(0), g.stride(1)
         _require(g.dtype in _DT, "g must be bfloat16 or float32")
         a.g_dtype = _DT[g.dtype]
+    a.g_w1, a.g_bias = _p(g_w1), _p(g_bias)
     a.out_stride_b, a.out_stride_h = out.stride(0), out.stride(1)
     a.state_stride_slot, a.state_stride_h = state.stride(0), state.stride(1)
     a.state_dtype = _DT[state.dtype]

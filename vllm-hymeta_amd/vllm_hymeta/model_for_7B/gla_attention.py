@@ -35,6 +35,20 @@ class GatedLinearAttention(torch.nn.Module):
         self.norm_eps = norm_eps
         self.gate_logit_normalizer = float(gate_logit_normalizer)
         self.tp_group = tp_group
+        # A bf16 checkpoint: the gate's first linear (16 rows over the same input) rides in the qkv projection as 16 more
+        # output rows (padded to the kernels' 64-row granularity), and its second linear (16 -> Hkv*D) is applied inside
+        # the recurrence kernel: a decode step then has no launch for the gate at all.
+        self.qkv_features = (self.shard.num_heads + 2 * self.shard.num_kv_heads) * self.head_dim
+        p0, p1 = gk_proj0, gk_proj1
+        self.gate_in_qkv = (qkv_proj.kind == "bf16" and p0.kind == "bf16" and p1.kind == "bf16" and p0.bias is None
+                            and p0.weight.shape == (16, hidden_size) and p1.weight.shape[1] == 16 and p1.weight.is_contiguous()
+                            and qkv_proj.weight.shape == (self.qkv_features, hidden_size) and self.qkv_features % 64 == 0)
+        if self.gate_in_qkv:
+            w = qkv_proj.weight
+            pad = torch.zeros(48, hidden_size, dtype=w.dtype, device=w.device)
+            bias = qkv_proj.bias if qkv_proj.bias is not None else torch.zeros(self.qkv_features, dtype=w.dtype, device=w.device)
+            self.qkv_proj = HymetaLinear.from_weight(torch.cat([w, p0.weight.to(w.device), pad]),
+                                                     torch.cat([bias, torch.zeros(64, dtype=bias.dtype, device=bias.device)]))
 
     can_defer_out = True     # forward(defer_out=True): o_proj may leave its K slices' sum to the fused add + norm that follows
 
@@ -45,19 +59,24 @@ class GatedLinearAttention(torch.nn.Module):
         sequence in batch order.  Returns ``[T, hidden]``."""
         H, Hkv, D = self.shard.num_heads, self.shard.num_kv_heads, self.head_dim
         T = hidden_states.shape[0]
-        qkv = self.qkv_proj(hidden_states)
-        q = qkv[:, : H * D].view(T, H, D)
-        k = qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
-        v = qkv[:, (H + Hkv) * D:].view(T, Hkv, D)
         p0, p1 = self.gk_proj0, self.gk_proj1
-        if (T <= hip_ops.LOWRANK_GATE_ROWS and p0.kind == "bf16" and p1.kind == "bf16" and p0.bias is None
+        qkv = self.qkv_proj(hidden_states)
+        n_pre = getattr(attn_metadata, "num_prefills", 0)
+        t_pre = getattr(attn_metadata, "num_prefill_tokens", 0)
+        gk = rank16 = None
+        if self.gate_in_qkv:
+            rank16 = qkv[:, self.qkv_features:self.qkv_features + 16]       # the gate's first linear, bf16 [T, 16]
+            if t_pre > 0:
+                gk = torch.nn.functional.linear(rank16[:t_pre], p1.weight, p1.bias).view(t_pre, Hkv, D)
+        elif (T <= hip_ops.LOWRANK_GATE_ROWS and p0.kind == "bf16" and p1.kind == "bf16" and p0.bias is None
                 and p0.weight.shape[0] == 16 and p0.weight.is_contiguous() and p1.weight.is_contiguous()):
             gk = hip_ops.lowrank_gate(hidden_states, p0.weight, p1.weight, p1.bias).view(T, Hkv, D)   # one launch
         else:
             gk = p1(p0(hidden_states)).view(T, Hkv, D)
+        q = qkv[:, : H * D].view(T, H, D)
+        k = qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
+        v = qkv[:, (H + Hkv) * D:(H + 2 * Hkv) * D].view(T, Hkv, D)
         out = torch.empty(T, H, D, dtype=hidden_states.dtype, device=hidden_states.device)
-        n_pre = getattr(attn_metadata, "num_prefills", 0)
-        t_pre = getattr(attn_metadata, "num_prefill_tokens", 0)
         gate = dict(gate_mode=_C.GATE_7B, gate_normalizer=self.gate_logit_normalizer,
                     out_norm_weight=self.g_norm_weight, out_norm_eps=self.norm_eps)
         if n_pre > 0:
@@ -66,8 +85,12 @@ class GatedLinearAttention(torch.nn.Module):
                 attn_metadata.query_start_loc[: n_pre + 1], attn_metadata.max_query_len or t_pre,
                 context_lens=attn_metadata.context_lens_tensor[:n_pre], out=out[:t_pre], **gate)
         if T > t_pre:
-            hip_ops.gla_decode(q[t_pre:], k[t_pre:], v[t_pre:], gk[t_pre:], gla_cache,
-                               state_indices_tensor[n_pre:], out=out[t_pre:], **gate)
+            if rank16 is not None:
+                hip_ops.gla_decode(q[t_pre:], k[t_pre:], v[t_pre:], rank16[t_pre:], gla_cache, state_indices_tensor[n_pre:],
+                                   out=out[t_pre:], g_w1=p1.weight, g_bias=p1.bias, **gate)
+            else:
+                hip_ops.gla_decode(q[t_pre:], k[t_pre:], v[t_pre:], gk[t_pre:], gla_cache,
+                                   state_indices_tensor[n_pre:], out=out[t_pre:], **gate)
         reduce = parallel._active(self.tp_group)
         y = self.o_proj(out.view(T, H * D), defer=defer_out and not reduce)
         return all_reduce_sum(y, self.tp_group) if reduce else y
