@@ -18,12 +18,12 @@ struct StreamArgs {
   int64_t x_stride_bytes, w_stride_bytes, out_stride;
   int gated;              // 1: W = [gate rows | up rows] (N / 2 each), out [M, N / 2] = bf16(silu(bf16(x gate^T)) * bf16(x up^T));
                           // no bias, no K slices
-  int tiles, big, chunks, splits;    // filled from the plan
+  int tiles, chunks, splits;    // filled from the plan
 };
 
 struct StreamPlan {
-  int nf;        // 16-column fragments per wave of the wider tiles: such a tile is 64 nf columns
-  int big;       // tiles [0, big) have that width, tiles [big, tiles) one fragment per wave less
+  int nf;        // 16-column fragments of the widest wave (waves own nf or nf - 1: the matrix's fragments are dealt
+                 // to the tiles, and a tile's to its four waves, in equal shares)
   int tiles, chunks;   // chunks: 512-byte pieces of a weight row
   int splits;          // K slices per tile (1: the workgroup writes the tile itself)
   int ring;      // pairs of k-steps each wave keeps in flight (2 or 4)

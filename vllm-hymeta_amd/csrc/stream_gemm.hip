@@ -50,16 +50,18 @@ __device__ __forceinline__ typename Acc<I8>::type mma(const u32x4& a, const u32x
   }
 }
 
-// One workgroup's work: the tile of 64 NF columns that starts at column group ``group0`` (64 columns per group), K slice
-// ``split``.  MT: 16-row fragments (rows = 16 MT); NF: 16-column fragments per wave; R: ring depth.
-template <int MT, int NF, int R, bool I8, bool NT>
-__device__ __forceinline__ void stream_tile(const StreamArgs& a, char* smem, const int group0, const int split) {
+// One wave's part of a workgroup's tile.  The tile is fragments [tile_f0, tile_f0 + tile_nf) of the matrix (a fragment =
+// 16 weight rows), this wave owns NF of them from ``wave_f0`` on; the four waves of a workgroup may own NF or NF - 1 each
+// (two instantiations, chosen per wave), share the staged x and meet at the same barriers.  K slice ``split``.
+// MT: 16-row fragments (rows = 16 MT); NFT: the widest wave of the launch (sizes the shared images); R: ring depth.
+template <int MT, int NF, int NFT, int R, bool I8, bool NT>
+__device__ __forceinline__ void stream_wave(const StreamArgs& a, char* smem, const int wave_f0, const int tile_f0,
+                                            const int tile_nf, const int split) {
   typedef typename Acc<I8>::type acc_t;
   constexpr int kRowsT = 16 * MT;
-  constexpr int kTileCols = 64 * NF;
-  constexpr int kPitch = kTileCols + 4;          // floats per row of the epilogue image
+  constexpr int kPitch = 64 * NFT + 4;           // floats per row of the epilogue image
   constexpr int kBufBytes = kRowsT * kChunkBytes;
-  constexpr int kWaveImg = 2 * NF * 2048;          // a wave's two weight images (one pair of k-steps each)
+  constexpr int kWaveImg = 2 * NFT * 2048;         // a wave's two weight images (one pair of k-steps each)
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,9 +95,10 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, char* smem, con
     // plain: the wave's 16 NF weight rows are consecutive output columns.  Gated: fragment i holds 8 gate rows and the
     // 8 up rows of the same output columns (rows 8 j .. 8 j + 7 of a fragment are sub-load j), so that a lane's
     // neighbour 8 columns on holds the other factor and the product is formed in the epilogue image.
-    const int col0 = group0 * 64 + wave * 16 * NF;
-    const int ocol0 = group0 * 32 + wave * 8 * NF;           // gated: first output column of the wave
+    const int col0 = 16 * wave_f0;
+    const int ocol0 = 8 * wave_f0;                           // gated: first output column of the wave
     const int up0 = a.N / 2;
+    const int img_col0 = 16 * (wave_f0 - tile_f0);           // the wave's first column in the tile's epilogue image
 
     // weight loads: group i = 16 rows, sub j = its rows 8j .. 8j+7; lane = (row l / 8, piece l % 8) of a 128-byte line.
     // The lane's piece is XOR-ed with the row (swz) so that the lane-linear LDS image serves conflict-free fragment reads.
@@ -191,18 +194,18 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, char* smem, con
         for (int r = 0; r < 4; ++r) {
           float v;
           if constexpr (I8) v = __int_as_float(acc[mt][i][r]); else v = acc[mt][i][r];
-          img[(16 * mt + 4 * cq + r) * kPitch + wave * 16 * NF + 16 * i + n] = v;
+          img[(16 * mt + 4 * cq + r) * kPitch + img_col0 + 16 * i + n] = v;
         }
     __syncthreads();
     if (a.gated) {
       // image column 16 f + n of fragment f: n < 8 the gate of output column 8 f + n, n >= 8 the up factor of 8 f + n - 8
-      for (int idx = tid; idx < kRowsT * 8 * NF; idx += 256) {
-        const int row = idx / (8 * NF), v = idx % (8 * NF);     // v: 4-column vector of the tile's 32 NF output columns
+      for (int idx = tid; idx < kRowsT * 2 * tile_nf; idx += 256) {
+        const int row = idx / (2 * tile_nf), v = idx % (2 * tile_nf);     // v: 4-column vector of the tile's 8 tile_nf output columns
         if (row >= a.M) continue;
         const int f = v >> 1, within = 4 * (v & 1);
         const acc_t g4 = *reinterpret_cast<const acc_t*>(img + row * kPitch + 16 * f + within);
         const acc_t u4 = *reinterpret_cast<const acc_t*>(img + row * kPitch + 16 * f + 8 + within);
-        const int ocol = group0 * 32 + 8 * f + within;
+        const int ocol = 8 * (tile_f0 + f) + within;
         float g[4], u[4];
         if constexpr (I8) {
           const float xs_ = a.x_scale[row];
@@ -227,13 +230,11 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, char* smem, con
       }
       return;
     }
-    constexpr int kVecs = kRowsT * kTileCols / 4 / 256;      // 4-column vectors per thread
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
-      const int idx = j * 256 + tid;
-      const int row = idx / (kTileCols / 4), c4 = idx % (kTileCols / 4);
+    const int vec_per_row = 4 * tile_nf;                     // 4-column vectors per row of the tile
+    for (int idx = tid; idx < kRowsT * vec_per_row; idx += 256) {
+      const int row = idx / vec_per_row, c4 = idx % vec_per_row;
       if (row >= a.M) continue;
-      const int col = group0 * 64 + 4 * c4;
+      const int col = 16 * tile_f0 + 4 * c4;
       const acc_t sum = *reinterpret_cast<const acc_t*>(img + row * kPitch + 4 * c4);
       if (a.splits > 1) {
         *reinterpret_cast<acc_t*>(a.slabs + ((static_cast<int64_t>(split) * a.M + row) * a.N + col) * 4) = sum;
@@ -259,16 +260,23 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, char* smem, con
   }
 }
 
-// Tiles [0, big) are 64 NFHI columns wide, the others 64 (NFHI - 1): with the two widths a matrix of any multiple of 64
-// columns is cut into a chosen number of workgroups (one per compute unit) whose loads differ by one fragment per wave.
+// The matrix's N / 16 fragments are dealt to the launch's tiles in equal shares (they differ by at most one fragment), and
+// a tile's to its four waves likewise: a matrix of any multiple of 64 columns is cut into a chosen number of workgroups
+// (one per compute unit) whose loads differ by a sixteenth of a tile at most.  NFHI = the widest wave's fragments.
 template <int MT, int NFHI, int R, bool I8, bool NT>
 __global__ __launch_bounds__(256, ((NFHI == 4 || MT * NFHI >= 8) ? 1 : 2)) void stream_gemm_kernel(StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
-  if (t < a.big) {
-    stream_tile<MT, NFHI, R, I8, NT>(a, smem, t * NFHI, split);
+  const int frags = a.N / 16;
+  const int f_lo = static_cast<int>(static_cast<int64_t>(t) * frags / a.tiles);
+  const int f_hi = static_cast<int>(static_cast<int64_t>(t + 1) * frags / a.tiles);
+  const int c = f_hi - f_lo;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w_lo = f_lo + wave * c / 4, w_hi = f_lo + (wave + 1) * c / 4;
+  if (w_hi - w_lo == NFHI) {
+    stream_wave<MT, NFHI, NFHI, R, I8, NT>(a, smem, w_lo, f_lo, c, split);
   } else if constexpr (NFHI > 1) {
-    stream_tile<MT, NFHI - 1, R, I8, NT>(a, smem, a.big * NFHI + (t - a.big) * (NFHI - 1), split);
+    stream_wave<MT, NFHI - 1, NFHI, R, I8, NT>(a, smem, w_lo, f_lo, c, split);
   }
 }
 
@@ -349,20 +357,22 @@ bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan
   // One workgroup per compute unit draws the most: a compute unit pulls 29-35 GB/s of weights with this kernel, HBM
   // delivers what about 190 of them ask for, and a second workgroup on a unit only lengthens the launch.
   const int want = want_forced > 0 ? want_forced : 256;
-  int tiles, nf_lo, big;
+  const int frags = N / 16;
+  int tiles, nf;
   if (nf_forced > 0) {                       // uniform tiles of the forced width
     if (groups % nf_forced != 0) return false;
-    tiles = groups / nf_forced, nf_lo = nf_forced, big = 0;
-  } else if (groups >= want) {               // wide matrix: `want` tiles (more when they would pass 256 columns), two widths
-    tiles = want > (groups + 3) / 4 ? want : (groups + 3) / 4;
-    nf_lo = groups / tiles, big = groups - nf_lo * tiles;
+    tiles = groups / nf_forced, nf = nf_forced;
+  } else if (groups >= want) {
+    // wide matrix: `want` tiles (more when a wave would pass 4 fragments), the fragments dealt out in equal shares
+    tiles = want > (frags + 15) / 16 ? want : (frags + 15) / 16;
+    nf = ((frags + tiles - 1) / tiles + 3) / 4;
   } else {
     // narrow matrix: K slices make up the count.  Tiles of 128 columns for the large ones (x is re-read once per
     // tile, the slabs grow with the slices); 64 columns for the small ones, whose time is mostly fixed cost and
     // which then need the fewest slices.  Measured on the 7B shapes at 16 and 64 rows.
-    int nf = static_cast<int64_t>(N) * K_bytes >= (64ll << 20) && groups % 2 == 0 ? 2 : 1;
+    nf = static_cast<int64_t>(N) * K_bytes >= (64ll << 20) && groups % 2 == 0 ? 2 : 1;
     if (!have_workspace) nf = 1;
-    tiles = groups / nf, nf_lo = nf, big = 0;
+    tiles = groups / nf;
   }
   int splits = 1;
   if (have_workspace && tiles < want) splits = want / tiles;
@@ -371,12 +381,10 @@ bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan
   if (splits > chunks) splits = chunks;
   if (splits > kMaxSplits) splits = kMaxSplits;
   if (splits < 1) splits = 1;
-  // the kernel is instantiated on the wider of the two widths; `big` counts the tiles that have it
-  p->nf = big > 0 ? nf_lo + 1 : nf_lo, p->big = big > 0 ? big : tiles;
-  p->tiles = tiles, p->chunks = chunks, p->splits = splits;
+  p->nf = nf, p->tiles = tiles, p->chunks = chunks, p->splits = splits;
   // bytes in flight per wave = ring x fragments x 2 KB: one-fragment tiles need the deeper ring to cover the memory latency
   p->ring = ring_forced == 4 || ring_forced == 2 ? ring_forced : (p->nf == 1 ? 4 : 2);
-  return p->nf <= 4;
+  return p->nf <= 4 && tiles <= groups;      // every wave of every tile owns at least one fragment
 }
 
 bool stream_gemm_plan_gated(int M, int K_bytes, int N, StreamPlan* p) {
@@ -393,7 +401,7 @@ size_t stream_gemm_workspace_bound(int M, int N) {
 
 template <bool I8>
 int stream_gemm_launch(StreamArgs a, const StreamPlan& p, hipStream_t s, bool defer_reduce) {
-  a.tiles = p.tiles, a.big = p.big, a.chunks = p.chunks, a.splits = p.splits;
+  a.tiles = p.tiles, a.chunks = p.chunks, a.splits = p.splits;
   if (a.k_bytes <= 0 || (a.k_bytes + kChunkBytes - 1) / kChunkBytes != p.chunks) return HYMETA_ERR_INVALID_ARG;
   if (a.gated && (p.splits != 1 || a.bias != nullptr || a.N % 128 != 0)) return HYMETA_ERR_INVALID_ARG;
   const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
