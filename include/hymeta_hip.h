@@ -686,6 +686,7 @@ typedef struct hymeta_gemm_partials {
 
 int hymeta_bf16_gemm_deferred(const hymeta_bf16_gemm_args* args, hymeta_gemm_partials* partials, hymeta_stream_t stream);
 int hymeta_w8a8_gemm_deferred(const hymeta_w8a8_gemm_args* args, hymeta_gemm_partials* partials, hymeta_stream_t stream);
+int hymeta_gptq_gemm_deferred(const hymeta_gptq_gemm_args* args, hymeta_gemm_partials* partials, hymeta_stream_t stream);
 /* out bf16 [M, N] = the linear's result (what the plain call would have written). */
 int hymeta_gemm_partials_reduce(const hymeta_gemm_partials* partials, void* out, int64_t out_stride_m, hymeta_stream_t stream);
 /* hymeta_add_rmsnorm with x = the linear's result taken from its partial sums (args->x is ignored; args->residual

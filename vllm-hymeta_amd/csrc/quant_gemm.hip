@@ -921,7 +921,11 @@ static size_t gptq_counter_bytes(int, int) { return kTicketBytes; }
 extern "C" size_t hymeta_gptq_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
   if (M <= 0 || N <= 0 || split_k == 1) return 0;
   // split_k <= 0 (the library chooses): never more (tile, slice) pairs than kMaxPairs, whatever K is
-  if (split_k <= 0) return gptq_counter_bytes(M, N) + static_cast<size_t>(kMaxPairs) * 64 * kWideCols * sizeof(float);
+  if (split_k <= 0) {
+    const size_t old = static_cast<size_t>(kMaxPairs) * 64 * kWideCols * sizeof(float);
+    const size_t streaming = M <= 64 ? stream_gptq_workspace_bound(M, N) : 0;
+    return gptq_counter_bytes(M, N) + (old > streaming ? old : streaming);
+  }
   return gptq_counter_bytes(M, N) + static_cast<size_t>(split_k) * M * N * sizeof(float);
 }
 
@@ -937,8 +941,9 @@ static int compute_units(void) {
   return cached;
 }
 
-extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream_t stream) {
+static int gptq_gemm_impl(const hymeta_gptq_gemm_args* args, hymeta_stream_t stream, hymeta_gemm_partials* deferred) {
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (deferred != nullptr) *deferred = hymeta_gemm_partials{};
   hymeta_gptq_gemm_args a = *args;
   if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;
@@ -953,6 +958,27 @@ extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream
        reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.workspace)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(a.scales) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  // decode-sized 4-bit, group 128: the weight-streaming kernel (whole-line loads through a wave-private LDS image, x
+  // shared through LDS, one workgroup per compute unit) when the library chooses the decomposition
+  static const int stream_from = [] { const char* e = getenv("HYMETA_GPTQ_STREAM_FROM"); return e ? atoi(e) : 1; }();
+  if (a.split_k <= 0 && a.M >= stream_from) {
+    StreamGptqPlan sp;
+    const bool have_ws = a.workspace != nullptr;
+    if (stream_gptq_plan(a.M, a.K, a.N, a.bits, a.group_size, have_ws, &sp) &&
+        (!have_ws || a.workspace_bytes >= kTicketBytes + stream_gptq_workspace_bytes(a.M, a.N, sp))) {
+      StreamGptqArgs sa = {};
+      sa.x = static_cast<const char*>(a.x), sa.qweight = a.qweight, sa.qzeros = a.qzeros, sa.scales = a.scales;
+      sa.bias = static_cast<const uint16_t*>(a.bias), sa.out = static_cast<uint16_t*>(a.out);
+      sa.slabs = have_ws ? reinterpret_cast<char*>(a.workspace) + kTicketBytes : nullptr;
+      sa.M = a.M, sa.N = a.N, sa.scales_f16 = a.scales_dtype == HYMETA_F16, sa.zero_offset = a.zero_offset;
+      sa.x_stride_bytes = a.x_stride_m * 2, sa.out_stride = a.out_stride_m;
+      if (deferred != nullptr && sp.splits > 1) {
+        deferred->slabs = sa.slabs, deferred->splits = sp.splits, deferred->bias = a.bias;
+        deferred->M = a.M, deferred->N = a.N;
+      }
+      return stream_gptq_launch(sa, sp, begin_launches(stream), deferred != nullptr);
+    }
+  }
   const bool wide = gptq_use_wide(a.M, a.K, a.N);
   const int G = a.K / a.group_size;
   const int units = wide ? a.K / kChunkK : G;       // what a K slice is counted in
@@ -1021,6 +1047,16 @@ extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream
 #undef HYMETA_LAUNCH_GPTQ_KS
 #undef HYMETA_LAUNCH_GPTQ
   return launch_status();
+}
+
+extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream_t stream) {
+  return gptq_gemm_impl(args, stream, nullptr);
+}
+
+extern "C" int hymeta_gptq_gemm_deferred(const hymeta_gptq_gemm_args* args, hymeta_gemm_partials* partials,
+                                         hymeta_stream_t stream) {
+  if (partials == nullptr) return HYMETA_ERR_INVALID_ARG;
+  return gptq_gemm_impl(args, stream, partials);
 }
 
 extern "C" int hymeta_gptq_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, void* out,

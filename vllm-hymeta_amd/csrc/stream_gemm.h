@@ -42,4 +42,30 @@ size_t stream_gemm_workspace_bound(int M, int N);
 template <bool I8>
 int stream_gemm_launch(StreamArgs args, const StreamPlan& plan, hipStream_t stream, bool defer_reduce = false);
 
+// ---- the 4-bit GPTQ form (stream_gptq.hip): group size 128, K a multiple of 256, N of 128 ----
+struct StreamGptqArgs {
+  const char* x;            // bf16 [M, K], x_stride_bytes per row
+  const void* qweight;      // int32 [K / 8, N]
+  const void* qzeros;       // int32 [K / 128, N / 8]
+  const void* scales;       // fp16 | bf16 [K / 128, N]
+  const uint16_t* bias;     // bf16 [N] or null
+  uint16_t* out;            // bf16 [M, N]
+  char* slabs;              // [splits][M][N] fp32 partial sums (splits > 1)
+  int M, N;
+  int scales_f16, zero_offset;
+  int64_t x_stride_bytes, out_stride;
+  int tiles, chunks, splits;    // filled from the plan
+};
+
+struct StreamGptqPlan {
+  int np;               // 32-column blocks of the widest wave (1 or 2)
+  int tiles, chunks;    // chunks: 256-k pieces of K
+  int splits;
+};
+
+bool stream_gptq_plan(int M, int K, int N, int bits, int group_size, bool have_workspace, StreamGptqPlan* plan);
+size_t stream_gptq_workspace_bytes(int M, int N, const StreamGptqPlan& plan);
+size_t stream_gptq_workspace_bound(int M, int N);
+int stream_gptq_launch(StreamGptqArgs args, const StreamGptqPlan& plan, hipStream_t stream, bool defer_reduce = false);
+
 }  // namespace hymeta

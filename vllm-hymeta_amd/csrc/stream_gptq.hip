@@ -1,0 +1,353 @@
+// Weight-streaming GEMM for 4-bit GPTQ linears at decode-sized batches (up to 64 rows): out = x dequant(W) (+ bias),
+// qweight int32 [K / 8, N] (a word = 8 consecutive k of ONE output column), qzeros int32 [K / 128, N / 8], scales
+// fp16 | bf16 [K / 128, N], group size 128.
+//
+// Built like the bf16 streaming kernel (stream_gemm.hip): a workgroup of 4 waves owns a tile of columns and a K slice,
+// x is staged through double-buffered LDS in 256-k chunks (one barrier per chunk), every wave streams the weights of
+// its own columns.  What differs is the weight path:
+//   * a wave's columns come in blocks of 32 (one 128-byte line of a qweight row): one load instruction is 8 packed rows
+//     x 128 bytes = 64 k of 32 columns, whole lines (lane = row l / 8, 16-byte piece l % 8).  It passes through a
+//     wave-private 1 KB LDS image, from which lane (n, cq) of the MFMA layout reads the ONE word that holds its 8
+//     k-slots of column n (rows two apart in parity sit in opposite halves of the banks);
+//   * (w >> 4 j) & 0x000F000F | 0x43004300 makes the bf16 pair (128 + q_j, 128 + q_{j+4}) in one instruction, 4 per
+//     word; the k order this induces inside a word, (0,4,1,5,2,6,3,7), is given to x when it is staged;
+//   * scale and zero are applied once per group to the group's partial sums, outside the MFMA chain:
+//       sum_k x w = s * ( sum_k x (128 + q)  -  (128 + z) * sum_k x ),
+//     with sum_k x from one extra MFMA per k-step against an all-ones fragment (it lands in the accumulator layout).
+// Tiles and waves are dealt the matrix's 32-column blocks in equal shares (a wave owns 1 or 2); narrow matrices are
+// cut along K, the slices' fp32 partial tiles go to slabs [slice][M][N] that the bf16 kernel's reduce launch (or the
+// consumer) sums.
+#include <cstdlib>
+
+#include "stream_gemm.h"
+
+namespace hymeta {
+namespace {
+
+constexpr int kChunkBytes = 512;                // bytes of one x row per staged chunk (256 k)
+constexpr int kPieces = kChunkBytes / 16;
+constexpr int kUnitsPerChunk = 4;               // weight units (64 k each) per chunk
+constexpr int kMaxSplits = 16;
+
+__device__ __forceinline__ f32x4 mma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float scale_at(const void* p, int64_t idx, bool f16) {
+  const uint16_t raw = static_cast<const uint16_t*>(p)[idx];
+  if (f16) return static_cast<float>(__builtin_bit_cast(_Float16, raw));
+  return bf2f(raw);
+}
+
+// One wave's part of a tile: NP blocks of 32 columns from block ``wave_b0`` on; the tile is blocks [tile_b0, tile_b0 +
+// tile_nb).  MT: 16-row fragments; NPT: the widest wave of the launch (sizes the shared images).
+template <int MT, int NP, int NPT>
+__device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, const int wave_b0, const int tile_b0,
+                                          const int tile_nb, const int split) {
+  constexpr int R = 4;                           // units in flight per block of columns: one chunk ahead
+  constexpr int NF = 2 * NP;                     // 16-column fragments of the wave
+  constexpr int kRowsT = 16 * MT;
+  constexpr int kPitch = 128 * NPT + 4;          // floats per row of the epilogue image (4 waves x 32 NPT columns)
+  constexpr int kBufBytes = kRowsT * kChunkBytes;
+  constexpr int kWaveImg = 2 * NPT * 1024;       // a wave's weight images: two alternating sets of NPT units
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int n = lane & 15, cq = lane >> 4;
+  char* wimg = smem + 2 * kBufBytes + wave * kWaveImg;
+  const int c_lo = static_cast<int>(static_cast<int64_t>(split) * a.chunks / a.splits);
+  const int c_hi = static_cast<int>(static_cast<int64_t>(split + 1) * a.chunks / a.splits);
+
+  // x staging: 16-byte piece idx = j * 256 + tid of the [rows][32 pieces] chunk image; the 8 values of a piece are
+  // stored in the order the nibble trick emits
+  constexpr int kStage = kRowsT * kPieces / 256;
+  const char* xsrc[kStage];
+  int xdst[kStage];
+#pragma unroll
+  for (int j = 0; j < kStage; ++j) {
+    const int idx = j * 256 + tid;
+    const int row = idx / kPieces, piece = idx % kPieces;
+    xsrc[j] = a.x + static_cast<int64_t>(min(row, a.M - 1)) * a.x_stride_bytes + piece * 16;
+    xdst[j] = row * kChunkBytes + ((piece & 16) | ((piece ^ row) & 15)) * 16;
+  }
+  int aoff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) aoff[mt] = (16 * mt + n) * kChunkBytes;
+
+  // weight loads: unit = 8 packed rows x 128 bytes of one 32-column block; lane = (row l / 8, piece l % 8)
+  const int64_t row_bytes = static_cast<int64_t>(a.N) * 4;
+  const int64_t unit_bytes = 8 * row_bytes;
+  const char* wl[NP];
+  int wdst;                                         // lane's 16 bytes inside a unit image: piece XOR 4 on odd rows
+  {
+    const int r = lane >> 3, p = lane & 7;
+    wdst = r * 128 + ((p ^ (4 * (r & 1))) * 16);
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      wl[i] = reinterpret_cast<const char*>(a.qweight) + (static_cast<int64_t>(c_lo) * 32 + r) * row_bytes +
+              (static_cast<int64_t>(wave_b0 + i) * 32 + 4 * p) * 4;
+  }
+  // fragment reads: k-step s of the unit, fragment f of the block: word (row 4 s + cq, column 16 f + n)
+  int wsrc[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int r = 4 * s + cq, c = 16 * f + n;
+      wsrc[s][f] = r * 128 + (((c >> 2) ^ (4 * (r & 1))) * 16) + (c & 3) * 4;
+    }
+
+  const int nunits = (c_hi - c_lo) * kUnitsPerChunk;
+  u32x4 ring[R][NP];
+  auto issue = [&](int slot, int unit) {
+    const int64_t off = static_cast<int64_t>(min(unit, nunits - 1)) * unit_bytes;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) ring[slot][i] = ld16nt(wl[i] + off);
+  };
+#pragma unroll
+  for (int r = 0; r < R; ++r) issue(r, r);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // scales and zeros of the lane's column in each fragment, one group ahead
+  const bool f16 = a.scales_f16 != 0;
+  const int groups_n8 = a.N / 8;
+  // two register sets used alternately (group parity is static in the unrolled chunk body): a set is loaded at the start of
+  // the group before its own and first read at the end of its own, two groups of work later -- no copy, no early wait
+  // (kept as loaded -- a 16-bit scale, the packed word of zeros -- and converted where they are used: a conversion next
+  // to the load would make the wave wait for it, and for every weight load before it, on the spot)
+  uint32_t sc[2][NF], zc[2][NF];
+  auto load_group = [&](int g, uint32_t (&s_)[NF], uint32_t (&z_)[NF]) {
+    const int gg = min(g, a.chunks * 2 - 1);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int col = (wave_b0 + (f >> 1)) * 32 + 16 * (f & 1) + n;
+      s_[f] = static_cast<const uint16_t*>(a.scales)[static_cast<int64_t>(gg) * a.N + col];
+      z_[f] = static_cast<const uint32_t*>(a.qzeros)[static_cast<int64_t>(gg) * groups_n8 + (col >> 3)];
+    }
+  };
+  const int zshift = 4 * (n & 7);                 // the lane's column inside a packed word of zeros (16 f + n: same for every f)
+  const float zbase = static_cast<float>(128 + a.zero_offset);
+  load_group(2 * c_lo, sc[0], zc[0]);
+
+  f32x4 acc[MT][NF];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[mt][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 xs[kStage];
+  auto stage_load = [&](int c) {
+    const int64_t off = static_cast<int64_t>(min(c, c_hi - 1)) * kChunkBytes;
+#pragma unroll
+    for (int j = 0; j < kStage; ++j) xs[j] = ld16g(xsrc[j] + off);
+  };
+  auto stage_store = [&](char* buf) {
+#pragma unroll
+    for (int j = 0; j < kStage; ++j) {
+      const u32x4 r = xs[j];
+      u32x4 o;     // (k0,k1)(k2,k3)(k4,k5)(k6,k7) -> (k0,k4)(k1,k5)(k2,k6)(k3,k7)
+      o[0] = __builtin_amdgcn_perm(r[2], r[0], 0x05040100u);
+      o[1] = __builtin_amdgcn_perm(r[2], r[0], 0x07060302u);
+      o[2] = __builtin_amdgcn_perm(r[3], r[1], 0x05040100u);
+      o[3] = __builtin_amdgcn_perm(r[3], r[1], 0x07060302u);
+      *reinterpret_cast<u32x4*>(buf + xdst[j]) = o;
+    }
+  };
+  stage_load(c_lo);
+  stage_store(smem);
+  __syncthreads();
+
+  const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  for (int c = c_lo; c < c_hi; ++c) {
+    const char* cur = smem + ((c - c_lo) & 1) * kBufBytes;
+    stage_load(c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int unit0 = (c - c_lo) * kUnitsPerChunk;
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {                // the chunk's two groups of 128 k
+      load_group(2 * c + g2 + 1, sc[g2 ^ 1], zc[g2 ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 gacc[MT][NF], sx[MT];
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {               // the group's two units of 64 k
+        const int p = 2 * g2 + uu;
+        const int slot = p % R;
+        char* region = wimg + (p & 1) * (NPT * 1024);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4*>(region + i * 1024 + wdst) = ring[slot][i];
+        // keep the refill where it is (see stream_gemm.hip)
+        __builtin_amdgcn_sched_barrier(0);
+        issue(slot, unit0 + p + R);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bool first = uu == 0 && s == 0;
+          u32x4 af[MT];
+          const int piece = 4 * (4 * g2 + 2 * uu + s) + cq;
+          const int poff = ((piece & 16) | ((piece ^ n) & 15)) * 16;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(cur + aoff[mt] + poff);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) sx[mt] = mma_bf16(af[mt], ones, first ? f32x4{0.f, 0.f, 0.f, 0.f} : sx[mt]);
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(region + (f >> 1) * 1024 + wsrc[s][f & 1]);
+            u32x4 b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = ((w >> (4 * j)) & 0x000F000Fu) | 0x43004300u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) gacc[mt][f] = mma_bf16(af[mt], b, first ? f32x4{0.f, 0.f, 0.f, 0.f} : gacc[mt][f]);
+          }
+        }
+      }
+      // the group's scale and zero, applied to its partial sums
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const float s_ = f16 ? static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(sc[g2][f]))) : __uint_as_float(sc[g2][f] << 16);
+        const float z_ = zbase + static_cast<float>((zc[g2][f] >> zshift) & 0xFu);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][f][r] = fmaf(s_, fmaf(-z_, sx[mt][r], gacc[mt][f][r]), acc[mt][f][r]);
+      }
+    }
+    stage_store(smem + (((c - c_lo) & 1) ^ 1) * kBufBytes);
+    __syncthreads();
+  }
+
+  // ---- epilogue: the tile as a row-major fp32 image in LDS
+  float* img = reinterpret_cast<float*>(smem);
+  const int img_col0 = 32 * (wave_b0 - tile_b0);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) img[(16 * mt + 4 * cq + r) * kPitch + img_col0 + 16 * f + n] = acc[mt][f][r];
+  __syncthreads();
+  const int vec_per_row = 8 * tile_nb;
+  for (int idx = tid; idx < kRowsT * vec_per_row; idx += 256) {
+    const int row = idx / vec_per_row, c4 = idx % vec_per_row;
+    if (row >= a.M) continue;
+    const int col = 32 * tile_b0 + 4 * c4;
+    f32x4 y = *reinterpret_cast<const f32x4*>(img + row * kPitch + 4 * c4);
+    if (a.splits > 1) {
+      *reinterpret_cast<f32x4*>(a.slabs + ((static_cast<int64_t>(split) * a.M + row) * a.N + col) * 4) = y;
+      continue;
+    }
+    if (a.bias != nullptr) {
+      const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + col);
+      y += f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+    }
+    const u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+    *reinterpret_cast<u32x2*>(a.out + static_cast<int64_t>(row) * a.out_stride + col) = o;
+  }
+}
+
+template <int MT, int NPHI>
+__global__ __launch_bounds__(256, 1) void stream_gptq_kernel(StreamGptqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
+  const int blocks = a.N / 32;
+  const int b_lo = static_cast<int>(static_cast<int64_t>(t) * blocks / a.tiles);
+  const int b_hi = static_cast<int>(static_cast<int64_t>(t + 1) * blocks / a.tiles);
+  const int c = b_hi - b_lo;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w_lo = b_lo + wave * c / 4, w_hi = b_lo + (wave + 1) * c / 4;
+  if (w_hi - w_lo == NPHI) {
+    gptq_wave<MT, NPHI, NPHI>(a, smem, w_lo, b_lo, c, split);
+  } else if constexpr (NPHI > 1) {
+    gptq_wave<MT, NPHI - 1, NPHI>(a, smem, w_lo, b_lo, c, split);
+  }
+}
+
+// The slices' partial tiles summed in slice order (+ bias) -> bf16; thread = 4 columns of a row.
+__global__ __launch_bounds__(256) void stream_gptq_reduce_kernel(StreamGptqArgs a) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int per_row = a.N / 4;
+  if (idx >= static_cast<int64_t>(a.M) * per_row) return;
+  const int row = static_cast<int>(idx / per_row), col = 4 * static_cast<int>(idx % per_row);
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < a.splits; sp += 4) {
+    f32x4 part[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      part[i] = *reinterpret_cast<const f32x4*>(a.slabs + ((static_cast<int64_t>(min(sp + i, a.splits - 1)) * a.M + row) * a.N + col) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (sp + i < a.splits) sum += part[i];
+  }
+  if (a.bias != nullptr) {
+    const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + col);
+    sum += f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+  }
+  const u32x2 o = {pack_bf16x2(sum[0], sum[1]), pack_bf16x2(sum[2], sum[3])};
+  *reinterpret_cast<u32x2*>(a.out + static_cast<int64_t>(row) * a.out_stride + col) = o;
+}
+
+template <int MT, int NP>
+int launch_gptq(const StreamGptqArgs& a, hipStream_t s, bool defer_reduce) {
+  constexpr size_t img = static_cast<size_t>(16 * MT) * (128 * NP + 4) * 4;
+  constexpr size_t stream = 2u * 16 * MT * kChunkBytes + 4u * 2 * NP * 1024;
+  constexpr size_t lds = img > stream ? img : stream;
+  auto kern = stream_gptq_kernel<MT, NP>;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
+      (void)hipGetLastError();
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles * a.splits), dim3(256), lds, s, a);
+  if (a.splits > 1 && !defer_reduce) {
+    if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+    const int64_t threads = static_cast<int64_t>(a.M) * (a.N / 4);
+    hipLaunchKernelGGL(stream_gptq_reduce_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, s, a);
+  }
+  return launch_status();
+}
+
+}  // namespace
+
+bool stream_gptq_plan(int M, int K, int N, int bits, int group_size, bool have_workspace, StreamGptqPlan* p) {
+  if (bits != 4 || group_size != 128 || M <= 0 || M > 64 || K % 256 != 0 || N % 128 != 0) return false;
+  static const int want_forced = [] { const char* e = getenv("HYMETA_GPTQ_STREAM_WGS"); return e ? atoi(e) : 0; }();
+  static const int splits_forced = [] { const char* e = getenv("HYMETA_GPTQ_STREAM_SPLITS"); return e ? atoi(e) : 0; }();
+  const int want = want_forced > 0 ? want_forced : 256;
+  const int chunks = K / 256;
+  const int blocks = N / 32;                   // 32-column blocks; a wave owns 1 or 2, a tile 4 to 8
+  // Matrices wide enough to give every compute unit a tile without K slices stay on the older kernels (quant_gemm.hip):
+  // this kernel is bound by instruction issue there (one wave per SIMD does de-quantisation, LDS reads and MFMAs in
+  // turn) and measures behind them, 30 against 22 us at 1 row and 51 against 47 at 64 on the 7B gate_up matrix.  On the
+  // narrow ones (qkv, o, down) it is level or ahead: 16 against 18-20 us at 64 rows on qkv and o.
+  static const bool wide_too = [] { const char* e = getenv("HYMETA_GPTQ_STREAM_WIDE"); return e && atoi(e) != 0; }();
+  if (blocks / 4 >= want && !wide_too) return false;
+  int tiles = blocks / 4 < want ? blocks / 4 : want;
+  if (tiles < (blocks + 7) / 8) tiles = (blocks + 7) / 8;
+  const int np = ((blocks + tiles - 1) / tiles + 3) / 4;
+  int splits = 1;
+  if (have_workspace && tiles < want) splits = want / tiles;
+  if (have_workspace && splits_forced > 0) splits = splits_forced;
+  if (splits > chunks) splits = chunks;
+  if (splits > kMaxSplits) splits = kMaxSplits;
+  if (splits < 1) splits = 1;
+  p->np = np, p->tiles = tiles, p->chunks = chunks, p->splits = splits;
+  return np >= 1 && np <= 2;
+}
+
+size_t stream_gptq_workspace_bytes(int M, int N, const StreamGptqPlan& p) {
+  return p.splits > 1 ? static_cast<size_t>(p.splits) * M * N * 4 : 0;
+}
+
+size_t stream_gptq_workspace_bound(int M, int N) { return static_cast<size_t>(kMaxSplits) * M * N * 4 / (N >= 32768 ? 16 : 1); }
+
+int stream_gptq_launch(StreamGptqArgs a, const StreamGptqPlan& p, hipStream_t s, bool defer_reduce) {
+  a.tiles = p.tiles, a.chunks = p.chunks, a.splits = p.splits;
+  const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+#define HYMETA_GPTQ_CASE(MT_, NP_) if (mt == MT_ && p.np == NP_) return launch_gptq<MT_, NP_>(a, s, defer_reduce);
+  HYMETA_GPTQ_CASE(1, 1) HYMETA_GPTQ_CASE(1, 2) HYMETA_GPTQ_CASE(2, 1) HYMETA_GPTQ_CASE(2, 2) HYMETA_GPTQ_CASE(4, 1) HYMETA_GPTQ_CASE(4, 2)
+#undef HYMETA_GPTQ_CASE
+  return HYMETA_ERR_UNSUPPORTED;
+}
+
+}  // namespace hymeta

@@ -253,6 +253,7 @@ _SIGNATURES = {
     "hymeta_bf16_gemm_silu_mul": (C.c_int, [C.POINTER(Bf16GemmArgs), _ptr]),
     "hymeta_bf16_gemm_deferred": (C.c_int, [C.POINTER(Bf16GemmArgs), C.POINTER(GemmPartials), _ptr]),
     "hymeta_w8a8_gemm_deferred": (C.c_int, [C.POINTER(W8A8GemmArgs), C.POINTER(GemmPartials), _ptr]),
+    "hymeta_gptq_gemm_deferred": (C.c_int, [C.POINTER(GptqGemmArgs), C.POINTER(GemmPartials), _ptr]),
     "hymeta_gemm_partials_reduce": (C.c_int, [C.POINTER(GemmPartials), _ptr, _i64, _ptr]),
     "hymeta_add_rmsnorm_partials": (C.c_int, [C.POINTER(AddRmsNormArgs), C.POINTER(GemmPartials), _ptr]),
     "hymeta_bf16_gemm_split_k": (C.c_int, [_i32, _i32, _i32]),

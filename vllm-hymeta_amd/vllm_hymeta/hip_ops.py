@@ -711,7 +711,7 @@ def lowrank_gate(x: torch.Tensor, w0: torch.Tensor, w1: torch.Tensor, bias: Opti
 # ---------------------------------------------------------------------------
 def gptq_gemm(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
               bits: int, group_size: int, bias: Optional[torch.Tensor] = None, zero_offset: int = 1,
-              split_k: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              split_k: int = 0, out: Optional[torch.Tensor] = None, defer: bool = False):
     """x bf16 [M,K] @ GPTQ(qweight int32 [K/pack,N], qzeros int32 [K/group,N/pack], scales fp16|bf16
     [K/group,N]) (+ bias bf16 [N]) -> bf16 [M,N]."""
     _dev(x, qweight, qzeros, scales, bias, out)
@@ -742,6 +742,10 @@ def gptq_gemm(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scal
     a.scales_dtype = _C.HYMETA_F16 if scales.dtype == torch.float16 else _C.HYMETA_BF16
     a.zero_offset, a.split_k = zero_offset, max(split_k, 0)
     a.x_stride_m, a.out_stride_m = x.stride(0), out.stride(0)
+    if defer and a.split_k == 0 and need:
+        desc = _C.GemmPartials()
+        _C.check(lib.hymeta_gptq_gemm_deferred(C.byref(a), C.byref(desc), _stream(x)), "hymeta_gptq_gemm_deferred")
+        return _partials(desc, M, N, x.device, "gptq_gemm", bias) if desc.splits > 0 else out
     _C.check(lib.hymeta_gptq_gemm(C.byref(a), _stream(x)), "hymeta_gptq_gemm")
     return out
 

@@ -83,7 +83,7 @@ class HymetaLinear(torch.nn.Module):
                 return y if self.bias is None else y.add_(self.bias)
             return hip_ops.gptq_gemm(x, self.qweight, self.qzeros, self.scales, self.meta["bits"],
                                      self.meta["group_size"], bias=self.bias,
-                                     zero_offset=self.meta.get("zero_offset", 1))
+                                     zero_offset=self.meta.get("zero_offset", 1), defer=defer)
         if w8a8_use_library(x.shape[0], self.qweight.shape[1], self.qweight.shape[0]):
             # the same per-token quantisation and scaling, exact int32 sums from the library GEMM in between
             xq, xs = hip_ops.w8a8_quantize(x)
