@@ -286,10 +286,17 @@ def kernel_table(runner, quant):
         rows[name] = {"us": round(ms * 1e3, 2), "gbs": round(nbytes / (ms * 1e-3) / 1e9, 1), "bytes": int(nbytes)}
 
     wb = WBYTES[quant]
+    # the projections as the step runs them: the K slices of o_proj / down_proj are summed by the fused add + norm that
+    # follows (timed with it), gate_up carries silu * mul in its epilogue where the kernel has one (bf16, W8A8)
+    res = torch.zeros(B, HIDDEN, device=dev, dtype=torch.bfloat16)
+
+    def with_norm(proj, inp, norm):
+        return lambda: [norm(proj(l)(inp, defer=True), res) for l in layers]
+
     add("qkv_proj", lambda: [l.attn.qkv_proj(x) for l in layers], len(layers), (H + 2 * HKV) * D * HIDDEN * wb)
-    add("o_proj", lambda: [l.attn.o_proj(xa) for l in layers], len(layers), HIDDEN * H * D * wb)
-    add("gate_up_proj", lambda: [l.mlp.gate_up_proj(x) for l in layers], len(layers), 2 * INTER * HIDDEN * wb)
-    add("down_proj", lambda: [l.mlp.down_proj(xi) for l in layers], len(layers), HIDDEN * INTER * wb)
+    add("o_proj + add_rmsnorm", with_norm(lambda l: l.attn.o_proj, xa, layers[0].mlp_norm), len(layers), HIDDEN * H * D * wb)
+    add("gate_up_proj + silu_mul", lambda: [l.mlp.gate_up_proj.forward_silu_mul(x) for l in layers], len(layers), 2 * INTER * HIDDEN * wb)
+    add("down_proj + add_rmsnorm", with_norm(lambda l: l.mlp.down_proj, xi, layers[0].attn_norm), len(layers), HIDDEN * INTER * wb)
     qkv = (torch.randn(B, (H + 2 * HKV) * D, device=dev)).to(torch.bfloat16)
     q, k, v = qkv[:, : H * D].view(B, H, D), qkv[:, H * D:(H + HKV) * D].view(B, HKV, D), qkv[:, (H + HKV) * D:].view(B, HKV, D)
     out = torch.empty(B, H, D, device=dev, dtype=torch.bfloat16)
