@@ -88,6 +88,12 @@ class MetaAttentionBackend(AttentionBackend):
         return MetaAttentionMetadataBuilder
 
     @staticmethod
+    def get_builder_cls_v1():
+        """The V1 engine's builder (the reference serves through V0 only; see ``meta_attention_v1``)."""
+        from .meta_attention_v1 import MetaAttentionMetadataBuilderV1
+        return MetaAttentionMetadataBuilderV1
+
+    @staticmethod
     def get_state_cls():
         from vllm.attention.backends.utils import CommonAttentionState
         return CommonAttentionState
