@@ -640,7 +640,7 @@ int hymeta_bf16_gemm_silu_mul(const hymeta_bf16_gemm_args* args, hymeta_stream_t
  * library choose when a workspace is given, and means 1 without one.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_w8a8_gemm_args {
-  const void* x;           /* bf16 [M, K] */
+  const void* x;           /* bf16 [M, K]; NULL: xq / x_scale below already hold the quantised rows (inputs) */
   const int8_t* qweight;   /* int8 [N, K] */
   const float* w_scale;    /* fp32 [N] */
   const void* bias;        /* bf16 [N] or NULL */
@@ -692,6 +692,12 @@ int hymeta_gemm_partials_reduce(const hymeta_gemm_partials* partials, void* out,
 /* hymeta_add_rmsnorm with x = the linear's result taken from its partial sums (args->x is ignored; args->residual
  * must be given; num_tokens == M, hidden == N). */
 int hymeta_add_rmsnorm_partials(const hymeta_add_rmsnorm_args* args, const hymeta_gemm_partials* partials, hymeta_stream_t stream);
+/* hymeta_add_rmsnorm (partials NULL or splits 0) or hymeta_add_rmsnorm_partials that ALSO writes the dynamic per-token
+ * int8 quantisation of its bf16 output -- xq int8 [num_tokens, hidden] contiguous, x_scale fp32 [num_tokens], the bits
+ * hymeta_w8a8_quantize gives on that output -- for the W8A8 linear that consumes the norm (qkv_proj, gate_up_proj):
+ * called with x == NULL and these two buffers, hymeta_w8a8_gemm / _silu_mul / _deferred skip their quantise launch. */
+int hymeta_add_rmsnorm_int8(const hymeta_add_rmsnorm_args* args, const hymeta_gemm_partials* partials, int8_t* xq,
+                            float* x_scale, hymeta_stream_t stream);
 
 
 /* The two ends of the same linear for prefill-sized M, where the host side puts a library int8

@@ -232,3 +232,46 @@ def test_tensor_parallel_gptq_mlp_shards_sum_to_the_unsharded_layer(tp):
         total += dn(hip_ops.silu_and_mul(gu(x.cuda()))).float()
     torch.cuda.synchronize()
     assert_bf16_close(total.cpu(), ref, f"tp={tp} GPTQ MLP", rel=1e-2)
+
+
+@pytest.mark.parametrize("partials", [False, True])
+def test_norm_that_quantises_its_output_feeds_w8a8_linears(partials):
+    """The block norm can write the int8 quantisation of its output in the same launch; the rows equal the stand-alone
+    quantise kernel's bit for bit, and W8A8 linears (plain and gated) called on that tensor give the bits of the plain
+    calls."""
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta.linear import HymetaLinear
+
+    g_ = gen(77)
+    M, hidden, inter = 48, 3584, 1024
+    w = (1 + 0.1 * torch.randn(hidden, generator=g_)).to(torch.bfloat16).cuda()
+    res = randn_bf16(g_, M, hidden).cuda()
+    if partials:
+        src = HymetaLinear.from_weight(randn_bf16(g_, hidden, 2048, scale=2048 ** -0.5).cuda())
+        xin = randn_bf16(g_, M, 2048).cuda()
+        make_x = lambda: src(xin, defer=True)
+        assert isinstance(make_x(), hip_ops.PartialSums)
+    else:
+        x0 = randn_bf16(g_, M, hidden).cuda()
+        make_x = lambda: x0
+    r1, r2 = res.clone(), res.clone()
+    plain = hip_ops.add_rmsnorm(make_x(), w, 1e-6, residual=r1)
+    fused = hip_ops.add_rmsnorm(make_x(), w, 1e-6, residual=r2, int8=True)
+    xq, xs = hip_ops.int8_rows_of(fused)
+    xq_ref, xs_ref = hip_ops.w8a8_quantize(plain)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, fused) and torch.equal(r1, r2) and hip_ops.int8_rows_of(plain) is None
+    assert torch.equal(xq, xq_ref) and torch.equal(xs, xs_ref)
+    qkv = HymetaLinear.from_w8a8(torch.randint(-127, 128, (4608, hidden), generator=g_, dtype=torch.int8).cuda(),
+                                 (torch.rand(4608, generator=g_) * 0.02 + 0.001).cuda(), randn_bf16(g_, 4608).cuda())
+    gate_up = HymetaLinear.from_w8a8(torch.randint(-127, 128, (2 * inter, hidden), generator=g_, dtype=torch.int8).cuda(),
+                                     (torch.rand(2 * inter, generator=g_) * 0.02 + 0.001).cuda())
+    a, b = qkv(fused), qkv(plain)
+    c, d = gate_up.forward_silu_mul(fused), gate_up.forward_silu_mul(plain)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(c, d)
+    # no residual (the first block's norm)
+    first = hip_ops.add_rmsnorm(plain, w, 1e-6, int8=True)
+    q2, s2 = hip_ops.w8a8_quantize(hip_ops.add_rmsnorm(plain, w, 1e-6))
+    torch.cuda.synchronize()
+    assert torch.equal(hip_ops.int8_rows_of(first)[0], q2) and torch.equal(hip_ops.int8_rows_of(first)[1], s2)

@@ -1,6 +1,7 @@
 // Element-wise glue of the attention layers: NeoX rotary embedding, the 70B
 // two-branch RMS-norm combine and the blocks' RMS norm with the residual add.  HBM-bound; 16-byte accesses throughout.
 #include "common.h"
+#include "w8a8_quant.h"
 
 namespace hymeta {
 
@@ -116,8 +117,10 @@ __global__ __launch_bounds__(256) void hybrid_combine_kernel(hymeta_combine_args
 
 // One workgroup per token.  With a residual: z = bf16(x + residual) is written over the residual
 // and read back by the same thread for the second pass.
-template <bool ADD>
-__global__ __launch_bounds__(256) void add_rmsnorm_kernel(hymeta_add_rmsnorm_args a) {
+// Q: also the row's dynamic int8 quantisation (xq [T, hidden], x_scale [T]) of the bf16 output, for a W8A8 linear that
+// consumes it: the linear then skips its own quantise launch.
+template <bool ADD, bool Q>
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(hymeta_add_rmsnorm_args a, int8_t* xq, float* x_scale) {
   __shared__ float s_red[4];
   const int64_t t = blockIdx.x;
   const uint16_t* x = reinterpret_cast<const uint16_t*>(a.x) + t * a.x_stride_t;
@@ -150,13 +153,15 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(hymeta_add_rmsnorm_arg
       o[i] = pack_bf16x2(bf16_round(lo_bf(z[i]) * rs) * lo_bf(wv[i]), bf16_round(hi_bf(z[i]) * rs) * hi_bf(wv[i]));
     st16(out + 8 * c, o);
   }
+  if constexpr (Q) quantise_row_int8(out, a.hidden, xq + t * a.hidden, x_scale + t, s_red);
 }
 
 // add_rmsnorm_kernel<true> whose x is a K-sliced linear's result still in partial sums: slices added in slice order,
 // W8A8 scales and the bias applied, the sum rounded to bf16 -- the bits the linear's own reduce launch would have
 // written -- then z = bf16(x + residual) as above.
-template <bool I8>
-__global__ __launch_bounds__(256) void add_rmsnorm_partials_kernel(hymeta_add_rmsnorm_args a, hymeta_gemm_partials p) {
+template <bool I8, bool Q>
+__global__ __launch_bounds__(256) void add_rmsnorm_partials_kernel(hymeta_add_rmsnorm_args a, hymeta_gemm_partials p, int8_t* xq,
+                                                                   float* x_scale) {
   __shared__ float s_red[4];
   const int64_t t = blockIdx.x;
   uint16_t* res = reinterpret_cast<uint16_t*>(a.residual) + t * a.residual_stride_t;
@@ -239,14 +244,15 @@ __global__ __launch_bounds__(256) void add_rmsnorm_partials_kernel(hymeta_add_rm
       o[i] = pack_bf16x2(bf16_round(lo_bf(z[i]) * rs) * lo_bf(wv[i]), bf16_round(hi_bf(z[i]) * rs) * hi_bf(wv[i]));
     st16(out + 8 * c, o);
   }
+  if constexpr (Q) quantise_row_int8(out, a.hidden, xq + t * a.hidden, x_scale + t, s_red);
 }
 
 }  // namespace hymeta
 
 using namespace hymeta;
 
-extern "C" int hymeta_add_rmsnorm_partials(const hymeta_add_rmsnorm_args* args, const hymeta_gemm_partials* partials,
-                                           hymeta_stream_t stream) {
+static int add_rmsnorm_partials_impl(const hymeta_add_rmsnorm_args* args, const hymeta_gemm_partials* partials, int8_t* xq,
+                                     float* x_scale, hymeta_stream_t stream) {
   if (args == nullptr || partials == nullptr) return HYMETA_ERR_INVALID_ARG;
   const hymeta_add_rmsnorm_args& a = *args;
   const hymeta_gemm_partials& p = *partials;
@@ -257,11 +263,23 @@ extern "C" int hymeta_add_rmsnorm_partials(const hymeta_add_rmsnorm_args* args, 
   if (p.is_int32 && (!p.x_scale || !p.w_scale)) return HYMETA_ERR_INVALID_ARG;
   if (a.hidden % 8 != 0 || (a.out_stride_t | a.residual_stride_t) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(p.slabs) | reinterpret_cast<uintptr_t>(a.residual) | reinterpret_cast<uintptr_t>(a.weight) |
-       reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(p.bias)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+       reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(xq)) % 16 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
   hipStream_t s = begin_launches(stream);
-  if (p.is_int32) hipLaunchKernelGGL((add_rmsnorm_partials_kernel<true>), dim3(a.num_tokens), dim3(256), 0, s, a, p);
-  else hipLaunchKernelGGL((add_rmsnorm_partials_kernel<false>), dim3(a.num_tokens), dim3(256), 0, s, a, p);
+  const dim3 grid(a.num_tokens), block(256);
+  if (xq != nullptr) {
+    if (p.is_int32) hipLaunchKernelGGL((add_rmsnorm_partials_kernel<true, true>), grid, block, 0, s, a, p, xq, x_scale);
+    else hipLaunchKernelGGL((add_rmsnorm_partials_kernel<false, true>), grid, block, 0, s, a, p, xq, x_scale);
+  } else {
+    if (p.is_int32) hipLaunchKernelGGL((add_rmsnorm_partials_kernel<true, false>), grid, block, 0, s, a, p, xq, x_scale);
+    else hipLaunchKernelGGL((add_rmsnorm_partials_kernel<false, false>), grid, block, 0, s, a, p, xq, x_scale);
+  }
   return launch_status();
+}
+
+extern "C" int hymeta_add_rmsnorm_partials(const hymeta_add_rmsnorm_args* args, const hymeta_gemm_partials* partials,
+                                           hymeta_stream_t stream) {
+  return add_rmsnorm_partials_impl(args, partials, nullptr, nullptr, stream);
 }
 
 extern "C" int hymeta_rope_neox(const hymeta_rope_args* args, hymeta_stream_t stream) {
@@ -399,7 +417,7 @@ extern "C" int hymeta_lowrank_gate(const hymeta_lowrank_gate_args* args, hymeta_
   return hymeta::launch_status();
 }
 
-extern "C" int hymeta_add_rmsnorm(const hymeta_add_rmsnorm_args* args, hymeta_stream_t stream) {
+static int add_rmsnorm_impl(const hymeta_add_rmsnorm_args* args, int8_t* xq, float* x_scale, hymeta_stream_t stream) {
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
   const hymeta_add_rmsnorm_args& a = *args;
   if (a.num_tokens < 0 || a.hidden <= 0) return HYMETA_ERR_INVALID_ARG;
@@ -407,9 +425,26 @@ extern "C" int hymeta_add_rmsnorm(const hymeta_add_rmsnorm_args* args, hymeta_st
   if (!a.x || !a.weight || !a.out) return HYMETA_ERR_INVALID_ARG;
   if (a.hidden % 8 != 0 || (a.x_stride_t | a.out_stride_t | (a.residual ? a.residual_stride_t : 0)) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.residual) | reinterpret_cast<uintptr_t>(a.weight) |
-       reinterpret_cast<uintptr_t>(a.out)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+       reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(xq)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
   hipStream_t s = begin_launches(stream);
-  if (a.residual != nullptr) hipLaunchKernelGGL((add_rmsnorm_kernel<true>), dim3(a.num_tokens), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((add_rmsnorm_kernel<false>), dim3(a.num_tokens), dim3(256), 0, s, a);
+  const dim3 grid(a.num_tokens), block(256);
+  if (xq != nullptr) {
+    if (a.residual != nullptr) hipLaunchKernelGGL((add_rmsnorm_kernel<true, true>), grid, block, 0, s, a, xq, x_scale);
+    else hipLaunchKernelGGL((add_rmsnorm_kernel<false, true>), grid, block, 0, s, a, xq, x_scale);
+  } else {
+    if (a.residual != nullptr) hipLaunchKernelGGL((add_rmsnorm_kernel<true, false>), grid, block, 0, s, a, xq, x_scale);
+    else hipLaunchKernelGGL((add_rmsnorm_kernel<false, false>), grid, block, 0, s, a, xq, x_scale);
+  }
   return launch_status();
+}
+
+extern "C" int hymeta_add_rmsnorm(const hymeta_add_rmsnorm_args* args, hymeta_stream_t stream) {
+  return add_rmsnorm_impl(args, nullptr, nullptr, stream);
+}
+
+extern "C" int hymeta_add_rmsnorm_int8(const hymeta_add_rmsnorm_args* args, const hymeta_gemm_partials* partials, int8_t* xq,
+                                       float* x_scale, hymeta_stream_t stream) {
+  if (xq == nullptr || x_scale == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (partials != nullptr && partials->splits > 0) return add_rmsnorm_partials_impl(args, partials, xq, x_scale, stream);
+  return add_rmsnorm_impl(args, xq, x_scale, stream);
 }

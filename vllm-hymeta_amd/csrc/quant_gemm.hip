@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "stream_gemm.h"
+#include "w8a8_quant.h"
 
 namespace hymeta {
 namespace {
@@ -681,42 +682,12 @@ __global__ __launch_bounds__(256) void gptq_dequant_kernel(const int32_t* __rest
 // ---------------------------------------------------------------------------------------------
 // W8A8
 // ---------------------------------------------------------------------------------------------
-// One workgroup per token row: s = max|x| / 127, xq = clamp(rint(x / s)).
+// One workgroup per token row: s = max|x| / 127, xq = clamp(rint(x / s)) (w8a8_quant.h).
 __global__ __launch_bounds__(256) void w8a8_quant_kernel(hymeta_w8a8_gemm_args a) {
   __shared__ float s_red[4];
   const int m = blockIdx.x;
-  const uint16_t* x = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(m) * a.x_stride_m;
-  const int chunks = a.K / 8;
-  float mx = 0.f;
-  for (int ch = threadIdx.x; ch < chunks; ch += blockDim.x) {
-    const u32x4 v = ld16(x + 8 * ch);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) mx = fmaxf(mx, fmaxf(fabsf(lo_bf(v[i])), fabsf(hi_bf(v[i]))));
-  }
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-  const float scale = fmaxf(mx, 1e-10f) / 127.f;
-  if (threadIdx.x == 0) a.x_scale[m] = scale;
-  const float inv = 1.f / scale;
-  int8_t* q = a.xq + static_cast<int64_t>(m) * a.K;
-  for (int ch = threadIdx.x; ch < chunks; ch += blockDim.x) {
-    const u32x4 v = ld16(x + 8 * ch);
-    uint32_t w[2] = {0u, 0u};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float f[2] = {lo_bf(v[i]), hi_bf(v[i])};
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int qi = static_cast<int>(fminf(fmaxf(rintf(f[e] * inv), -128.f), 127.f));
-        const int j = 2 * i + e;
-        w[j >> 2] |= (static_cast<uint32_t>(qi) & 0xffu) << (8 * (j & 3));
-      }
-    }
-    *reinterpret_cast<u32x2*>(q + 8 * ch) = u32x2{w[0], w[1]};
-  }
+  quantise_row_int8(reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(m) * a.x_stride_m, a.K,
+                    a.xq + static_cast<int64_t>(m) * a.K, a.x_scale + m, s_red);
 }
 
 // out = bf16(acc * x_scale[m] * w_scale[n] + bias[n]): thread = 4 columns of one row
@@ -1106,7 +1077,7 @@ static int w8a8_gemm_impl(const hymeta_w8a8_gemm_args* args, hymeta_stream_t str
   const hymeta_w8a8_gemm_args& a = *args;
   if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;
-  if (!a.x || !a.qweight || !a.w_scale || !a.out || !a.xq || !a.x_scale) return HYMETA_ERR_INVALID_ARG;
+  if (!a.qweight || !a.w_scale || !a.out || !a.xq || !a.x_scale) return HYMETA_ERR_INVALID_ARG;   // x NULL: xq / x_scale are inputs
   if (a.K % 64 != 0 || a.N % kColsPerBlock != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((a.x_stride_m | a.out_stride_m) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.qweight) | reinterpret_cast<uintptr_t>(a.out) |
@@ -1122,8 +1093,10 @@ static int w8a8_gemm_impl(const hymeta_w8a8_gemm_args* args, hymeta_stream_t str
     if (stream_gemm_plan(a.M, a.K, a.N, have_ws, &plan) &&
         (!have_ws || a.workspace_bytes >= kTicketBytes + stream_gemm_workspace_bytes(a.M, a.N, plan))) {
       hipStream_t s = begin_launches(stream);
-      hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
-      if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+      if (a.x != nullptr) {
+        hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
+        if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+      }
       StreamArgs sa = {};
       sa.x = reinterpret_cast<const char*>(a.xq), sa.w = reinterpret_cast<const char*>(a.qweight);
       sa.bias = static_cast<const uint16_t*>(a.bias), sa.out = static_cast<uint16_t*>(a.out);
@@ -1150,8 +1123,10 @@ static int w8a8_gemm_impl(const hymeta_w8a8_gemm_args* args, hymeta_stream_t str
   hipStream_t s = begin_launches(stream);
   int* counters = static_cast<int*>(a.workspace);
   int* slabs = reinterpret_cast<int*>(static_cast<char*>(a.workspace) + kTicketBytes);
-  hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
-  if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+  if (a.x != nullptr) {
+    hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
+    if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+  }
   const int mt = mt_for(a.M);
   dim3 grid(a.N / kColsPerBlock, (a.M + 16 * mt - 1) / (16 * mt), splits), block(256);
   const size_t lds = static_cast<size_t>(4) * 16 * mt * kColsPerBlock * sizeof(int);
@@ -1209,7 +1184,7 @@ extern "C" int hymeta_w8a8_gemm_silu_mul(const hymeta_w8a8_gemm_args* args, hyme
   const hymeta_w8a8_gemm_args& a = *args;
   if (a.M < 0 || a.K <= 0 || a.N <= 0 || a.bias != nullptr) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;
-  if (!a.x || !a.qweight || !a.w_scale || !a.out || !a.xq || !a.x_scale) return HYMETA_ERR_INVALID_ARG;
+  if (!a.qweight || !a.w_scale || !a.out || !a.xq || !a.x_scale) return HYMETA_ERR_INVALID_ARG;   // x NULL: xq / x_scale are inputs
   if (a.K % 64 != 0 || (a.x_stride_m | a.out_stride_m) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.qweight) | reinterpret_cast<uintptr_t>(a.out) |
        reinterpret_cast<uintptr_t>(a.xq) | reinterpret_cast<uintptr_t>(a.w_scale)) % 16 != 0)
@@ -1217,8 +1192,10 @@ extern "C" int hymeta_w8a8_gemm_silu_mul(const hymeta_w8a8_gemm_args* args, hyme
   StreamPlan plan;
   if (!stream_gemm_plan_gated(a.M, a.K, a.N, &plan)) return HYMETA_ERR_UNSUPPORTED;
   hipStream_t s = begin_launches(stream);
-  hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
-  if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+  if (a.x != nullptr) {
+    hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
+    if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+  }
   StreamArgs sa = {};
   sa.x = reinterpret_cast<const char*>(a.xq), sa.w = reinterpret_cast<const char*>(a.qweight);
   sa.out = static_cast<uint16_t*>(a.out);

@@ -644,11 +644,24 @@ def hybrid_combine(o_attn: torch.Tensor, o_lin: torch.Tensor, weight1: torch.Ten
     return out
 
 
+INT8_ROWS_ATTR = "_hymeta_int8_rows"
+
+
+def int8_rows_of(x: torch.Tensor):
+    """``(xq int8 [T, K], x_scale fp32 [T])`` a producer attached to exactly this tensor object (``add_rmsnorm(...,
+    int8=True)``), or None.  A view or copy of the tensor does not carry them."""
+    return getattr(x, INT8_ROWS_ATTR, None)
+
+
 def add_rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, residual: Optional[torch.Tensor] = None,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, int8: bool = False) -> torch.Tensor:
     """RMS norm of the decoder blocks.  With ``residual``: residual <- bf16(x + residual) in place
     and the norm is taken of that sum (the blocks' ``mlp_norm(hidden, residual)`` call).  ``x`` may be the
-    ``PartialSums`` of a K-sliced linear (needs ``residual``): the slices are added as the input is read."""
+    ``PartialSums`` of a K-sliced linear (needs ``residual``): the slices are added as the input is read.
+
+    ``int8``: the launch also writes the dynamic per-token int8 quantisation of its output (the bits ``w8a8_quantize``
+    gives) and attaches ``(xq, x_scale)`` to the returned tensor (``int8_rows_of``); a W8A8 linear called on that very
+    tensor skips its own quantise launch."""
     if isinstance(x, PartialSums):
         x.check_live()
         M, N = x.shape
@@ -661,6 +674,13 @@ def add_rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, residu
         _require(out.shape == (M, N) and out.dtype == torch.bfloat16 and out.stride(1) == 1, "out must be row-contiguous bf16 [T, hidden]")
         a = _C.AddRmsNormArgs(x=None, residual=residual.data_ptr(), weight=weight.data_ptr(), out=out.data_ptr(), num_tokens=M,
                               hidden=N, x_stride_t=0, residual_stride_t=residual.stride(0), out_stride_t=out.stride(0), eps=eps)
+        if int8:
+            xq = torch.empty(M, N, dtype=torch.int8, device=out.device)
+            xs = torch.empty(M, dtype=torch.float32, device=out.device)
+            _C.check(_C.load().hymeta_add_rmsnorm_int8(C.byref(a), C.byref(x.desc), _p(xq), _p(xs), _stream(residual)),
+                     "hymeta_add_rmsnorm_int8")
+            setattr(out, INT8_ROWS_ATTR, (xq, xs))
+            return out
         _C.check(_C.load().hymeta_add_rmsnorm_partials(C.byref(a), C.byref(x.desc), _stream(residual)), "hymeta_add_rmsnorm_partials")
         return out
     _dev(x, weight, residual, out)
@@ -677,6 +697,12 @@ def add_rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, residu
                           weight=weight.data_ptr(), out=out.data_ptr(), num_tokens=x.shape[0], hidden=x.shape[1],
                           x_stride_t=x.stride(0), residual_stride_t=residual.stride(0) if residual is not None else 0,
                           out_stride_t=out.stride(0), eps=eps)
+    if int8:
+        xq = torch.empty(x.shape, dtype=torch.int8, device=out.device)
+        xs = torch.empty(x.shape[0], dtype=torch.float32, device=out.device)
+        _C.check(_C.load().hymeta_add_rmsnorm_int8(C.byref(a), None, _p(xq), _p(xs), _stream(x)), "hymeta_add_rmsnorm_int8")
+        setattr(out, INT8_ROWS_ATTR, (xq, xs))
+        return out
     _C.check(_C.load().hymeta_add_rmsnorm(C.byref(a), _stream(x)), "hymeta_add_rmsnorm")
     return out
 
@@ -838,11 +864,12 @@ def w8a8_gemm(x: torch.Tensor, qweight: torch.Tensor, w_scale: torch.Tensor,
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
     _require(out.shape == (M, N) and out.dtype == torch.bfloat16 and out.stride(1) == 1, "out must be bf16 [M, N]")
-    xq = torch.empty(M, K, dtype=torch.int8, device=x.device)
-    xs = torch.empty(M, dtype=torch.float32, device=x.device)
+    ready = int8_rows_of(x)
+    xq, xs = ready if ready is not None else (torch.empty(M, K, dtype=torch.int8, device=x.device),
+                                              torch.empty(M, dtype=torch.float32, device=x.device))
     a = _C.W8A8GemmArgs()
     a.x, a.qweight, a.w_scale, a.bias, a.out, a.xq, a.x_scale = (
-        _p(x), _p(qweight), _p(w_scale), _p(bias), _p(out), _p(xq), _p(xs))
+        None if ready is not None else _p(x), _p(qweight), _p(w_scale), _p(bias), _p(out), _p(xq), _p(xs))
     a.M, a.K, a.N = M, K, N
     a.x_stride_m, a.out_stride_m = x.stride(0), out.stride(0)
     lib = _C.load()
@@ -890,10 +917,12 @@ def gemm_silu_mul(x: torch.Tensor, weight: torch.Tensor, w_scale: Optional[torch
         return out
     _require(w_scale is not None and w_scale.dtype == torch.float32 and w_scale.is_contiguous() and w_scale.numel() == N,
              "w_scale must be contiguous fp32 [2 I]")
-    xq = torch.empty(M, K, dtype=torch.int8, device=x.device)
-    xs = torch.empty(M, dtype=torch.float32, device=x.device)
+    ready = int8_rows_of(x)
+    xq, xs = ready if ready is not None else (torch.empty(M, K, dtype=torch.int8, device=x.device),
+                                              torch.empty(M, dtype=torch.float32, device=x.device))
     a = _C.W8A8GemmArgs()
-    a.x, a.qweight, a.w_scale, a.out, a.xq, a.x_scale = _p(x), _p(weight), _p(w_scale), _p(out), _p(xq), _p(xs)
+    a.x, a.qweight, a.w_scale, a.out, a.xq, a.x_scale = (None if ready is not None else _p(x), _p(weight), _p(w_scale), _p(out),
+                                                         _p(xq), _p(xs))
     a.M, a.K, a.N = M, K, N
     a.x_stride_m, a.out_stride_m = x.stride(0), out.stride(0)
     _C.check(lib.hymeta_w8a8_gemm_silu_mul(C.byref(a), _stream(x)), "hymeta_w8a8_gemm_silu_mul")
@@ -905,6 +934,8 @@ def w8a8_quantize(x: torch.Tensor):
     _dev(x)
     M, K = x.shape
     _require(x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [M, K]")
+    if int8_rows_of(x) is not None:
+        return int8_rows_of(x)
     xq = torch.empty(M, K, dtype=torch.int8, device=x.device)
     xs = torch.empty(M, dtype=torch.float32, device=x.device)
     _C.check(_C.load().hymeta_w8a8_quantize(_p(x), _p(xq), _p(xs), M, K, x.stride(0), _stream(x)), "hymeta_w8a8_quantize")
