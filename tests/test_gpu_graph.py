@@ -103,3 +103,86 @@ def test_decode_step_replays_from_a_graph():
         rows = B - 1 if pad else B      # the padded row's linear-attention output is left unwritten
         assert torch.equal(out_g[:rows], out_e[:rows]), "graph replay differs from the eager step"
         assert torch.equal(kv_g, kv_e) and torch.equal(state_g, state_e) and torch.equal(res_buf, res_e)
+
+
+@pytest.mark.parametrize("quant", ["bf16", "w8a8"])
+def test_whole_model_decode_step_replays_from_a_graph(quant):
+    """The 7B model class's decode step (streaming linears with K slices summed by the norms, the gate folded into qkv and
+    gla_decode, int8 rows written by the norms for W8A8) captured after an eager warm-up and replayed three times with
+    eager work and new inputs between the replays: every replay equals the eager step on the same inputs and states."""
+    from test_gpu_layers import _md
+    from test_gpu_model_7b import _checkpoint
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta.model_for_7B.configuration_gla_swa import GLAswaConfig
+    from vllm_hymeta.model_for_7B.modeling_gla_swa import GLAswaForCausalLM
+
+    dev = torch.device("cuda")
+    g_ = gen(21)
+    cfg = GLAswaConfig(vocab_size=256, hidden_size=1024, num_hidden_layers=4, num_attention_heads=8, num_key_value_heads=2,
+                       intermediate_size=2048, sliding_window=40, max_position_embeddings=512)
+    ckpt = _checkpoint(g_, cfg)
+    if quant == "w8a8":
+        import re
+        for name in list(ckpt):
+            if re.search(r"\.(q_proj|k_proj|v_proj|o_proj|gate_proj|up_proj|down_proj)\.weight$", name):
+                w = ckpt[name].float()
+                s = w.abs().amax(1, keepdim=True).clamp_min(1e-8) / 127
+                ckpt[name] = torch.clamp(torch.round(w / s), -127, 127).to(torch.int8)
+                ckpt[name + "_scale"] = s.float()
+    B, bs, ctx = 20, 16, 70          # 17 rows and more: the W8A8 linears take the streaming kernel too
+    model = GLAswaForCausalLM(cfg, max_num_seqs=B, device=dev)
+    model.load_weights(ckpt.items())
+    lin = model.model.layers[0].mlp.down_proj
+    assert lin.kind == quant and isinstance(lin(randn_bf16(g_, B, 2048).cuda(), defer=True), hip_ops.PartialSums)
+    nblk = (ctx + 8 + bs - 1) // bs
+    kv = [torch.randn(2, B * nblk, bs, 2, D, device=dev).to(torch.bfloat16) for _ in cfg.attn_layers]
+    bt = torch.randperm(B * nblk, generator=g_).to(torch.int32).view(B, nblk).to(dev)
+    ids = torch.zeros(B, dtype=torch.int64, device=dev)
+    pos = torch.zeros(B, dtype=torch.int64, device=dev)
+    seq_lens = torch.zeros(B, dtype=torch.int32, device=dev)
+    slots = torch.zeros(B, dtype=torch.int64, device=dev)
+    md = _md(dev, decode_seq_lens=[ctx + 8] * B, block_tables=bt, slot_mapping=slots)
+    md.seq_lens_tensor, md.seq_lens, md.use_cuda_graph = seq_lens, None, True
+    cache, idx = model.get_seqlen_agnostic_capture_inputs(B)
+    idx.copy_(torch.arange(B, dtype=torch.int32, device=dev))
+
+    def set_inputs(step):
+        gi = gen(100 + step)
+        ids.copy_(torch.randint(0, cfg.vocab_size, (B,), generator=gi).to(dev))
+        p = torch.tensor([ctx + step - i for i in range(B)], dtype=torch.int64, device=dev)
+        pos.copy_(p)
+        seq_lens.copy_((p + 1).to(torch.int32))
+        slots.copy_(torch.gather(bt.long(), 1, (p // bs).unsqueeze(1)).squeeze(1) * bs + p % bs)
+
+    def run():
+        return model(ids, pos, attn_metadata=md, kv_caches=kv, seqlen_agnostic_capture_inputs=(cache, idx))
+
+    state0 = (torch.randn(cache[0].shape, device=dev) * 0.1).to(torch.bfloat16)
+    kv0 = [k.clone() for k in kv]
+
+    def reset():
+        cache[0].copy_(state0)
+        for k, k0 in zip(kv, kv0):
+            k.copy_(k0)
+
+    set_inputs(0)
+    reset()
+    run()
+    torch.cuda.synchronize()
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        run()
+        with torch.cuda.graph(graph, stream=side):
+            out = run()
+    torch.cuda.synchronize()
+    for step in (1, 2, 3):
+        set_inputs(step)
+        reset()
+        eager = run().clone()
+        state_e, kv_e = cache[0].clone(), [k.clone() for k in kv]
+        lin(randn_bf16(g_, B, 2048).cuda())          # eager work of the same ops between replays
+        reset()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager), f"replay {step}: hidden states"
+        assert torch.equal(cache[0], state_e) and all(torch.equal(a, b) for a, b in zip(kv, kv_e)), f"replay {step}: caches"
