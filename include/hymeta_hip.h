@@ -134,6 +134,16 @@ typedef struct hymeta_gla_decode_args {
    * to bf16 as the linear's output is.  NULL g_w1: g is the finished gate, as above. */
   const void* g_w1;
   const void* g_bias;
+  /* q, k, v (and the low-rank g) taken straight from the partial sums of the fused qkv projection that was cut into K
+   * slices (see hymeta_gemm_partials below: fp32 slabs [qkv_splits][batch][qkv_n], bias bf16 [qkv_n] or NULL): with
+   * qkv_slabs given the q / k / v / g pointers and strides are ignored, head h of q is columns q_col + h * head_dim ...,
+   * kv-head j of k / v columns k_col / v_col + j * head_dim ..., the 16 rank columns start at g_col (g_w1 required for
+   * the 7B gate); every value is the slices' sum in slice order plus bias, rounded to bf16 -- what the projection's
+   * reduce launch would have written. */
+  const void* qkv_slabs;
+  const void* qkv_bias;
+  int32_t qkv_splits, qkv_n;
+  int32_t q_col, k_col, v_col, g_col;
 } hymeta_gla_decode_args;
 
 int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stream_t stream);
@@ -696,6 +706,11 @@ int hymeta_add_rmsnorm_partials(const hymeta_add_rmsnorm_args* args, const hymet
  * int8 quantisation of its bf16 output -- xq int8 [num_tokens, hidden] contiguous, x_scale fp32 [num_tokens], the bits
  * hymeta_w8a8_quantize gives on that output -- for the W8A8 linear that consumes the norm (qkv_proj, gate_up_proj):
  * called with x == NULL and these two buffers, hymeta_w8a8_gemm / _silu_mul / _deferred skip their quantise launch. */
+/* hymeta_rope_neox with the fused qkv projection taken from its partial sums: writes the projection's whole bf16 row
+ * (args->q = the [num_tokens, N] output buffer, q heads first, then k heads, head_dim apart; args->k NULL or q + H * D;
+ * v and any further columns follow and are written unrotated) -- the linear's reduce launch and the RoPE launch
+ * (model_for_7B/modeling_gla_swa.py:196-197) in one.  num_kv_heads = the k heads to rotate. */
+int hymeta_rope_neox_partials(const hymeta_rope_args* args, const hymeta_gemm_partials* partials, hymeta_stream_t stream);
 int hymeta_add_rmsnorm_int8(const hymeta_add_rmsnorm_args* args, const hymeta_gemm_partials* partials, int8_t* xq,
                             float* x_scale, hymeta_stream_t stream);
 

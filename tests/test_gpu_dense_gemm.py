@@ -157,3 +157,32 @@ def test_k_slice_sum_left_to_the_fused_add_rmsnorm(kind, M, K, N, bias):
     lin(x)
     with pytest.raises(ValueError):
         hip_ops.add_rmsnorm(stale, w, 1e-6, residual=r2)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "w8a8"])
+def test_qkv_projection_finished_by_rope_from_its_partial_sums(kind):
+    """7B sliding-window layer: the K-sliced qkv projection's slice sum, bias and the rotation of q and k in one launch
+    equal the plain projection followed by the in-place RoPE, bit for bit."""
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta.linear import HymetaLinear
+    from vllm_hymeta.model_for_7B.window_attention import rope_cos_sin_cache
+
+    g_ = gen(31)
+    T, H, Hkv, D, hidden = 37, 28, 4, 128, 3584
+    N = (H + 2 * Hkv) * D
+    x = randn_bf16(g_, T, hidden).cuda()
+    b = randn_bf16(g_, N).cuda()
+    if kind == "bf16":
+        lin = HymetaLinear.from_weight(randn_bf16(g_, N, hidden, scale=hidden ** -0.5).cuda(), b)
+    else:
+        lin = HymetaLinear.from_w8a8(torch.randint(-127, 128, (N, hidden), generator=g_, dtype=torch.int8).cuda(),
+                                     (torch.rand(N, generator=g_) * 0.02 + 0.001).cuda(), b)
+    table = rope_cos_sin_cache(D, 4096, 1e6, device=x.device)
+    pos = torch.randint(0, 4096, (T,), generator=g_).cuda()
+    ref = lin(x)
+    hip_ops.rope_neox_(pos, ref[:, : H * D].view(T, H, D), ref[:, H * D:(H + Hkv) * D].view(T, Hkv, D), table)
+    part = lin(x, defer=True)
+    assert isinstance(part, hip_ops.PartialSums)
+    got = hip_ops.rope_from_partials(part, pos, table, H, Hkv)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)

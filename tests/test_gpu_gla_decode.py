@@ -181,3 +181,32 @@ def test_gla_decode_rejects_bad_arguments():
         hip_ops.gla_decode(q, q, q, q, st, slot)
     with pytest.raises(ValueError):
         hip_ops.gla_decode(q.float(), q, q, q, st, slot)
+
+
+def test_gla_decode_reads_the_projection_from_its_partial_sums():
+    """7B GLA layer, pure decode: q, k, v and the gate's rank-16 input taken from the K-slice sums of the fused qkv (+ gate)
+    projection give the outputs and states of the run on the finished projection, bit for bit."""
+    from vllm_hymeta import hip_ops, _C
+    from vllm_hymeta.linear import HymetaLinear
+
+    B, H, Hkv, hidden = 23, 28, 4, 3584
+    QKV = (H + 2 * Hkv) * D
+    g_ = gen(8)
+    x = randn_bf16(g_, B, hidden).cuda()
+    lin = HymetaLinear.from_weight(randn_bf16(g_, QKV + 64, hidden, scale=hidden ** -0.5).cuda(), randn_bf16(g_, QKV + 64, scale=0.1).cuda())
+    w1, b1 = randn_bf16(g_, Hkv * D, 16, scale=0.5).cuda(), randn_bf16(g_, Hkv * D, scale=0.1).cuda()
+    w = (1 + 0.1 * torch.randn(D, generator=g_)).to(torch.bfloat16).cuda()
+    state = randn_bf16(g_, B + 2, Hkv, D, D, scale=0.1).cuda()
+    slot = torch.randperm(B + 2, generator=g_)[:B].to(torch.int32).cuda()
+    kw = dict(gate_mode=_C.GATE_7B, out_norm_weight=w, out_norm_eps=1e-6, g_w1=w1, g_bias=b1)
+    qkv = lin(x)
+    q, k, v = qkv[:, : H * D].view(B, H, D), qkv[:, H * D:(H + Hkv) * D].view(B, Hkv, D), qkv[:, (H + Hkv) * D:QKV].view(B, Hkv, D)
+    s_a = state.clone()
+    out_a = hip_ops.gla_decode(q, k, v, qkv[:, QKV:QKV + 16], s_a, slot, **kw)
+    part = lin(x, defer=True)
+    assert isinstance(part, hip_ops.PartialSums)
+    s_b = state.clone()
+    out_b = hip_ops.gla_decode((B, H, D), (B, Hkv, D), None, None, s_b, slot, qkv_partials=part,
+                               qkv_cols=(0, H * D, (H + Hkv) * D, QKV), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b) and torch.equal(s_a, s_b)

@@ -10,29 +10,53 @@
 // (NSPLIT 2): fully coalesced either way.
 #include "common.h"
 #include "gla_gate.h"
+#include "partial_sums.h"
 
 namespace hymeta {
 
 // The gate given in its low-rank form (7B: gk = W1 (W0 x) + b with a rank of 16): ``g`` then holds the rank-16 row of the
 // token (bf16, the first linear's rounded output) and the second linear is applied here, one output feature per thread, in
 // the arithmetic of hymeta_lowrank_gate's second stage (fma chain in rank order, bias added, rounded to bf16).
-__device__ __forceinline__ float lowrank_gate_value(const hymeta_gla_decode_args& a, int b, int feature) {
-  const uint16_t* t = reinterpret_cast<const uint16_t*>(a.g) + b * a.g_stride_b;
+__device__ __forceinline__ hymeta_gemm_partials qkv_partials(const hymeta_gla_decode_args& a) {
+  hymeta_gemm_partials p = {};
+  p.slabs = a.qkv_slabs, p.splits = a.qkv_splits, p.bias = a.qkv_bias, p.M = a.batch, p.N = a.qkv_n;
+  return p;
+}
+
+__device__ __forceinline__ float lowrank_gate_from(const hymeta_gla_decode_args& a, const float* t, int feature) {
   const uint16_t* w1 = reinterpret_cast<const uint16_t*>(a.g_w1) + static_cast<int64_t>(feature) * 16;
-  const u32x4 ta = ld16(t), tb = ld16(t + 8), wa = ld16(w1), wb = ld16(w1 + 8);
+  const u32x4 wa = ld16(w1), wb = ld16(w1 + 8);
   float y = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    y = fmaf(lo_bf(ta[i]), lo_bf(wa[i]), y);
-    y = fmaf(hi_bf(ta[i]), hi_bf(wa[i]), y);
+    y = fmaf(t[2 * i], lo_bf(wa[i]), y);
+    y = fmaf(t[2 * i + 1], hi_bf(wa[i]), y);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    y = fmaf(lo_bf(tb[i]), lo_bf(wb[i]), y);
-    y = fmaf(hi_bf(tb[i]), hi_bf(wb[i]), y);
+    y = fmaf(t[8 + 2 * i], lo_bf(wb[i]), y);
+    y = fmaf(t[9 + 2 * i], hi_bf(wb[i]), y);
   }
   if (a.g_bias != nullptr) y += bf2f(reinterpret_cast<const uint16_t*>(a.g_bias)[feature]);
   return bf16_round(y);
+}
+
+__device__ __forceinline__ float lowrank_gate_value(const hymeta_gla_decode_args& a, int b, int feature) {
+  float t[16];
+  if (a.qkv_slabs != nullptr) {
+    const hymeta_gemm_partials p = qkv_partials(a);
+    float lo[8], hi[8];
+    partial_row8<false>(p, b, a.g_col, lo);
+    partial_row8<false>(p, b, a.g_col + 8, hi);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = lo[i], t[8 + i] = hi[i];
+  } else {
+    const uint16_t* tp = reinterpret_cast<const uint16_t*>(a.g) + b * a.g_stride_b;
+    const u32x4 ta = ld16(tp), tb = ld16(tp + 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[2 * i] = lo_bf(ta[i]), t[2 * i + 1] = hi_bf(ta[i]), t[8 + 2 * i] = lo_bf(tb[i]), t[9 + 2 * i] = hi_bf(tb[i]);
+  }
+  return lowrank_gate_from(a, t, feature);
 }
 
 template <typename StateT>
@@ -79,8 +103,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   const int kvh = h / (a.num_heads / a.num_kv_heads);
 
   if (tid < D) {
+    const bool from_slabs = a.qkv_slabs != nullptr;
+    const hymeta_gemm_partials qp_ = qkv_partials(a);
     const uint16_t* qp = reinterpret_cast<const uint16_t*>(a.q) + b * a.q_stride_b + h * a.q_stride_h;
     const uint16_t* kp = reinterpret_cast<const uint16_t*>(a.k) + b * a.k_stride_b + kvh * a.k_stride_h;
+    const float q_raw = from_slabs ? partial_elem(qp_, b, a.q_col + h * D + tid) : bf2f(qp[tid]);
+    const float k_raw1 = from_slabs ? partial_elem(qp_, b, a.k_col + kvh * D + tid) : bf2f(kp[tid]);
     float g_raw = 0.f;
     if (a.g_w1 != nullptr) {
       g_raw = lowrank_gate_value(a, b, kvh * D + tid);
@@ -91,7 +119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
     const float lb = a.lower_bound != nullptr ? a.lower_bound[h * D + tid] : 0.f;
     float qs, kb, g;
-    apply_gate(gp, bf2f(qp[tid]), bf2f(kp[tid]), g_raw, lb, qs, kb, g);
+    apply_gate(gp, q_raw, k_raw1, g_raw, lb, qs, kb, g);
     s_q[tid] = qs;
     s_k[tid] = kb;
     s_dec[tid] = __expf(g);
@@ -104,12 +132,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   // v for this lane's 8 columns
   float vf[8];
   {
-    const uint16_t* vp = reinterpret_cast<const uint16_t*>(a.v) + b * a.v_stride_b + kvh * a.v_stride_h + col0;
-    u32x4 raw = ld16(vp);
+    if (a.qkv_slabs != nullptr) {
+      partial_row8<false>(qkv_partials(a), b, a.v_col + kvh * D + col0, vf);
+    } else {
+      const uint16_t* vp = reinterpret_cast<const uint16_t*>(a.v) + b * a.v_stride_b + kvh * a.v_stride_h + col0;
+      u32x4 raw = ld16(vp);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      vf[2 * i] = lo_bf(raw[i]);
-      vf[2 * i + 1] = hi_bf(raw[i]);
+      for (int i = 0; i < 4; ++i) {
+        vf[2 * i] = lo_bf(raw[i]);
+        vf[2 * i + 1] = hi_bf(raw[i]);
+      }
     }
   }
 
@@ -236,6 +268,8 @@ __global__ __launch_bounds__(THREADS) void gla_decode_group_kernel(hymeta_gla_de
   __shared__ float s_k[D];
   __shared__ float s_dec[D];
   __shared__ float s_red[NW][REP][COLS];
+  __shared__ float s_in[REP + 2][D];     // inputs taken from the projection's partial sums: q heads, k, v
+  __shared__ float s_t[16];              // and the gate's rank-16 row
 
   const int tid = threadIdx.x;
   const int b = blockIdx.x / a.num_kv_heads;
@@ -245,53 +279,13 @@ __global__ __launch_bounds__(THREADS) void gla_decode_group_kernel(hymeta_gla_de
   if (slot < 0) return;  // padded sequence: state and output untouched
   const int h0 = kvh * REP;
 
-  if (tid < D) {
-    const uint16_t* kp = reinterpret_cast<const uint16_t*>(a.k) + b * a.k_stride_b + kvh * a.k_stride_h;
-    float g_raw = 0.f;
-    if (a.g_w1 != nullptr) {
-      g_raw = lowrank_gate_value(a, b, kvh * D + tid);
-    } else if (a.g != nullptr) {
-      const int64_t goff = b * a.g_stride_b + kvh * a.g_stride_h + tid;
-      g_raw = a.g_dtype == HYMETA_F32 ? reinterpret_cast<const float*>(a.g)[goff]
-                                      : bf2f(reinterpret_cast<const uint16_t*>(a.g)[goff]);
-    }
-    const float k_raw = bf2f(kp[tid]);
-#pragma unroll
-    for (int r = 0; r < REP; ++r) {
-      const uint16_t* qp = reinterpret_cast<const uint16_t*>(a.q) + b * a.q_stride_b + (h0 + r) * a.q_stride_h;
-      float qs, kb, g;
-      apply_gate(gp, bf2f(qp[tid]), k_raw, g_raw, 0.f, qs, kb, g);
-      s_q[r][tid] = qs;
-      if (r == 0) {
-        s_k[tid] = kb;
-        s_dec[tid] = __expf(g);
-      }
-    }
-  }
-
   const int cg = tid % CG;
   const int r0 = tid / CG;
   const int col0 = split * COLS + cg * 8;
 
-  float vf[8];
-  {
-    const uint16_t* vp = reinterpret_cast<const uint16_t*>(a.v) + b * a.v_stride_b + kvh * a.v_stride_h + col0;
-    u32x4 raw = ld16(vp);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      vf[2 * i] = lo_bf(raw[i]);
-      vf[2 * i + 1] = hi_bf(raw[i]);
-    }
-  }
-
   const int64_t sbase = static_cast<int64_t>(slot) * a.state_stride_slot + static_cast<int64_t>(kvh) * a.state_stride_h;
-  float acc[REP][8];
-#pragma unroll
-  for (int r = 0; r < REP; ++r)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) acc[r][c] = 0.f;
-
-  // every load of the lane's rows is in flight before the first is used
+  // the state rows first: every load of the lane's rows is in flight before anything else is fetched, so that the
+  // q / k / gate prologue below (loads, exponentials) runs under their latency instead of in front of it
   u32x4 raw[NPASS][STATE_F32 ? 2 : 1];
   char* sp = reinterpret_cast<char*>(a.state) + (sbase + col0) * (STATE_F32 ? 4 : 2);
 #pragma unroll
@@ -300,6 +294,76 @@ __global__ __launch_bounds__(THREADS) void gla_decode_group_kernel(hymeta_gla_de
     raw[i][0] = NT ? ld16nt(p) : ld16(p);
     if constexpr (STATE_F32) raw[i][1] = NT ? ld16nt(p + 16) : ld16(p + 16);
   }
+
+  const bool from_slabs = a.qkv_slabs != nullptr;
+  if (from_slabs) {
+    // the whole workgroup sums the slices of its (REP + 2) x 128 input values (+ the 16 rank columns) in 4-column pieces
+    const hymeta_gemm_partials qp_ = qkv_partials(a);
+    constexpr int kPer = D / 4;
+    for (int item = tid; item < (REP + 2) * kPer + 4; item += THREADS) {
+      const int row = item / kPer, c4 = item % kPer;
+      int col;
+      float* dst;
+      if (row < REP) col = a.q_col + (h0 + row) * D + 4 * c4, dst = &s_in[row][4 * c4];
+      else if (row == REP) col = a.k_col + kvh * D + 4 * c4, dst = &s_in[REP][4 * c4];
+      else if (row == REP + 1) col = a.v_col + kvh * D + 4 * c4, dst = &s_in[REP + 1][4 * c4];
+      else col = a.g_col + 4 * c4, dst = &s_t[4 * c4];
+      *reinterpret_cast<f32x4*>(dst) = partial_row4(qp_, b, col);
+    }
+    __syncthreads();
+  }
+
+  if (tid < D) {
+    const uint16_t* kp = reinterpret_cast<const uint16_t*>(a.k) + b * a.k_stride_b + kvh * a.k_stride_h;
+    float g_raw = 0.f;
+    if (a.g_w1 != nullptr) {
+      g_raw = from_slabs ? lowrank_gate_from(a, s_t, kvh * D + tid) : lowrank_gate_value(a, b, kvh * D + tid);
+    } else if (a.g != nullptr) {
+      const int64_t goff = b * a.g_stride_b + kvh * a.g_stride_h + tid;
+      g_raw = a.g_dtype == HYMETA_F32 ? reinterpret_cast<const float*>(a.g)[goff]
+                                      : bf2f(reinterpret_cast<const uint16_t*>(a.g)[goff]);
+    }
+    const float k_raw = from_slabs ? s_in[REP][tid] : bf2f(kp[tid]);
+    float q_raw[REP];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+      const uint16_t* qp = reinterpret_cast<const uint16_t*>(a.q) + b * a.q_stride_b + (h0 + r) * a.q_stride_h;
+      q_raw[r] = from_slabs ? s_in[r][tid] : bf2f(qp[tid]);
+    }
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+      float qs, kb, g;
+      apply_gate(gp, q_raw[r], k_raw, g_raw, 0.f, qs, kb, g);
+      s_q[r][tid] = qs;
+      if (r == 0) {
+        s_k[tid] = kb;
+        s_dec[tid] = __expf(g);
+      }
+    }
+  }
+
+  float vf[8];
+  {
+    if (from_slabs) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) vf[c] = s_in[REP + 1][col0 + c];
+    } else {
+      const uint16_t* vp = reinterpret_cast<const uint16_t*>(a.v) + b * a.v_stride_b + kvh * a.v_stride_h + col0;
+      u32x4 raw = ld16(vp);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vf[2 * i] = lo_bf(raw[i]);
+        vf[2 * i + 1] = hi_bf(raw[i]);
+      }
+    }
+  }
+
+  float acc[REP][8];
+#pragma unroll
+  for (int r = 0; r < REP; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[r][c] = 0.f;
+
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NPASS; ++i) {
@@ -446,21 +510,33 @@ extern "C" int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stre
   const hymeta_gla_decode_args& a = *args;
   if (a.batch < 0 || a.num_heads <= 0 || a.num_kv_heads <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.batch == 0) return HYMETA_OK;
-  if (!a.q || !a.k || !a.v || !a.out || !a.state || !a.slot_idx) return HYMETA_ERR_INVALID_ARG;
+  const bool from_slabs = a.qkv_slabs != nullptr;
+  if (from_slabs) {
+    if (a.qkv_splits < 1 || a.qkv_n <= 0 || a.qkv_n % 8 != 0 || (a.q_col | a.k_col | a.v_col | a.g_col) % 8 != 0) return HYMETA_ERR_INVALID_ARG;
+    if (a.q_col < 0 || a.q_col + a.num_heads * a.head_dim > a.qkv_n || a.k_col < 0 || a.k_col + a.num_kv_heads * a.head_dim > a.qkv_n ||
+        a.v_col < 0 || a.v_col + a.num_kv_heads * a.head_dim > a.qkv_n)
+      return HYMETA_ERR_INVALID_ARG;
+    if (a.g_w1 != nullptr && (a.g_col < 0 || a.g_col + 16 > a.qkv_n)) return HYMETA_ERR_INVALID_ARG;
+    if ((a.gate_mode == HYMETA_GATE_NONE || a.gate_mode == HYMETA_GATE_7B) && !a.g_w1) return HYMETA_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(a.qkv_slabs) | reinterpret_cast<uintptr_t>(a.qkv_bias)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+    if (!a.out || !a.state || !a.slot_idx) return HYMETA_ERR_INVALID_ARG;
+  } else if (!a.q || !a.k || !a.v || !a.out || !a.state || !a.slot_idx) {
+    return HYMETA_ERR_INVALID_ARG;
+  }
   if (a.head_dim != kHeadDim) return HYMETA_ERR_UNSUPPORTED;
   if (a.num_heads % a.num_kv_heads != 0) return HYMETA_ERR_INVALID_ARG;
   if (a.g_dtype != HYMETA_BF16 && a.g_dtype != HYMETA_F32) return HYMETA_ERR_UNSUPPORTED;
   if (a.state_dtype != HYMETA_BF16 && a.state_dtype != HYMETA_F32) return HYMETA_ERR_UNSUPPORTED;
   if (a.gate_mode < HYMETA_GATE_NONE || a.gate_mode > HYMETA_GATE_70B_LOWER_BOUND) return HYMETA_ERR_UNSUPPORTED;
-  if ((a.gate_mode == HYMETA_GATE_NONE || a.gate_mode == HYMETA_GATE_7B) && !a.g) return HYMETA_ERR_INVALID_ARG;
+  if (!from_slabs && (a.gate_mode == HYMETA_GATE_NONE || a.gate_mode == HYMETA_GATE_7B) && !a.g) return HYMETA_ERR_INVALID_ARG;
   if (a.gate_mode == HYMETA_GATE_70B_LOWER_BOUND && !a.lower_bound) return HYMETA_ERR_INVALID_ARG;
-  if (a.g_w1 != nullptr) {      // low-rank gate: g = bf16 [batch, 16] rows, 16-byte loads
+  if (a.g_w1 != nullptr && !from_slabs) {      // low-rank gate: g = bf16 [batch, 16] rows, 16-byte loads
     if (!a.g || a.g_dtype != HYMETA_BF16 || a.g_stride_b % 8 != 0) return HYMETA_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(a.g) | reinterpret_cast<uintptr_t>(a.g_w1)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
   }
   // 16-byte vector access on v, out and state rows
-  if ((a.v_stride_b | a.v_stride_h | a.state_stride_slot | a.state_stride_h) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(a.v) | reinterpret_cast<uintptr_t>(a.state)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if (((from_slabs ? 0 : (a.v_stride_b | a.v_stride_h)) | a.state_stride_slot | a.state_stride_h) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if (((from_slabs ? 0 : reinterpret_cast<uintptr_t>(a.v)) | reinterpret_cast<uintptr_t>(a.state)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
 
   GateParams gp;
   gp.mode = a.gate_mode;

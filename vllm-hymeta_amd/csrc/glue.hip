@@ -1,6 +1,7 @@
 // Element-wise glue of the attention layers: NeoX rotary embedding, the 70B
 // two-branch RMS-norm combine and the blocks' RMS norm with the residual add.  HBM-bound; 16-byte accesses throughout.
 #include "common.h"
+#include "partial_sums.h"
 #include "w8a8_quant.h"
 
 namespace hymeta {
@@ -41,6 +42,55 @@ __global__ __launch_bounds__(256) void rope_neox_kernel(hymeta_rope_args a) {
     }
     st16(x + 8 * ch, xo);
     st16(x + half + 8 * ch, yo);
+  }
+}
+
+// The fused qkv projection finished from its K slices' partial sums, RoPE included: row t of out [T, N] = the linear's
+// result (columns [0, (H + Hkv) D) are the q and k heads and get the rotation, the rest -- v, and whatever rides behind
+// it -- is written as it is).  Same arithmetic as the linear's reduce launch followed by rope_neox_kernel.
+template <bool I8>
+__global__ __launch_bounds__(256) void rope_partials_kernel(hymeta_rope_args a, hymeta_gemm_partials p) {
+  const int64_t t = blockIdx.x;
+  const int half = a.rot_dim / 2;
+  const int chunks = half / 8;
+  int64_t pos = a.positions[t] + a.position_offset;
+  pos = pos < 0 ? 0 : (pos >= a.max_position ? a.max_position - 1 : pos);
+  const uint16_t* cs = reinterpret_cast<const uint16_t*>(a.cos_sin_cache) + pos * a.rot_dim;
+  uint16_t* out = reinterpret_cast<uint16_t*>(a.q) + t * a.q_stride_t;
+  const int rope_heads = a.num_heads + a.num_kv_heads;
+  for (int w = threadIdx.x; w < rope_heads * chunks; w += blockDim.x) {
+    const int head = w / chunks, ch = w % chunks;
+    const int col = head * a.head_dim + 8 * ch;
+    float x[8], y[8];
+    partial_row8<I8>(p, t, col, x);
+    partial_row8<I8>(p, t, col + half, y);
+    const u32x4 cv = ld16(cs + 8 * ch), sv = ld16(cs + half + 8 * ch);
+    u32x4 xo, yo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float r[2][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float xf = x[2 * i + e], yf = y[2 * i + e];
+        const float c = e ? hi_bf(cv[i]) : lo_bf(cv[i]);
+        const float s = e ? hi_bf(sv[i]) : lo_bf(sv[i]);
+        r[0][e] = bf16_round(xf * c) - bf16_round(yf * s);
+        r[1][e] = bf16_round(yf * c) + bf16_round(xf * s);
+      }
+      xo[i] = pack_bf16x2(r[0][0], r[0][1]);
+      yo[i] = pack_bf16x2(r[1][0], r[1][1]);
+    }
+    st16(out + col, xo);
+    st16(out + col + half, yo);
+  }
+  const int first = rope_heads * a.head_dim;
+  for (int c = first / 8 + threadIdx.x; c < p.N / 8; c += blockDim.x) {
+    float x[8];
+    partial_row8<I8>(p, t, 8 * c, x);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(x[2 * i], x[2 * i + 1]);
+    st16(out + 8 * c, o);
   }
 }
 
@@ -166,68 +216,17 @@ __global__ __launch_bounds__(256) void add_rmsnorm_partials_kernel(hymeta_add_rm
   const int64_t t = blockIdx.x;
   uint16_t* res = reinterpret_cast<uint16_t*>(a.residual) + t * a.residual_stride_t;
   const uint16_t* w = reinterpret_cast<const uint16_t*>(a.weight);
-  const uint16_t* bias = static_cast<const uint16_t*>(p.bias);
   uint16_t* out = reinterpret_cast<uint16_t*>(a.out) + t * a.out_stride_t;
   const int chunks = a.hidden / 8;
-  const int64_t slab = static_cast<int64_t>(p.M) * p.N;
-  const float xs = I8 ? p.x_scale[t] : 0.f;
   float ss = 0.f;
   for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
     float x[8];
-    if constexpr (I8) {
-      const int32_t* src = static_cast<const int32_t*>(p.slabs) + t * p.N + 8 * c;
-      int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      // four slices' loads in flight at a time (a loop of dependent load-add pairs would wait out one cache latency
-      // per slice); the adds stay in slice order
-      for (int sp = 0; sp < p.splits; sp += 4) {
-        u32x4 lo[4], hi[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t off = static_cast<int64_t>(min(sp + i, p.splits - 1)) * slab;
-          lo[i] = ld16(src + off), hi[i] = ld16(src + off + 4);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (sp + i < p.splits) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += static_cast<int>(lo[i][e]), acc[4 + e] += static_cast<int>(hi[i][e]);
-          }
-      }
-      float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (bias != nullptr) {
-        const u32x4 bw = ld16(bias + 8 * c);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) b[2 * i] = lo_bf(bw[i]), b[2 * i + 1] = hi_bf(bw[i]);
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = w8a8_scaled(acc[e], xs, p.w_scale[8 * c + e], b[e]);
-    } else {
-      const float* src = static_cast<const float*>(p.slabs) + t * p.N + 8 * c;
-      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      for (int sp = 0; sp < p.splits; sp += 4) {
-        f32x4 l4[4], h4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t off = static_cast<int64_t>(min(sp + i, p.splits - 1)) * slab;
-          l4[i] = *reinterpret_cast<const f32x4*>(src + off), h4[i] = *reinterpret_cast<const f32x4*>(src + off + 4);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (sp + i < p.splits) lo += l4[i], hi += h4[i];
-      }
-      if (bias != nullptr) {
-        const u32x4 bw = ld16(bias + 8 * c);
-        lo += f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
-        hi += f32x4{lo_bf(bw[2]), hi_bf(bw[2]), lo_bf(bw[3]), hi_bf(bw[3])};
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] = lo[e], x[4 + e] = hi[e];
-    }
+    partial_row8<I8>(p, t, 8 * c, x);
     const u32x4 r = ld16(res + 8 * c);
     u32x4 z;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      z[i] = pack_bf16x2(bf16_round(x[2 * i]) + lo_bf(r[i]), bf16_round(x[2 * i + 1]) + hi_bf(r[i]));
+      z[i] = pack_bf16x2(x[2 * i] + lo_bf(r[i]), x[2 * i + 1] + hi_bf(r[i]));
     st16(res + 8 * c, z);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -293,6 +292,31 @@ extern "C" int hymeta_rope_neox(const hymeta_rope_args* args, hymeta_stream_t st
   if ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k) |
        reinterpret_cast<uintptr_t>(a.cos_sin_cache)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(rope_neox_kernel, dim3(a.num_tokens), dim3(256), 0, begin_launches(stream), a);
+  return launch_status();
+}
+
+extern "C" int hymeta_rope_neox_partials(const hymeta_rope_args* args, const hymeta_gemm_partials* partials,
+                                         hymeta_stream_t stream) {
+  if (args == nullptr || partials == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_rope_args& a = *args;
+  const hymeta_gemm_partials& p = *partials;
+  if (a.num_tokens < 0 || a.num_heads <= 0 || a.num_kv_heads < 0 || p.splits < 1 || !p.slabs) return HYMETA_ERR_INVALID_ARG;
+  if (a.num_tokens != p.M) return HYMETA_ERR_INVALID_ARG;
+  if (a.num_tokens == 0) return HYMETA_OK;
+  if (!a.q || !a.positions || !a.cos_sin_cache) return HYMETA_ERR_INVALID_ARG;
+  if (p.is_int32 && (!p.x_scale || !p.w_scale)) return HYMETA_ERR_INVALID_ARG;
+  if (a.rot_dim != a.head_dim || a.rot_dim % 16 != 0 || p.N % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  // the output is the projection's own [T, N] buffer: q heads, then k heads, head_dim apart, the row N or more wide
+  if (a.q_stride_h != a.head_dim || (a.num_heads + a.num_kv_heads) * a.head_dim > p.N || a.q_stride_t < p.N || a.q_stride_t % 8 != 0)
+    return HYMETA_ERR_INVALID_ARG;
+  if (a.k != nullptr && (a.k != static_cast<char*>(a.q) + static_cast<int64_t>(a.num_heads) * a.head_dim * 2 ||
+                         a.k_stride_t != a.q_stride_t || a.k_stride_h != a.head_dim))
+    return HYMETA_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.cos_sin_cache) | reinterpret_cast<uintptr_t>(p.slabs) |
+       reinterpret_cast<uintptr_t>(p.bias)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  hipStream_t s = begin_launches(stream);
+  if (p.is_int32) hipLaunchKernelGGL(rope_partials_kernel<true>, dim3(a.num_tokens), dim3(256), 0, s, a, p);
+  else hipLaunchKernelGGL(rope_partials_kernel<false>, dim3(a.num_tokens), dim3(256), 0, s, a, p);
   return launch_status();
 }
 

@@ -45,6 +45,8 @@ class GlaDecodeArgs(C.Structure):
         ("g_dtype", _i32), ("state_dtype", _i32), ("gate_mode", _i32),
         ("scale", _f32), ("gate_normalizer", _f32), ("gate_clamp", _f32), ("out_norm_eps", _f32),
         ("state_heads", _i32), ("g_w1", _ptr), ("g_bias", _ptr),
+        ("qkv_slabs", _ptr), ("qkv_bias", _ptr), ("qkv_splits", _i32), ("qkv_n", _i32),
+        ("q_col", _i32), ("k_col", _i32), ("v_col", _i32), ("g_col", _i32),
     ]
 
 
@@ -256,6 +258,7 @@ _SIGNATURES = {
     "hymeta_gptq_gemm_deferred": (C.c_int, [C.POINTER(GptqGemmArgs), C.POINTER(GemmPartials), _ptr]),
     "hymeta_gemm_partials_reduce": (C.c_int, [C.POINTER(GemmPartials), _ptr, _i64, _ptr]),
     "hymeta_add_rmsnorm_partials": (C.c_int, [C.POINTER(AddRmsNormArgs), C.POINTER(GemmPartials), _ptr]),
+    "hymeta_rope_neox_partials": (C.c_int, [C.POINTER(RopeArgs), C.POINTER(GemmPartials), _ptr]),
     "hymeta_add_rmsnorm_int8": (C.c_int, [C.POINTER(AddRmsNormArgs), C.POINTER(GemmPartials), _ptr, _ptr, _ptr]),
     "hymeta_bf16_gemm_split_k": (C.c_int, [_i32, _i32, _i32]),
     "hymeta_bf16_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -65,6 +65,8 @@ def gla_decode(
     out_norm_eps: float = 1e-6,
     g_w1: Optional[torch.Tensor] = None,
     g_bias: Optional[torch.Tensor] = None,
+    qkv_partials: Optional["PartialSums"] = None,
+    qkv_cols: Optional[tuple] = None,
 ) -> torch.Tensor:
     """q [B,H,D]; k, v, g [B,Hkv,D]; state [slots,H,D,D] (one state per query head, the reference's
     layout) or [slots,Hkv,D,D] (one per key/value head; any gate but the 70B lower-bound one), updated
@@ -73,8 +75,15 @@ def gla_decode(
     Low-rank gate (7B): with ``g_w1`` bf16 [Hkv*D, 16] (and ``g_bias`` bf16 [Hkv*D]) ``g`` is the rank-16 input
     bf16 [B, 16] and the kernel applies the second linear of the gate projection itself.
 
+    ``qkv_partials`` (fp32 ``PartialSums`` of the fused qkv projection) with ``qkv_cols = (q_col, k_col, v_col, g_col)``:
+    q, k, v and the rank-16 gate input are read from the partial sums (the projection's reduce launch is skipped); then
+    ``q`` / ``k`` / ``v`` / ``g`` are given as shapes only: ``(B, H, D)``, ``(B, Hkv, D)``, ``(B, Hkv, D)``, None.
+
     Returns out [B,H,D] bf16 (rows of skipped sequences, slot -1, are left as they were).
     """
+    if qkv_partials is not None:
+        return _gla_decode_from_partials(q, k, qkv_partials, qkv_cols, state, slot_idx, scale, out, gate_mode, gate_normalizer,
+                                         gate_clamp, out_norm_weight, out_norm_eps, g_w1, g_bias)
     _dev(q, k, v, g, state, slot_idx, lower_bound, out_norm_weight)
     B, H, D = q.shape
     Hkv = k.shape[1]
@@ -131,6 +140,44 @@ def gla_decode(
     a.scale = float(scale) if scale is not None else 0.0
     a.gate_normalizer, a.gate_clamp, a.out_norm_eps = gate_normalizer, gate_clamp, out_norm_eps
     _C.check(_C.load().hymeta_gla_decode(C.byref(a), _stream(q)), "hymeta_gla_decode")
+    return out
+
+
+def _gla_decode_from_partials(q_shape, k_shape, partials, cols, state, slot_idx, scale, out, gate_mode, gate_normalizer,
+                              gate_clamp, out_norm_weight, out_norm_eps, g_w1, g_bias) -> torch.Tensor:
+    partials.check_live()
+    B, H, D = q_shape
+    Hkv = k_shape[1]
+    _dev(state, slot_idx, out_norm_weight, g_w1, g_bias, out)
+    _require(partials.shape[0] == B and not partials.desc.is_int32, "partial sums must be fp32 slabs of B rows")
+    _require(gate_mode == _C.GATE_7B and g_w1 is not None, "partial-sum inputs are wired for the 7B low-rank gate")
+    _require(g_w1.dtype == torch.bfloat16 and g_w1.is_contiguous() and g_w1.shape == (Hkv * D, 16), "g_w1 must be contiguous bf16 [Hkv*D, 16]")
+    _require(g_bias is None or (g_bias.dtype == torch.bfloat16 and g_bias.is_contiguous() and g_bias.numel() == Hkv * D),
+             "g_bias must be contiguous bf16 [Hkv*D]")
+    _require(state.dim() == 4 and state.shape[2:] == (D, D) and state.shape[1] in (H, Hkv) and state.stride(3) == 1
+             and state.stride(2) == D and state.dtype in _DT, "state must be [slots, H | Hkv, D, D] with contiguous blocks")
+    _require(slot_idx.dtype == torch.int32 and slot_idx.shape == (B,) and slot_idx.is_contiguous(), "slot_idx must be contiguous int32 [B]")
+    if out is None:
+        out = torch.empty(B, H, D, dtype=torch.bfloat16, device=partials.device)
+    _require(out.shape == (B, H, D) and out.dtype == torch.bfloat16 and out.stride(-1) == 1, "out must be bf16 [B, H, D]")
+    if out_norm_weight is not None:
+        _require(out_norm_weight.dtype == torch.bfloat16 and out_norm_weight.is_contiguous() and out_norm_weight.numel() == D,
+                 "out_norm_weight must be contiguous bf16 [D]")
+    a = _C.GlaDecodeArgs()
+    a.out, a.state, a.slot_idx, a.out_norm_weight = _p(out), _p(state), _p(slot_idx), _p(out_norm_weight)
+    a.batch, a.num_heads, a.num_kv_heads, a.head_dim = B, H, Hkv, D
+    a.out_stride_b, a.out_stride_h = out.stride(0), out.stride(1)
+    a.state_stride_slot, a.state_stride_h = state.stride(0), state.stride(1)
+    a.state_dtype, a.g_dtype = _DT[state.dtype], _C.HYMETA_BF16
+    a.state_heads = state.shape[1]
+    a.gate_mode = gate_mode
+    a.scale = float(scale) if scale is not None else 0.0
+    a.gate_normalizer, a.gate_clamp, a.out_norm_eps = gate_normalizer, gate_clamp, out_norm_eps
+    a.g_w1, a.g_bias = _p(g_w1), _p(g_bias)
+    d = partials.desc
+    a.qkv_slabs, a.qkv_bias, a.qkv_splits, a.qkv_n = d.slabs, d.bias, d.splits, d.N
+    a.q_col, a.k_col, a.v_col, a.g_col = (int(c) for c in cols)
+    _C.check(_C.load().hymeta_gla_decode(C.byref(a), _stream(out)), "hymeta_gla_decode")
     return out
 
 
@@ -599,6 +646,30 @@ def rope_neox_(positions: torch.Tensor, q: torch.Tensor, k: Optional[torch.Tenso
         a.k, a.num_kv_heads = _p(k), k.shape[1]
         a.k_stride_t, a.k_stride_h = k.stride(0), k.stride(1)
     _C.check(_C.load().hymeta_rope_neox(C.byref(a), _stream(q)), "hymeta_rope_neox")
+
+
+def rope_from_partials(partials: "PartialSums", positions: torch.Tensor, cos_sin_cache: torch.Tensor, num_heads: int,
+                       num_kv_heads: int, position_offset: int = 0) -> torch.Tensor:
+    """The fused qkv projection finished from its K slices' partial sums with NeoX RoPE on the q and k heads: returns
+    the projection's bf16 ``[T, N]`` output (q heads, k heads, then v and whatever rides behind), the bits of the plain
+    linear followed by ``rope_neox_`` in one launch instead of two."""
+    partials.check_live()
+    T, N = partials.shape
+    D = cos_sin_cache.shape[1]
+    _dev(positions, cos_sin_cache)
+    _require(positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == T,
+             "positions must be contiguous int64 [T]")
+    _require(cos_sin_cache.dtype == torch.bfloat16 and cos_sin_cache.is_contiguous(), "cos_sin_cache must be contiguous bf16 [max_pos, D]")
+    _require((num_heads + 2 * num_kv_heads) * D <= N, "the projection is narrower than its q, k and v heads")
+    out = torch.empty(T, N, dtype=torch.bfloat16, device=partials.device)
+    a = _C.RopeArgs()
+    a.q, a.positions, a.cos_sin_cache = _p(out), _p(positions), _p(cos_sin_cache)
+    a.num_tokens, a.num_heads, a.num_kv_heads, a.head_dim, a.rot_dim = T, num_heads, num_kv_heads, D, D
+    a.max_position = cos_sin_cache.shape[0]
+    a.position_offset = int(position_offset)
+    a.q_stride_t, a.q_stride_h = N, D
+    _C.check(_C.load().hymeta_rope_neox_partials(C.byref(a), C.byref(partials.desc), _stream(out)), "hymeta_rope_neox_partials")
+    return out
 
 
 def _combine_args(o_attn, o_lin, weight1, weight2, stats, out, eps):

@@ -60,9 +60,20 @@ class GatedLinearAttention(torch.nn.Module):
         H, Hkv, D = self.shard.num_heads, self.shard.num_kv_heads, self.head_dim
         T = hidden_states.shape[0]
         p0, p1 = self.gk_proj0, self.gk_proj1
-        qkv = self.qkv_proj(hidden_states)
         n_pre = getattr(attn_metadata, "num_prefills", 0)
         t_pre = getattr(attn_metadata, "num_prefill_tokens", 0)
+        gate = dict(gate_mode=_C.GATE_7B, gate_normalizer=self.gate_logit_normalizer,
+                    out_norm_weight=self.g_norm_weight, out_norm_eps=self.norm_eps)
+        # a pure decode step with the gate in the projection: the recurrence kernel reads q, k, v and the gate's rank-16
+        # input straight from the projection's K-slice sums (no reduce launch for the projection)
+        qkv = self.qkv_proj(hidden_states, defer=self.gate_in_qkv and n_pre == 0)
+        if isinstance(qkv, hip_ops.PartialSums):
+            QKV = self.qkv_features
+            out = hip_ops.gla_decode((T, H, D), (T, Hkv, D), None, None, gla_cache, state_indices_tensor, g_w1=p1.weight, g_bias=p1.bias,
+                                     qkv_partials=qkv, qkv_cols=(0, H * D, (H + Hkv) * D, QKV), **gate)
+            reduce = parallel._active(self.tp_group)
+            y = self.o_proj(out.view(T, H * D), defer=defer_out and not reduce)
+            return all_reduce_sum(y, self.tp_group) if reduce else y
         gk = rank16 = None
         if self.gate_in_qkv:
             rank16 = qkv[:, self.qkv_features:self.qkv_features + 16]       # the gate's first linear, bf16 [T, 16]
@@ -77,8 +88,6 @@ class GatedLinearAttention(torch.nn.Module):
         k = qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
         v = qkv[:, (H + Hkv) * D:(H + 2 * Hkv) * D].view(T, Hkv, D)
         out = torch.empty(T, H, D, dtype=hidden_states.dtype, device=hidden_states.device)
-        gate = dict(gate_mode=_C.GATE_7B, gate_normalizer=self.gate_logit_normalizer,
-                    out_norm_weight=self.g_norm_weight, out_norm_eps=self.norm_eps)
         if n_pre > 0:
             hip_ops.gla_prefill_varlen(
                 q[:t_pre], k[:t_pre], v[:t_pre], gk[:t_pre], gla_cache, state_indices_tensor[:n_pre],

@@ -61,11 +61,13 @@ class SlidingWindowAttention(torch.nn.Module):
         [2, nblk, bs, Hkv_local, D]`` / ``attn_metadata`` given explicitly are bound / set for the call."""
         H, Hkv, D = self.shard.num_heads, self.shard.num_kv_heads, self.head_dim
         T = hidden_states.shape[0]
-        qkv = self.qkv_proj(hidden_states)
-        q = qkv[:, : H * D]
-        k = qkv[:, H * D:(H + Hkv) * D]
-        v = qkv[:, (H + Hkv) * D:]
-        hip_ops.rope_neox_(positions, q.view(T, H, D), k.view(T, Hkv, D), self.cos_sin_cache)
+        qkv = self.qkv_proj(hidden_states, defer=True)
+        if isinstance(qkv, hip_ops.PartialSums):      # K-sliced projection: its slice sum and the rotation in one launch
+            qkv = hip_ops.rope_from_partials(qkv, positions, self.cos_sin_cache, H, Hkv)
+            q, k, v = qkv[:, : H * D], qkv[:, H * D:(H + Hkv) * D], qkv[:, (H + Hkv) * D:]
+        else:
+            q, k, v = qkv[:, : H * D], qkv[:, H * D:(H + Hkv) * D], qkv[:, (H + Hkv) * D:]
+            hip_ops.rope_neox_(positions, q.view(T, H, D), k.view(T, Hkv, D), self.cos_sin_cache)
         if kv_cache is not None:
             bind_kv_cache(self.attn, kv_cache)
         if attn_metadata is not None and current_attn_metadata() is not attn_metadata:
