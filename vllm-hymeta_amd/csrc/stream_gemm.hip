@@ -133,55 +133,69 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& a, char* smem, con
     for (int r = 0; r < R; ++r) issue(r, r);
     __builtin_amdgcn_sched_barrier(0);
 
-    u32x4 xs[kStage];
-    auto stage_load = [&](int c) {
+    // Deep rings (R > 4) run kUnroll chunks per trip of the loop so that ring slots stay compile-time registers, and
+    // hold two chunks of x in registers ahead of the shared image (kAhead), so that neither the weights nor x are
+    // waited for a whole memory latency per chunk when a slice has only a few chunks.
+    constexpr int kUnroll = R > 4 ? R / 4 : 1;
+    constexpr int kAhead = R > 4 ? 2 : 1;
+    u32x4 xs[kAhead][kStage];
+    auto stage_load = [&](int slot, int c) {
       const int off = min(c, c_hi - 1) * kChunkBytes;
       const bool inside = off + piece_off < a.k_bytes;
 #pragma unroll
-      for (int j = 0; j < kStage; ++j) xs[j] = inside ? ld16g(xsrc[j] + off) : u32x4{0, 0, 0, 0};
+      for (int j = 0; j < kStage; ++j) xs[slot][j] = inside ? ld16g(xsrc[j] + off) : u32x4{0, 0, 0, 0};
     };
-    auto stage_store = [&](char* buf) {
+    auto stage_store = [&](int slot, char* buf) {
 #pragma unroll
-      for (int j = 0; j < kStage; ++j) *reinterpret_cast<u32x4*>(buf + xdst[j]) = xs[j];
+      for (int j = 0; j < kStage; ++j) *reinterpret_cast<u32x4*>(buf + xdst[j]) = xs[slot][j];
     };
-    stage_load(c_lo);
-    stage_store(smem);
+    stage_load(0, c_lo);
+    if constexpr (kAhead == 2) stage_load(1, c_lo + 1);
+    stage_store(0, smem);
     __syncthreads();
 
-    for (int c = c_lo; c < c_hi; ++c) {
-      const char* cur = smem + ((c - c_lo) & 1) * kBufBytes;
-      stage_load(c + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const int pair0 = (c - c_lo) * (kChunkSteps / 2);
+    // at the top of chunk i (counted from c_lo): the shared image i & 1 holds chunk i, the registers chunks i + 1 ..
+    // i + kAhead - 1; chunk i + kAhead is asked for, and chunk i + 1 goes to the other image at the bottom
+    for (int c0 = c_lo; c0 < c_hi; c0 += kUnroll) {
 #pragma unroll
-      for (int p = 0; p < kChunkSteps / 2; ++p) {
-        const int slot = p % R;
-        char* region = wimg + (p & 1) * (NF * 2048);
+      for (int cc = 0; cc < kUnroll; ++cc) {
+        const int c = c0 + cc;
+        if (c < c_hi) {
+          const char* cur = smem + ((c - c_lo) & 1) * kBufBytes;
+          stage_load(kAhead == 2 ? (cc & 1) : 0, c + kAhead);
+          __builtin_amdgcn_sched_barrier(0);
+          const int pair0 = (c - c_lo) * (kChunkSteps / 2);
 #pragma unroll
-        for (int q = 0; q < 2 * NF; ++q) *reinterpret_cast<u32x4*>(region + q * 1024 + lane * 16) = ring[slot][q];
-        // the scheduler must not sink the refill towards its use a whole ring later (it would, to save registers,
-        // and every pair would then wait out a full memory latency)
-        __builtin_amdgcn_sched_barrier(0);
-        issue(slot, pair0 + p + R);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int p = 0; p < kChunkSteps / 2; ++p) {
+            const int slot = (cc * (kChunkSteps / 2) + p) % R;
+            char* region = wimg + (p & 1) * (NF * 2048);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          u32x4 af[MT], bfr[NF];
-          const int piece = 4 * (2 * p + h) + cq;
-          const int poff = ((piece & 16) | ((piece ^ n) & 15)) * 16;
+            for (int q = 0; q < 2 * NF; ++q) *reinterpret_cast<u32x4*>(region + q * 1024 + lane * 16) = ring[slot][q];
+            // the scheduler must not sink the refill towards its use a whole ring later (it would, to save registers,
+            // and every pair would then wait out a full memory latency)
+            __builtin_amdgcn_sched_barrier(0);
+            issue(slot, pair0 + p + R);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(cur + aoff[mt] + poff);
-          const int woff = n * 128 + (((4 * h + cq) ^ ((n >> 1) & 7)) * 16);
+            for (int h = 0; h < 2; ++h) {
+              u32x4 af[MT], bfr[NF];
+              const int piece = 4 * (2 * p + h) + cq;
+              const int poff = ((piece & 16) | ((piece ^ n) & 15)) * 16;
 #pragma unroll
-          for (int i = 0; i < NF; ++i) bfr[i] = *reinterpret_cast<const u32x4*>(region + i * 2048 + woff);
+              for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(cur + aoff[mt] + poff);
+              const int woff = n * 128 + (((4 * h + cq) ^ ((n >> 1) & 7)) * 16);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
+              for (int i = 0; i < NF; ++i) bfr[i] = *reinterpret_cast<const u32x4*>(region + i * 2048 + woff);
 #pragma unroll
-            for (int i = 0; i < NF; ++i) acc[mt][i] = mma<I8>(af[mt], bfr[i], acc[mt][i]);
+              for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < NF; ++i) acc[mt][i] = mma<I8>(af[mt], bfr[i], acc[mt][i]);
+            }
+          }
+          stage_store(kAhead == 2 ? ((cc + 1) & 1) : 0, smem + (((c - c_lo) & 1) ^ 1) * kBufBytes);
+          __syncthreads();
         }
       }
-      stage_store(smem + (((c - c_lo) & 1) ^ 1) * kBufBytes);
-      __syncthreads();
     }
 
     // ---- epilogue: the tile as a row-major 4-byte image in LDS
@@ -342,7 +356,7 @@ int launch_stream(const StreamArgs& a, hipStream_t s, bool defer_reduce) {
 }  // namespace
 
 // Tuning overrides, read once: HYMETA_STREAM_NF (uniform tile width, 1..4), HYMETA_STREAM_WGS (workgroups to aim for),
-// HYMETA_STREAM_SPLITS (K slices), HYMETA_STREAM_RING (2 or 4).
+// HYMETA_STREAM_SPLITS (K slices), HYMETA_STREAM_RING (2, 4, 8 or 16).
 static int tune(const char* name) {
   const char* e = getenv(name);
   return e == nullptr ? 0 : atoi(e);
@@ -383,7 +397,8 @@ bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan
   if (splits < 1) splits = 1;
   p->nf = nf, p->tiles = tiles, p->chunks = chunks, p->splits = splits;
   // bytes in flight per wave = ring x fragments x 2 KB: one-fragment tiles need the deeper ring to cover the memory latency
-  p->ring = ring_forced == 4 || ring_forced == 2 ? ring_forced : (p->nf == 1 ? 4 : 2);
+  p->ring = ring_forced == 2 || ring_forced == 4 || ring_forced == 8 || ring_forced == 16 ? ring_forced : (p->nf == 1 ? 4 : 2);
+  if (p->nf > 2 && p->ring > 4) p->ring = 4;            // deep rings are built for the narrow tiles only
   return p->nf <= 4 && tiles <= groups;      // every wave of every tile owns at least one fragment
 }
 
@@ -406,7 +421,13 @@ int stream_gemm_launch(StreamArgs a, const StreamPlan& p, hipStream_t s, bool de
   if (a.gated && (p.splits != 1 || a.bias != nullptr || a.N % 128 != 0)) return HYMETA_ERR_INVALID_ARG;
   const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
 #define HYMETA_STREAM_CASE(MT_, NF_) \
-  if (mt == MT_ && p.nf == NF_) return p.ring == 4 ? launch_stream<MT_, NF_, I8, 4>(a, s, defer_reduce) : launch_stream<MT_, NF_, I8, 2>(a, s, defer_reduce);
+  if (mt == MT_ && p.nf == NF_) {                                                                   \
+    if constexpr (NF_ <= 2) {                                                                       \
+      if (p.ring == 16) return launch_stream<MT_, NF_, I8, 16>(a, s, defer_reduce);                 \
+      if (p.ring == 8) return launch_stream<MT_, NF_, I8, 8>(a, s, defer_reduce);                   \
+    }                                                                                               \
+    return p.ring == 4 ? launch_stream<MT_, NF_, I8, 4>(a, s, defer_reduce) : launch_stream<MT_, NF_, I8, 2>(a, s, defer_reduce); \
+  }
   HYMETA_STREAM_CASE(1, 1) HYMETA_STREAM_CASE(1, 2) HYMETA_STREAM_CASE(1, 3) HYMETA_STREAM_CASE(1, 4)
   HYMETA_STREAM_CASE(2, 1) HYMETA_STREAM_CASE(2, 2) HYMETA_STREAM_CASE(2, 3) HYMETA_STREAM_CASE(2, 4)
   HYMETA_STREAM_CASE(4, 1) HYMETA_STREAM_CASE(4, 2) HYMETA_STREAM_CASE(4, 3) HYMETA_STREAM_CASE(4, 4)

@@ -2,9 +2,11 @@
 // qweight int32 [K / 8, N] (a word = 8 consecutive k of ONE output column), qzeros int32 [K / 128, N / 8], scales
 // fp16 | bf16 [K / 128, N], group size 128.
 //
-// Built like the bf16 streaming kernel (stream_gemm.hip): a workgroup of 4 waves owns a tile of columns and a K slice,
-// x is staged through double-buffered LDS in 256-k chunks (one barrier per chunk), every wave streams the weights of
-// its own columns.  What differs is the weight path:
+// Built like the bf16 streaming kernel (stream_gemm.hip): a workgroup owns a tile of columns and a K slice, x is staged
+// through double-buffered LDS in 256-k chunks (one barrier per chunk), every wave streams the weights of its own
+// columns.  The workgroup has 8 waves, two per SIMD: waves w and w + 4 own the same columns and take one each of a
+// chunk's two groups of 128 k, so that one wave's de-quantisation (VALU) and LDS round trips run under the other's
+// MFMAs; their two partial tiles are added when the tile is written.  What differs further is the weight path:
 //   * a wave's columns come in blocks of 32 (one 128-byte line of a qweight row): one load instruction is 8 packed rows
 //     x 128 bytes = 64 k of 32 columns, whole lines (lane = row l / 8, 16-byte piece l % 8).  It passes through a
 //     wave-private 1 KB LDS image, from which lane (n, cq) of the MFMA layout reads the ONE word that holds its 8
@@ -40,11 +42,20 @@ __device__ __forceinline__ float scale_at(const void* p, int64_t idx, bool f16) 
 }
 
 // One wave's part of a tile: NP blocks of 32 columns from block ``wave_b0`` on; the tile is blocks [tile_b0, tile_b0 +
-// tile_nb).  MT: 16-row fragments; NPT: the widest wave of the launch (sizes the shared images).
+// tile_nb).  MT: the wave's 16-row fragments; NPT: the widest wave of the launch (sizes the shared images).
+// Waves w and w + 4 own the same columns and split K: one group of every chunk each, over all 16 MT rows.
 template <int MT, int NP, int NPT>
 __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, const int wave_b0, const int tile_b0,
                                           const int tile_nb, const int split) {
-  constexpr int R = 4;                           // units in flight per block of columns: one chunk ahead
+  // How far ahead the wave asks for things.  Deeper rings (4 chunks) with x and the scales two chunks ahead were measured
+  // and change nothing: these launches are bound by their fixed costs on narrow matrices and by instruction issue on
+  // wide ones, not by the time a load is in flight.
+  constexpr int R = 4;                           // ring of the wave's weight units per block of columns: two chunks ahead
+  constexpr int kAheadX = 1;                     // chunks of x held in registers ahead of the shared image
+  constexpr int kAheadS = 1;                     // groups the scales and zeros are loaded ahead
+  constexpr int kSets = 2 * kAheadS;             // their register sets
+  constexpr int kUnroll = 2;                     // chunks per trip of the main loop: every index above is static inside
+  constexpr int kThreads = 512;
   constexpr int NF = 2 * NP;                     // 16-column fragments of the wave
   constexpr int kRowsT = 16 * MT;
   constexpr int kPitch = 128 * NPT + 4;          // floats per row of the epilogue image (4 waves x 32 NPT columns)
@@ -53,6 +64,7 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2;                    // which of a chunk's two groups this wave takes
   const int lane = tid & 63;
   const int n = lane & 15, cq = lane >> 4;
   char* wimg = smem + 2 * kBufBytes + wave * kWaveImg;
@@ -61,12 +73,12 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
 
   // x staging: 16-byte piece idx = j * 256 + tid of the [rows][32 pieces] chunk image; the 8 values of a piece are
   // stored in the order the nibble trick emits
-  constexpr int kStage = kRowsT * kPieces / 256;
+  constexpr int kStage = kRowsT * kPieces / kThreads;
   const char* xsrc[kStage];
   int xdst[kStage];
 #pragma unroll
   for (int j = 0; j < kStage; ++j) {
-    const int idx = j * 256 + tid;
+    const int idx = j * kThreads + tid;
     const int row = idx / kPieces, piece = idx % kPieces;
     xsrc[j] = a.x + static_cast<int64_t>(min(row, a.M - 1)) * a.x_stride_bytes + piece * 16;
     xdst[j] = row * kChunkBytes + ((piece & 16) | ((piece ^ row) & 15)) * 16;
@@ -85,7 +97,7 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
     wdst = r * 128 + ((p ^ (4 * (r & 1))) * 16);
 #pragma unroll
     for (int i = 0; i < NP; ++i)
-      wl[i] = reinterpret_cast<const char*>(a.qweight) + (static_cast<int64_t>(c_lo) * 32 + r) * row_bytes +
+      wl[i] = reinterpret_cast<const char*>(a.qweight) + (static_cast<int64_t>(c_lo) * 32 + 16 * half + r) * row_bytes +
               (static_cast<int64_t>(wave_b0 + i) * 32 + 4 * p) * 4;
   }
   // fragment reads: k-step s of the unit, fragment f of the block: word (row 4 s + cq, column 16 f + n)
@@ -98,10 +110,12 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
       wsrc[s][f] = r * 128 + (((c >> 2) ^ (4 * (r & 1))) * 16) + (c & 3) * 4;
     }
 
-  const int nunits = (c_hi - c_lo) * kUnitsPerChunk;
+  // the wave's own units, two per chunk: unit v is unit (v & 1) of its group in chunk v / 2 of the slice
+  const int nunits = (c_hi - c_lo) * 2;
   u32x4 ring[R][NP];
   auto issue = [&](int slot, int unit) {
-    const int64_t off = static_cast<int64_t>(min(unit, nunits - 1)) * unit_bytes;
+    const int v = min(unit, nunits - 1);
+    const int64_t off = static_cast<int64_t>((v >> 1) * kUnitsPerChunk + (v & 1)) * unit_bytes;
 #pragma unroll
     for (int i = 0; i < NP; ++i) ring[slot][i] = ld16nt(wl[i] + off);
   };
@@ -112,13 +126,13 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
   // scales and zeros of the lane's column in each fragment, one group ahead
   const bool f16 = a.scales_f16 != 0;
   const int groups_n8 = a.N / 8;
-  // two register sets used alternately (group parity is static in the unrolled chunk body): a set is loaded at the start of
-  // the group before its own and first read at the end of its own, two groups of work later -- no copy, no early wait
+  // register sets used in rotation (the wave's group index modulo kSets is static in the unrolled chunk loop): a set is
+  // loaded kAheadS groups before its own and first read at the end of its own -- no copy, no early wait
   // (kept as loaded -- a 16-bit scale, the packed word of zeros -- and converted where they are used: a conversion next
   // to the load would make the wave wait for it, and for every weight load before it, on the spot)
-  uint32_t sc[2][NF], zc[2][NF];
-  auto load_group = [&](int g, uint32_t (&s_)[NF], uint32_t (&z_)[NF]) {
-    const int gg = min(g, a.chunks * 2 - 1);
+  uint32_t sc[kSets][NF], zc[kSets][NF];
+  auto load_group = [&](int gi, uint32_t (&s_)[NF], uint32_t (&z_)[NF]) {      // gi: the wave's own group count from c_lo
+    const int gg = min(2 * (c_lo + gi) + half, a.chunks * 2 - 1);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int col = (wave_b0 + (f >> 1)) * 32 + 16 * (f & 1) + n;
@@ -128,7 +142,8 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
   };
   const int zshift = 4 * (n & 7);                 // the lane's column inside a packed word of zeros (16 f + n: same for every f)
   const float zbase = static_cast<float>(128 + a.zero_offset);
-  load_group(2 * c_lo, sc[0], zc[0]);
+#pragma unroll
+  for (int g = 0; g < kAheadS; ++g) load_group(g, sc[g], zc[g]);
 
   f32x4 acc[MT][NF];
 #pragma unroll
@@ -136,16 +151,16 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[mt][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 xs[kStage];
-  auto stage_load = [&](int c) {
+  u32x4 xs[kAheadX][kStage];
+  auto stage_load = [&](int set, int c) {
     const int64_t off = static_cast<int64_t>(min(c, c_hi - 1)) * kChunkBytes;
 #pragma unroll
-    for (int j = 0; j < kStage; ++j) xs[j] = ld16g(xsrc[j] + off);
+    for (int j = 0; j < kStage; ++j) xs[set][j] = ld16g(xsrc[j] + off);
   };
-  auto stage_store = [&](char* buf) {
+  auto stage_store = [&](int set, char* buf) {
 #pragma unroll
     for (int j = 0; j < kStage; ++j) {
-      const u32x4 r = xs[j];
+      const u32x4 r = xs[set][j];
       u32x4 o;     // (k0,k1)(k2,k3)(k4,k5)(k6,k7) -> (k0,k4)(k1,k5)(k2,k6)(k3,k7)
       o[0] = __builtin_amdgcn_perm(r[2], r[0], 0x05040100u);
       o[1] = __builtin_amdgcn_perm(r[2], r[0], 0x07060302u);
@@ -154,69 +169,87 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
       *reinterpret_cast<u32x4*>(buf + xdst[j]) = o;
     }
   };
-  stage_load(c_lo);
-  stage_store(smem);
+  stage_load(0, c_lo);
+  if constexpr (kAheadX == 2) stage_load(1, c_lo + 1);
+  stage_store(0, smem);
   __syncthreads();
 
   const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-  for (int c = c_lo; c < c_hi; ++c) {
-    const char* cur = smem + ((c - c_lo) & 1) * kBufBytes;
-    stage_load(c + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    const int unit0 = (c - c_lo) * kUnitsPerChunk;
+  // at the top of chunk i (counted from c_lo): the shared image i & 1 holds x of chunk i, the registers those of chunks
+  // i + 1 .. i + kAheadX - 1; chunk i + kAheadX is asked for, and chunk i + 1 goes to the other image at the bottom
+  for (int c0 = c_lo; c0 < c_hi; c0 += kUnroll) {
 #pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2) {                // the chunk's two groups of 128 k
-      load_group(2 * c + g2 + 1, sc[g2 ^ 1], zc[g2 ^ 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4 gacc[MT][NF], sx[MT];
-#pragma unroll
-      for (int uu = 0; uu < 2; ++uu) {               // the group's two units of 64 k
-        const int p = 2 * g2 + uu;
-        const int slot = p % R;
-        char* region = wimg + (p & 1) * (NPT * 1024);
-#pragma unroll
-        for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4*>(region + i * 1024 + wdst) = ring[slot][i];
-        // keep the refill where it is (see stream_gemm.hip)
+    for (int cc = 0; cc < kUnroll; ++cc) {
+      const int c = c0 + cc;
+      if (c >= c_hi) break;
+      const char* cur = smem + ((c - c_lo) & 1) * kBufBytes;
+      stage_load(cc % kAheadX, c + kAheadX);
+      {
+        const int gb = cc % kSets;                     // the group's set of scale / zero registers
+        load_group(c - c_lo + kAheadS, sc[(gb + kAheadS) % kSets], zc[(gb + kAheadS) % kSets]);
         __builtin_amdgcn_sched_barrier(0);
-        issue(slot, unit0 + p + R);
+        const int unit0 = (c - c_lo) * 2;
+        // the group's two units (64 k each) of every block go to the wave's images, and their ring slots are refilled
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+          const int slot = (2 * cc + uu) % R;
+#pragma unroll
+          for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4*>(wimg + uu * (NPT * 1024) + i * 1024 + wdst) = ring[slot][i];
+        }
+        // keep the refills where they are (see stream_gemm.hip)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const bool first = uu == 0 && s == 0;
-          u32x4 af[MT];
-          const int piece = 4 * (4 * g2 + 2 * uu + s) + cq;
-          const int poff = ((piece & 16) | ((piece ^ n) & 15)) * 16;
+        for (int uu = 0; uu < 2; ++uu) issue((2 * cc + uu) % R, unit0 + uu + R);
+        __builtin_amdgcn_sched_barrier(0);
+        // one block of 32 columns at a time (its partial sums are the only ones live); the rows' sums of x come with the first
+        f32x4 sx[MT];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(cur + aoff[mt] + poff);
+        for (int i = 0; i < NP; ++i) {
+          f32x4 gacc[MT][2];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) sx[mt] = mma_bf16(af[mt], ones, first ? f32x4{0.f, 0.f, 0.f, 0.f} : sx[mt]);
+          for (int ks = 0; ks < 4; ++ks) {               // the group's four k-steps: unit ks / 2, half ks % 2 of it
+            const int uu = ks >> 1, s = ks & 1;
+            const char* region = wimg + uu * (NPT * 1024) + i * 1024;
+            u32x4 af[MT];
+            const int piece = 4 * (4 * half + ks) + cq;
+            const int poff = ((piece & 16) | ((piece ^ n) & 15)) * 16;
 #pragma unroll
-          for (int f = 0; f < NF; ++f) {
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(region + (f >> 1) * 1024 + wsrc[s][f & 1]);
-            u32x4 b;
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(cur + aoff[mt] + poff);
+            if (i == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = ((w >> (4 * j)) & 0x000F000Fu) | 0x43004300u;
+              for (int mt = 0; mt < MT; ++mt) sx[mt] = mma_bf16(af[mt], ones, ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sx[mt]);
+            }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) gacc[mt][f] = mma_bf16(af[mt], b, first ? f32x4{0.f, 0.f, 0.f, 0.f} : gacc[mt][f]);
+            for (int f = 0; f < 2; ++f) {
+              const uint32_t w = *reinterpret_cast<const uint32_t*>(region + wsrc[s][f]);
+              u32x4 b;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) b[j] = ((w >> (4 * j)) & 0x000F000Fu) | 0x43004300u;
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) gacc[mt][f] = mma_bf16(af[mt], b, ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : gacc[mt][f]);
+            }
+          }
+          // the group's scale and zero, applied to its partial sums
+#pragma unroll
+          for (int f2 = 0; f2 < 2; ++f2) {
+            const int f = 2 * i + f2;
+            const float s_ = f16 ? static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(sc[gb][f]))) : __uint_as_float(sc[gb][f] << 16);
+            const float z_ = zbase + static_cast<float>((zc[gb][f] >> zshift) & 0xFu);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[mt][f][r] = fmaf(s_, fmaf(-z_, sx[mt][r], gacc[mt][f2][r]), acc[mt][f][r]);
           }
         }
       }
-      // the group's scale and zero, applied to its partial sums
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const float s_ = f16 ? static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(sc[g2][f]))) : __uint_as_float(sc[g2][f] << 16);
-        const float z_ = zbase + static_cast<float>((zc[g2][f] >> zshift) & 0xFu);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[mt][f][r] = fmaf(s_, fmaf(-z_, sx[mt][r], gacc[mt][f][r]), acc[mt][f][r]);
-      }
+      stage_store((cc + 1) % kAheadX, smem + (((c - c_lo) & 1) ^ 1) * kBufBytes);
+      __syncthreads();
     }
-    stage_store(smem + (((c - c_lo) & 1) ^ 1) * kBufBytes);
-    __syncthreads();
   }
 
-  // ---- epilogue: the tile as a row-major fp32 image in LDS
+  // ---- epilogue: the tile as a row-major fp32 image in LDS; with K split between the halves there is one image for
+  // each, added on the way out (half 0 + half 1)
+  constexpr int kImg = kRowsT * kPitch;
   float* img = reinterpret_cast<float*>(smem);
   const int img_col0 = 32 * (wave_b0 - tile_b0);
 #pragma unroll
@@ -224,14 +257,15 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) img[(16 * mt + 4 * cq + r) * kPitch + img_col0 + 16 * f + n] = acc[mt][f][r];
+      for (int r = 0; r < 4; ++r) img[half * kImg + (16 * mt + 4 * cq + r) * kPitch + img_col0 + 16 * f + n] = acc[mt][f][r];
   __syncthreads();
   const int vec_per_row = 8 * tile_nb;
-  for (int idx = tid; idx < kRowsT * vec_per_row; idx += 256) {
+  for (int idx = tid; idx < kRowsT * vec_per_row; idx += kThreads) {
     const int row = idx / vec_per_row, c4 = idx % vec_per_row;
     if (row >= a.M) continue;
     const int col = 32 * tile_b0 + 4 * c4;
     f32x4 y = *reinterpret_cast<const f32x4*>(img + row * kPitch + 4 * c4);
+    y += *reinterpret_cast<const f32x4*>(img + kImg + row * kPitch + 4 * c4);
     if (a.splits > 1) {
       *reinterpret_cast<f32x4*>(a.slabs + ((static_cast<int64_t>(split) * a.M + row) * a.N + col) * 4) = y;
       continue;
@@ -246,14 +280,14 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
 }
 
 template <int MT, int NPHI>
-__global__ __launch_bounds__(256, 1) void stream_gptq_kernel(StreamGptqArgs a) {
+__global__ __launch_bounds__(512, 1) void stream_gptq_kernel(StreamGptqArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
   const int blocks = a.N / 32;
   const int b_lo = static_cast<int>(static_cast<int64_t>(t) * blocks / a.tiles);
   const int b_hi = static_cast<int>(static_cast<int64_t>(t + 1) * blocks / a.tiles);
   const int c = b_hi - b_lo;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;      // waves w and w + 4 share their columns
   const int w_lo = b_lo + wave * c / 4, w_hi = b_lo + (wave + 1) * c / 4;
   if (w_hi - w_lo == NPHI) {
     gptq_wave<MT, NPHI, NPHI>(a, smem, w_lo, b_lo, c, split);
@@ -288,8 +322,9 @@ __global__ __launch_bounds__(256) void stream_gptq_reduce_kernel(StreamGptqArgs 
 
 template <int MT, int NP>
 int launch_gptq(const StreamGptqArgs& a, hipStream_t s, bool defer_reduce) {
-  constexpr size_t img = static_cast<size_t>(16 * MT) * (128 * NP + 4) * 4;
-  constexpr size_t stream = 2u * 16 * MT * kChunkBytes + 4u * 2 * NP * 1024;
+  constexpr int rows = 16 * MT;
+  constexpr size_t img = 2u * static_cast<size_t>(rows) * (128 * NP + 4) * 4;     // K split: one image per half
+  constexpr size_t stream = 2u * rows * kChunkBytes + 8u * 2 * NP * 1024;
   constexpr size_t lds = img > stream ? img : stream;
   auto kern = stream_gptq_kernel<MT, NP>;
   static bool configured = false;
@@ -298,7 +333,7 @@ int launch_gptq(const StreamGptqArgs& a, hipStream_t s, bool defer_reduce) {
       (void)hipGetLastError();
     configured = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.tiles * a.splits), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.tiles * a.splits), dim3(512), lds, s, a);
   if (a.splits > 1 && !defer_reduce) {
     if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
     const int64_t threads = static_cast<int64_t>(a.M) * (a.N / 4);
@@ -316,12 +351,14 @@ bool stream_gptq_plan(int M, int K, int N, int bits, int group_size, bool have_w
   const int want = want_forced > 0 ? want_forced : 256;
   const int chunks = K / 256;
   const int blocks = N / 32;                   // 32-column blocks; a wave owns 1 or 2, a tile 4 to 8
-  // Matrices wide enough to give every compute unit a tile without K slices stay on the older kernels (quant_gemm.hip):
-  // this kernel is bound by instruction issue there (one wave per SIMD does de-quantisation, LDS reads and MFMAs in
-  // turn) and measures behind them, 30 against 22 us at 1 row and 51 against 47 at 64 on the 7B gate_up matrix.  On the
-  // narrow ones (qkv, o, down) it is level or ahead: 16 against 18-20 us at 64 rows on qkv and o.
-  static const bool wide_too = [] { const char* e = getenv("HYMETA_GPTQ_STREAM_WIDE"); return e && atoi(e) != 0; }();
-  if (blocks / 4 >= want && !wide_too) return false;
+  // Matrices wide enough to give every compute unit a tile without K slices have waves that own two blocks: with four
+  // row fragments (33 to 64 rows) those have no registers left for them at two waves per SIMD, and such calls stay on
+  // the older kernels (quant_gemm.hip).  Measured on the 7B gate_up matrix: level with them up to 16 rows (24 against
+  // 23 us; they keep those), ahead at 17 to 32 (30 against 40 us).  HYMETA_GPTQ_STREAM_WIDE=0 keeps every wide matrix
+  // on the older kernels, =2 sends all up to 32 rows here.
+  static const int wide_mode = [] { const char* e = getenv("HYMETA_GPTQ_STREAM_WIDE"); return e == nullptr ? 1 : atoi(e); }();
+  const bool wide = blocks / 4 >= want;
+  if (wide && (wide_mode == 0 || M > 32 || (M <= 16 && wide_mode != 2))) return false;
   int tiles = blocks / 4 < want ? blocks / 4 : want;
   if (tiles < (blocks + 7) / 8) tiles = (blocks + 7) / 8;
   const int np = ((blocks + tiles - 1) / tiles + 3) / 4;
@@ -332,7 +369,7 @@ bool stream_gptq_plan(int M, int K, int N, int bits, int group_size, bool have_w
   if (splits > kMaxSplits) splits = kMaxSplits;
   if (splits < 1) splits = 1;
   p->np = np, p->tiles = tiles, p->chunks = chunks, p->splits = splits;
-  return np >= 1 && np <= 2;
+  return np == 1 || (np == 2 && M <= 32);
 }
 
 size_t stream_gptq_workspace_bytes(int M, int N, const StreamGptqPlan& p) {
@@ -345,7 +382,7 @@ int stream_gptq_launch(StreamGptqArgs a, const StreamGptqPlan& p, hipStream_t s,
   a.tiles = p.tiles, a.chunks = p.chunks, a.splits = p.splits;
   const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
 #define HYMETA_GPTQ_CASE(MT_, NP_) if (mt == MT_ && p.np == NP_) return launch_gptq<MT_, NP_>(a, s, defer_reduce);
-  HYMETA_GPTQ_CASE(1, 1) HYMETA_GPTQ_CASE(1, 2) HYMETA_GPTQ_CASE(2, 1) HYMETA_GPTQ_CASE(2, 2) HYMETA_GPTQ_CASE(4, 1) HYMETA_GPTQ_CASE(4, 2)
+  HYMETA_GPTQ_CASE(1, 1) HYMETA_GPTQ_CASE(1, 2) HYMETA_GPTQ_CASE(2, 1) HYMETA_GPTQ_CASE(2, 2) HYMETA_GPTQ_CASE(4, 1)
 #undef HYMETA_GPTQ_CASE
   return HYMETA_ERR_UNSUPPORTED;
 }
