@@ -144,6 +144,11 @@ typedef struct hymeta_gla_decode_args {
   const void* qkv_bias;
   int32_t qkv_splits, qkv_n;
   int32_t q_col, k_col, v_col, g_col;
+  /* Both linears of the low-rank gate inside the kernel (a checkpoint whose qkv projection is quantised cannot carry
+   * the gate's first linear as extra rows): with g_w0 bf16 [16, g_hidden] contiguous given (g_w1 required, no
+   * qkv_slabs), g is the LAYER INPUT, bf16 [batch, g_hidden] rows g_stride_b apart.  State per key/value head only. */
+  const void* g_w0;
+  int32_t g_hidden;
 } hymeta_gla_decode_args;
 
 int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stream_t stream);

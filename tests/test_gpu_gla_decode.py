@@ -143,6 +143,17 @@ def test_gla_decode_low_rank_gate_applied_in_the_kernel(state_heads):
     out_b = hip_ops.gla_decode(q, k, v, wide[:, 40:56], s_b, slot, g_w1=w1, g_bias=b1, **kw)
     torch.cuda.synchronize()
     assert torch.equal(out_a, out_b) and torch.equal(s_a, s_b)
+    if state_heads == "kv":
+        # both linears in the kernel, from the layer input (rows of a wider tensor): the same bits again
+        xw = torch.zeros(B, hidden + 64, dtype=torch.bfloat16, device="cuda")
+        xw[:, 8:8 + hidden] = x
+        s_c = state.clone()
+        out_c = hip_ops.gla_decode(q, k, v, xw[:, 8:8 + hidden], s_c, slot, g_w0=w0, g_w1=w1, g_bias=b1, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, out_c) and torch.equal(s_a, s_c)
+    else:
+        with pytest.raises(Exception):
+            hip_ops.gla_decode(q, k, v, x, state.clone(), slot, g_w0=w0, g_w1=w1, g_bias=b1, **kw)
 
 
 @pytest.mark.parametrize("first_layer", [True, False])

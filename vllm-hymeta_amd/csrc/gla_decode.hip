@@ -8,6 +8,7 @@
 // the q-contraction in registers.  Rows of the state are 256 B, so a wave's
 // 16-byte-per-lane access covers whole rows (NSPLIT 1) or 128-B half rows
 // (NSPLIT 2): fully coalesced either way.
+#include "lowrank_gate.h"
 #include "common.h"
 #include "gla_gate.h"
 #include "partial_sums.h"
@@ -313,11 +314,17 @@ __global__ __launch_bounds__(THREADS) void gla_decode_group_kernel(hymeta_gla_de
     __syncthreads();
   }
 
+  // both linears of the low-rank gate here: g is the layer's input row, the first linear's 16 values land in s_t
+  const bool gate_from_x = a.g_w0 != nullptr;
+  if (gate_from_x)
+    lowrank_first_linear(reinterpret_cast<const uint16_t*>(a.g) + b * a.g_stride_b, reinterpret_cast<const uint16_t*>(a.g_w0), a.g_hidden,
+                         reinterpret_cast<float(*)[16]>(&s_red[0][0][0]), s_t);
+
   if (tid < D) {
     const uint16_t* kp = reinterpret_cast<const uint16_t*>(a.k) + b * a.k_stride_b + kvh * a.k_stride_h;
     float g_raw = 0.f;
     if (a.g_w1 != nullptr) {
-      g_raw = from_slabs ? lowrank_gate_from(a, s_t, kvh * D + tid) : lowrank_gate_value(a, b, kvh * D + tid);
+      g_raw = (from_slabs || gate_from_x) ? lowrank_gate_from(a, s_t, kvh * D + tid) : lowrank_gate_value(a, b, kvh * D + tid);
     } else if (a.g != nullptr) {
       const int64_t goff = b * a.g_stride_b + kvh * a.g_stride_h + tid;
       g_raw = a.g_dtype == HYMETA_F32 ? reinterpret_cast<const float*>(a.g)[goff]
@@ -533,6 +540,12 @@ extern "C" int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stre
   if (a.g_w1 != nullptr && !from_slabs) {      // low-rank gate: g = bf16 [batch, 16] rows, 16-byte loads
     if (!a.g || a.g_dtype != HYMETA_BF16 || a.g_stride_b % 8 != 0) return HYMETA_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(a.g) | reinterpret_cast<uintptr_t>(a.g_w1)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  }
+  if (a.g_w0 != nullptr) {      // both linears in the kernel: g = the layer input, bf16 [batch, g_hidden]
+    if (!a.g_w1 || from_slabs || a.g_hidden <= 0 || a.g_hidden % 8 != 0) return HYMETA_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(a.g_w0) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+    const int sh = a.state_heads == 0 ? a.num_heads : a.state_heads;
+    if (sh == a.num_heads) return HYMETA_ERR_UNSUPPORTED;   // the kernels of the state per key/value head only
   }
   // 16-byte vector access on v, out and state rows
   if (((from_slabs ? 0 : (a.v_stride_b | a.v_stride_h)) | a.state_stride_slot | a.state_stride_h) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;

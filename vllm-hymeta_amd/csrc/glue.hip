@@ -1,5 +1,6 @@
 // Element-wise glue of the attention layers: NeoX rotary embedding, the 70B
 // two-branch RMS-norm combine and the blocks' RMS norm with the residual add.  HBM-bound; 16-byte accesses throughout.
+#include "lowrank_gate.h"
 #include "common.h"
 #include "partial_sums.h"
 #include "w8a8_quant.h"
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void lowrank_gate_kernel(hymeta_lowrank_gate_a
   constexpr int R = 16;
   __shared__ float s_part[4][R];
   __shared__ float s_t[R];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const uint16_t* x = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(blockIdx.x) * a.x_stride_t;
   const uint16_t* w0 = reinterpret_cast<const uint16_t*>(a.w0);
   // the second stage's weights do not depend on the first: fetch this thread's first two rows now, under the first
@@ -368,40 +369,7 @@ __global__ __launch_bounds__(256) void lowrank_gate_kernel(hymeta_lowrank_gate_a
     const int o = min(tid + 256 * j, a.out_features - 1);
     w1a[j] = ld16(w1 + static_cast<int64_t>(o) * R), w1b[j] = ld16(w1 + static_cast<int64_t>(o) * R + 8);
   }
-  float acc[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = 0.f;
-#pragma unroll 2
-  for (int ch = tid; ch < a.hidden / 8; ch += 256) {
-    const u32x4 xv = ld16(x + 8 * ch);
-    float xf[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      xf[2 * i] = lo_bf(xv[i]);
-      xf[2 * i + 1] = hi_bf(xv[i]);
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const u32x4 wv = ld16(w0 + static_cast<int64_t>(r) * a.hidden + 8 * ch);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acc[r] = fmaf(xf[2 * i], lo_bf(wv[i]), acc[r]);
-        acc[r] = fmaf(xf[2 * i + 1], hi_bf(wv[i]), acc[r]);
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) acc[r] += __shfl_xor(acc[r], off);
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) s_part[wave][r] = acc[r];
-  }
-  __syncthreads();
-  if (tid < R) s_t[tid] = bf16_round(s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid]);
-  __syncthreads();
+  lowrank_first_linear(x, w0, a.hidden, s_part, s_t);
   float t[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) t[r] = s_t[r];

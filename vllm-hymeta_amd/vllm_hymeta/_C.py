@@ -47,6 +47,7 @@ class GlaDecodeArgs(C.Structure):
         ("state_heads", _i32), ("g_w1", _ptr), ("g_bias", _ptr),
         ("qkv_slabs", _ptr), ("qkv_bias", _ptr), ("qkv_splits", _i32), ("qkv_n", _i32),
         ("q_col", _i32), ("k_col", _i32), ("v_col", _i32), ("g_col", _i32),
+        ("g_w0", _ptr), ("g_hidden", _i32),
     ]
 
 

@@ -67,13 +67,16 @@ def gla_decode(
     g_bias: Optional[torch.Tensor] = None,
     qkv_partials: Optional["PartialSums"] = None,
     qkv_cols: Optional[tuple] = None,
+    g_w0: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """q [B,H,D]; k, v, g [B,Hkv,D]; state [slots,H,D,D] (one state per query head, the reference's
     layout) or [slots,Hkv,D,D] (one per key/value head; any gate but the 70B lower-bound one), updated
     in place; slot_idx [B] int32.
 
     Low-rank gate (7B): with ``g_w1`` bf16 [Hkv*D, 16] (and ``g_bias`` bf16 [Hkv*D]) ``g`` is the rank-16 input
-    bf16 [B, 16] and the kernel applies the second linear of the gate projection itself.
+    bf16 [B, 16] and the kernel applies the second linear of the gate projection itself.  With ``g_w0`` bf16
+    [16, hidden] as well, ``g`` is the layer input bf16 [B, hidden] and the kernel applies both linears (state per
+    key/value head only).
 
     ``qkv_partials`` (fp32 ``PartialSums`` of the fused qkv projection) with ``qkv_cols = (q_col, k_col, v_col, g_col)``:
     q, k, v and the rank-16 gate input are read from the partial sums (the projection's reduce launch is skipped); then
@@ -91,13 +94,18 @@ def gla_decode(
              "q, k, v must be bfloat16")
     _require(k.shape == (B, Hkv, D) and v.shape == (B, Hkv, D), "k, v must be [B, Hkv, D]")
     if g_w1 is not None:
-        _dev(g_w1, g_bias)
-        _require(g is not None and g.shape == (B, 16) and g.dtype == torch.bfloat16 and g.stride(1) == 1 and g.stride(0) % 8 == 0,
-                 "low-rank gate: g must be bf16 [B, 16] with rows a multiple of 8 elements apart")
+        _dev(g_w1, g_bias, g_w0)
+        width = 16 if g_w0 is None else g_w0.shape[1]
+        _require(g_w0 is None or (g_w0.dtype == torch.bfloat16 and g_w0.is_contiguous() and g_w0.dim() == 2 and g_w0.shape[0] == 16
+                                  and width % 8 == 0 and state.shape[1] == Hkv != H),
+                 "g_w0 must be contiguous bf16 [16, hidden], with a state per key/value head")
+        _require(g is not None and g.shape == (B, width) and g.dtype == torch.bfloat16 and g.stride(1) == 1 and g.stride(0) % 8 == 0,
+                 "low-rank gate: g must be bf16 [B, 16] (or [B, hidden] with g_w0) with rows a multiple of 8 elements apart")
         _require(g_w1.dtype == torch.bfloat16 and g_w1.is_contiguous() and g_w1.shape == (Hkv * D, 16), "g_w1 must be contiguous bf16 [Hkv*D, 16]")
         _require(g_bias is None or (g_bias.dtype == torch.bfloat16 and g_bias.is_contiguous() and g_bias.numel() == Hkv * D),
                  "g_bias must be contiguous bf16 [Hkv*D]")
     else:
+        _require(g_w0 is None, "g_w0 needs g_w1")
         _require(g is None or g.shape == (B, Hkv, D), "g must be [B, Hkv, D]")
     _require(state.dim() == 4 and state.shape[2:] == (D, D) and state.shape[1] in (H, Hkv),
              "state must be [slots, H, D, D] or [slots, Hkv, D, D]")
@@ -132,6 +140,8 @@ def gla_decode(
         _require(g.dtype in _DT, "g must be bfloat16 or float32")
         a.g_dtype = _DT[g.dtype]
     a.g_w1, a.g_bias = _p(g_w1), _p(g_bias)
+    if g_w0 is not None:
+        a.g_w0, a.g_hidden = _p(g_w0), g_w0.shape[1]
     a.out_stride_b, a.out_stride_h = out.stride(0), out.stride(1)
     a.state_stride_slot, a.state_stride_h = state.stride(0), state.stride(1)
     a.state_dtype = _DT[state.dtype]

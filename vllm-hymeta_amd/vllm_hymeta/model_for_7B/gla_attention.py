@@ -75,6 +75,20 @@ class GatedLinearAttention(torch.nn.Module):
             y = self.o_proj(out.view(T, H * D), defer=defer_out and not reduce)
             return all_reduce_sum(y, self.tp_group) if reduce else y
         gk = rank16 = None
+        # a quantised checkpoint (its gate projection is not quantised): on a pure decode step with a state per key/value
+        # head the recurrence kernel applies both of the gate's linears to the layer input itself
+        gate_in_kernel = (not self.gate_in_qkv and n_pre == 0 and T > 0 and gla_cache.shape[1] == Hkv != H
+                          and p0.kind == "bf16" and p1.kind == "bf16" and p0.bias is None and p0.weight.shape[0] == 16
+                          and p0.weight.is_contiguous() and p1.weight.is_contiguous() and hidden_states.stride(0) % 8 == 0)
+        if gate_in_kernel:
+            q = qkv[:, : H * D].view(T, H, D)
+            k = qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
+            v = qkv[:, (H + Hkv) * D:(H + 2 * Hkv) * D].view(T, Hkv, D)
+            out = hip_ops.gla_decode(q, k, v, hidden_states, gla_cache, state_indices_tensor, g_w0=p0.weight, g_w1=p1.weight,
+                                     g_bias=p1.bias, **gate)
+            reduce = parallel._active(self.tp_group)
+            y = self.o_proj(out.view(T, H * D), defer=defer_out and not reduce)
+            return all_reduce_sum(y, self.tp_group) if reduce else y
         if self.gate_in_qkv:
             rank16 = qkv[:, self.qkv_features:self.qkv_features + 16]       # the gate's first linear, bf16 [T, 16]
             if t_pre > 0:
