@@ -14,6 +14,7 @@ constexpr int kHeadDim = 128;    // the only head size the Hymeta models use
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));  // MFMA A/B fragment (8 bf16)
 
 __device__ __forceinline__ float bf2f(uint16_t x) {

@@ -63,9 +63,8 @@ __global__ __launch_bounds__(256) void rope_partials_kernel(hymeta_rope_args a, 
     const int head = w / chunks, ch = w % chunks;
     const int col = head * a.head_dim + 8 * ch;
     float x[8], y[8];
-    partial_row8<I8>(p, t, col, x);
-    partial_row8<I8>(p, t, col + half, y);
     const u32x4 cv = ld16(cs + 8 * ch), sv = ld16(cs + half + 8 * ch);
+    partial_row8_x2<I8>(p, t, col, col + half, x, y);      // both halves' loads in flight together
     u32x4 xo, yo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -219,30 +218,67 @@ __global__ __launch_bounds__(256) void add_rmsnorm_partials_kernel(hymeta_add_rm
   const uint16_t* w = reinterpret_cast<const uint16_t*>(a.weight);
   uint16_t* out = reinterpret_cast<uint16_t*>(a.out) + t * a.out_stride_t;
   const int chunks = a.hidden / 8;
-  float ss = 0.f;
-  for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
-    float x[8];
-    partial_row8<I8>(p, t, 8 * c, x);
-    const u32x4 r = ld16(res + 8 * c);
-    u32x4 z;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      z[i] = pack_bf16x2(x[2 * i] + lo_bf(r[i]), x[2 * i + 1] + hi_bf(r[i]));
-    st16(res + 8 * c, z);
+  if (chunks <= 512) {
+    // up to 4096 columns: a thread owns chunks tid and tid + 256; every load of both (residual, norm weight, the slabs
+    // of a batch of slices) is in flight before the first is used, and z stays in registers between the two passes
+    const int ca = min(static_cast<int>(threadIdx.x), chunks - 1), cb = threadIdx.x + 256 < chunks ? threadIdx.x + 256 : ca;
+    const bool has_a = static_cast<int>(threadIdx.x) < chunks, has_b = static_cast<int>(threadIdx.x) + 256 < chunks;
+    const u32x4 ra = ld16(res + 8 * ca), rb = ld16(res + 8 * cb);
+    const u32x4 wa = ld16(w + 8 * ca), wb = ld16(w + 8 * cb);
+    float xa[8], xb[8];
+    partial_row8_x2<I8>(p, t, 8 * ca, 8 * cb, xa, xb);
+    u32x4 za, zb;
+    float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float z0 = lo_bf(z[i]), z1 = hi_bf(z[i]);
-      ss += z0 * z0 + z1 * z1;
+      za[i] = pack_bf16x2(xa[2 * i] + lo_bf(ra[i]), xa[2 * i + 1] + hi_bf(ra[i]));
+      zb[i] = pack_bf16x2(xb[2 * i] + lo_bf(rb[i]), xb[2 * i + 1] + hi_bf(rb[i]));
     }
-  }
-  const float rs = rsqrtf(block_sum_256(ss, s_red) / a.hidden + a.eps);
-  for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
-    const u32x4 z = ld16(res + 8 * c), wv = ld16(w + 8 * c);
-    u32x4 o;
+    if (has_a) {
+      st16(res + 8 * ca, za);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      o[i] = pack_bf16x2(bf16_round(lo_bf(z[i]) * rs) * lo_bf(wv[i]), bf16_round(hi_bf(z[i]) * rs) * hi_bf(wv[i]));
-    st16(out + 8 * c, o);
+      for (int i = 0; i < 4; ++i) ss += lo_bf(za[i]) * lo_bf(za[i]) + hi_bf(za[i]) * hi_bf(za[i]);
+    }
+    if (has_b) {
+      st16(res + 8 * cb, zb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ss += lo_bf(zb[i]) * lo_bf(zb[i]) + hi_bf(zb[i]) * hi_bf(zb[i]);
+    }
+    const float rs = rsqrtf(block_sum_256(ss, s_red) / a.hidden + a.eps);
+    u32x4 oa, ob;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      oa[i] = pack_bf16x2(bf16_round(lo_bf(za[i]) * rs) * lo_bf(wa[i]), bf16_round(hi_bf(za[i]) * rs) * hi_bf(wa[i]));
+      ob[i] = pack_bf16x2(bf16_round(lo_bf(zb[i]) * rs) * lo_bf(wb[i]), bf16_round(hi_bf(zb[i]) * rs) * hi_bf(wb[i]));
+    }
+    if (has_a) st16(out + 8 * ca, oa);
+    if (has_b) st16(out + 8 * cb, ob);
+  } else {
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+      float x[8];
+      partial_row8<I8>(p, t, 8 * c, x);
+      const u32x4 r = ld16(res + 8 * c);
+      u32x4 z;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        z[i] = pack_bf16x2(x[2 * i] + lo_bf(r[i]), x[2 * i + 1] + hi_bf(r[i]));
+      st16(res + 8 * c, z);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float z0 = lo_bf(z[i]), z1 = hi_bf(z[i]);
+        ss += z0 * z0 + z1 * z1;
+      }
+    }
+    const float rs = rsqrtf(block_sum_256(ss, s_red) / a.hidden + a.eps);
+    for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+      const u32x4 z = ld16(res + 8 * c), wv = ld16(w + 8 * c);
+      u32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        o[i] = pack_bf16x2(bf16_round(lo_bf(z[i]) * rs) * lo_bf(wv[i]), bf16_round(hi_bf(z[i]) * rs) * hi_bf(wv[i]));
+      st16(out + 8 * c, o);
+    }
   }
   if constexpr (Q) quantise_row_int8(out, a.hidden, xq + t * a.hidden, x_scale + t, s_red);
 }

@@ -3,6 +3,8 @@
 // own reduce launch would have written.  Used by the consumers that take the place of that launch.
 #pragma once
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace hymeta {
@@ -55,6 +57,53 @@ __device__ __forceinline__ void partial_row8(const hymeta_gemm_partials& p, int6
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) x[e] = bf16_round(lo[e] + b[e]), x[4 + e] = bf16_round(hi[e] + b[4 + e]);
+  }
+}
+
+// partial_row8 for two column groups of the same row at once, every load of a batch of four slices of both in flight
+// together (two calls in a row are not interleaved by the compiler: the second's loads wait behind the first's adds).
+template <bool I8>
+__device__ __forceinline__ void partial_row8_x2(const hymeta_gemm_partials& p, int64_t t, int col_a, int col_b, float (&xa)[8], float (&xb)[8]) {
+  const int64_t slab = static_cast<int64_t>(p.M) * p.N;
+  const uint16_t* bias = static_cast<const uint16_t*>(p.bias);
+  float ba[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  u32x4 bwa = {0, 0, 0, 0}, bwb = {0, 0, 0, 0};
+  if (bias != nullptr) bwa = ld16(bias + col_a), bwb = ld16(bias + col_b);
+  const char* src_a = static_cast<const char*>(p.slabs) + (t * p.N + col_a) * 4;
+  const char* src_b = static_cast<const char*>(p.slabs) + (t * p.N + col_b) * 4;
+  typedef typename std::conditional<I8, i32x4, f32x4>::type vec_t;
+  vec_t lo_a = {0, 0, 0, 0}, hi_a = {0, 0, 0, 0}, lo_b = {0, 0, 0, 0}, hi_b = {0, 0, 0, 0};
+  for (int sp = 0; sp < p.splits; sp += 4) {
+    vec_t la[4], ha[4], lb[4], hb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t off = static_cast<int64_t>(min(sp + i, p.splits - 1)) * slab * 4;
+      la[i] = *reinterpret_cast<const vec_t*>(src_a + off), ha[i] = *reinterpret_cast<const vec_t*>(src_a + off + 16);
+      lb[i] = *reinterpret_cast<const vec_t*>(src_b + off), hb[i] = *reinterpret_cast<const vec_t*>(src_b + off + 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (sp + i < p.splits) lo_a += la[i], hi_a += ha[i], lo_b += lb[i], hi_b += hb[i];
+  }
+  if (bias != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ba[2 * i] = lo_bf(bwa[i]), ba[2 * i + 1] = hi_bf(bwa[i]), bb[2 * i] = lo_bf(bwb[i]), bb[2 * i + 1] = hi_bf(bwb[i]);
+  }
+  if constexpr (I8) {
+    const float xs = p.x_scale[t];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xa[e] = bf16_round(w8a8_scaled(lo_a[e], xs, p.w_scale[col_a + e], ba[e]));
+      xa[4 + e] = bf16_round(w8a8_scaled(hi_a[e], xs, p.w_scale[col_a + 4 + e], ba[4 + e]));
+      xb[e] = bf16_round(w8a8_scaled(lo_b[e], xs, p.w_scale[col_b + e], bb[e]));
+      xb[4 + e] = bf16_round(w8a8_scaled(hi_b[e], xs, p.w_scale[col_b + 4 + e], bb[4 + e]));
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xa[e] = bf16_round(lo_a[e] + ba[e]), xa[4 + e] = bf16_round(hi_a[e] + ba[4 + e]);
+      xb[e] = bf16_round(lo_b[e] + bb[e]), xb[4 + e] = bf16_round(hi_b[e] + bb[4 + e]);
+    }
   }
 }
 

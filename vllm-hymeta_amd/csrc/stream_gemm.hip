@@ -36,7 +36,6 @@ constexpr int kChunkBytes = 64 * kChunkSteps;  // 512 bytes of one row
 constexpr int kPieces = kChunkBytes / 16;      // 16-byte pieces per row of a chunk
 constexpr int kMaxSplits = 16;
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <bool I8> struct Acc { typedef f32x4 type; };
 template <> struct Acc<true> { typedef i32x4 type; };
