@@ -74,8 +74,11 @@ def parse():
 
 
 # --------------------------------------------------------------------------- synthetic checkpoint
-def config_7b(vocab=4096):
-    """The published 7B geometry; the vocabulary is cut down (embedding and LM head are the engine's side)."""
+VOCAB = 152064
+
+
+def config_7b(vocab=VOCAB):
+    """The published 7B geometry, vocabulary included (the step ends in the lm_head logits and their argmax)."""
     from vllm_hymeta.model_for_7B.configuration_gla_swa import GLAswaConfig
     return GLAswaConfig(vocab_size=vocab)
 
@@ -144,6 +147,11 @@ def linear_weight_bytes(quant, tp=1):
     return int(N_LAYERS * per_layer * WBYTES[quant] / tp)
 
 
+def logits_bytes(B):
+    """lm_head (kept in bf16) read once, fp32 logits written and read back by the argmax."""
+    return VOCAB * HIDDEN * 2 + 2 * B * VOCAB * 4
+
+
 def attention_bytes(B, ctx, heads=H, kv_heads=HKV, state_heads=HKV):
     """Algorithmic bytes of the attention kernels of one step: GLA states read + written, visible K/V rows."""
     keys = min(ctx + 1, WINDOW + 1)
@@ -188,6 +196,7 @@ class DecodeRunner:
             seq_start_loc=None)
         self.graph = None
         self.out = None
+        self.with_logits = True
 
     def _refresh_slots(self):
         blk = torch.gather(self.block_tables.long(), 1, (self.positions // BLOCK).unsqueeze(1)).squeeze(1)
@@ -200,8 +209,15 @@ class DecodeRunner:
         self._refresh_slots()
 
     def eager_step(self):
-        return self.model(self.input_ids, self.positions, attn_metadata=self.md, kv_caches=self.kv,
-                          seqlen_agnostic_capture_inputs=self.capture_inputs)
+        """One greedy decode step: the 28 layers, the lm_head logits of every sequence, their argmax -- which becomes the
+        next step's input token, as in the engine's decode loop."""
+        from vllm_hymeta import hip_ops
+
+        h = self.model(self.input_ids, self.positions, attn_metadata=self.md, kv_caches=self.kv,
+                       seqlen_agnostic_capture_inputs=self.capture_inputs)
+        if self.with_logits:
+            hip_ops.argmax_rows(self.model.compute_logits(h), out=self.input_ids)
+        return h
 
     def capture(self, before_capture=None):
         """``before_capture``: called after the eager warm-up, right before recording starts (the tensor-parallel mode
@@ -561,12 +577,12 @@ def main():
 
     B, total = args.batch, args.warmup + args.steps
     model = build_model_7b(dev, args.quant, max_num_seqs=B, gla_state=args.gla_state)
-    runner = DecodeRunner(model, B, args.ctx, total + 8, dev)
+    runner = DecodeRunner(model, B, args.ctx, 2 * total + 16, dev)
     runner.capture()
     elapsed, gpu_ms = timed_steps(runner, args.warmup, args.steps)
 
     state_heads = HKV if args.gla_state == "kv_head" else H
-    step_bytes = linear_weight_bytes(args.quant) + attention_bytes(B, args.ctx, state_heads=state_heads)
+    step_bytes = linear_weight_bytes(args.quant) + attention_bytes(B, args.ctx, state_heads=state_heads) + logits_bytes(B)
     achieved = step_bytes / (gpu_ms * 1e-3) / 1e9
     keys = min(args.ctx + 1, WINDOW + 1)
     line = {
@@ -585,8 +601,9 @@ def main():
         "config": {
             "workload": f"Hymeta-7B {args.quant} TP=1 decode, ctx {args.ctx}, block_size {BLOCK}, {B} sequences; step = one token per "
                         "sequence through all 28 layers of GLAswaForCausalLM (embedding, norms, qkv/o/gate_up/down projections, 14 x GLA "
-                        f"decode, 14 x paged sliding-window decode over {keys} keys with fused KV write, final norm), one HIP graph per "
-                        "step; LM head and sampler (the engine's) not run",
+                        f"decode, 14 x paged sliding-window decode over {keys} keys with fused KV write, final norm), then the fp32 "
+                        "lm_head logits of every sequence and their argmax (greedy sampling), which is the next step's input token; "
+                        "one HIP graph per step",
             "batch_per_gpu": B,
             "ctx": args.ctx,
             "linears": args.quant,
@@ -595,7 +612,7 @@ def main():
                           if args.gla_state == "kv_head" else "one state per query head (the reference's cache shape)"),
         },
         "roofline": {
-            "kernel": "whole decode step (one graph launch): linear weights + visible K/V rows + GLA states",
+            "kernel": "whole decode step (one graph launch): linear weights + visible K/V rows + GLA states + lm_head and logits",
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
@@ -605,9 +622,16 @@ def main():
             "algorithmic_bytes_per_launch": int(step_bytes),
             "linear_weight_bytes": linear_weight_bytes(args.quant),
             "attention_bytes": int(attention_bytes(B, args.ctx, state_heads=state_heads)),
+            "logits_bytes": logits_bytes(B),
             "avg_launch_ms": round(gpu_ms, 5),
         },
     }
+    # the same step without lm_head and sampling (what a captured model forward of the engine holds)
+    runner.with_logits = False
+    runner.capture()
+    _, layers_ms = timed_steps(runner, args.warmup, args.steps)
+    line["layers_only_ms_per_step"] = round(layers_ms, 4)
+    runner.with_logits = True
     if not args.no_side:
         line["kernels"] = kernel_table(runner, args.quant)
         if not args.no_prefill:
@@ -623,7 +647,7 @@ def main():
             rq = DecodeRunner(mq, B, args.ctx, total + 8, dev)
             rq.capture()
             el, ms = timed_steps(rq, args.warmup, args.steps)
-            sb = linear_weight_bytes(q) + attention_bytes(B, args.ctx, state_heads=state_heads)
+            sb = linear_weight_bytes(q) + attention_bytes(B, args.ctx, state_heads=state_heads) + logits_bytes(B)
             line["model_decode"][q] = {"ms_per_step": round(ms, 4), "tokens_per_s": round(B / (ms * 1e-3), 1),
                                        "hbm_frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernels": kernel_table(rq, q)}
             del rq, mq

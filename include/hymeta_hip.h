@@ -632,6 +632,21 @@ int hymeta_bf16_gemm_split_k(int32_t M, int32_t K, int32_t N);
 size_t hymeta_bf16_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream);
 
+/* Logits of a bf16 lm_head: out fp32 [M, N] (out_stride_m in fp32 elements, a multiple of 4) = x weight^T (+ bias)
+ * with fp32 accumulation and no rounding of the result; workspace and split_k unused.  M <= 64, K a multiple of 64 and
+ * at least 256, N a multiple of 64; other shapes HYMETA_ERR_UNSUPPORTED.
+ * Replaces lm_head.float() applied to hidden_states.float() in compute_logits
+ * (vllm_hymeta/model_for_7B/modeling_gla_swa.py:548,579-583, vllm_hymeta/models/modeling_hymeta.py:1429,1462-1466):
+ * a checkpoint's bf16 lm_head widened to fp32 holds the same values, so the product of the bf16 operands accumulated
+ * in fp32 is that fp32 GEMM up to the order of the sums, at half the weight bytes. */
+int hymeta_bf16_gemm_f32out(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream);
+
+/* Greedy sampling of a decode step: out[m] = index of the largest of logits[m, 0 .. N) (fp32 rows stride_m elements
+ * apart; the lowest index among equals), as one launch that a captured decode step can hold.  N and stride_m
+ * multiples of 4.  Stands in for the argmax of vLLM's sampler on greedy requests (the reference hands its logits to
+ * that sampler: vllm_hymeta/model_for_7B/modeling_gla_swa.py:579-590). */
+int hymeta_argmax_rows(const float* logits, int64_t stride_m, int32_t M, int32_t N, int64_t* out, hymeta_stream_t stream);
+
 /* The gate/up projection of a gated MLP with its activation in the GEMM's epilogue, for decode-sized batches:
  * weight = [gate rows | up rows] (N rows in all, the fused gate_up_proj), out bf16 [M, N / 2] =
  * silu(x gate^T) * (x up^T), both factors rounded to bf16 before the product -- the arithmetic of

@@ -186,3 +186,30 @@ def test_qkv_projection_finished_by_rope_from_its_partial_sums(kind):
     got = hip_ops.rope_from_partials(part, pos, table, H, Hkv)
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 512, 1024), (20, 3584, 4096), (64, 3584, 151936), (130, 1024, 2048 + 64)])
+def test_bf16_logits_are_the_fp32_product_of_the_widened_operands(M, K, N):
+    """lm_head kept in bf16: x W^T with fp32 accumulation and an unrounded fp32 result, against the fp64 product of the
+    same bf16 values (what lm_head.float() on hidden_states.float() computes, up to fp32 summation error) -- also more
+    than 64 rows (64 at a time) and the 7B vocabulary; then the greedy token of each row."""
+    from vllm_hymeta import hip_ops
+
+    g_ = gen(41)
+    x = randn_bf16(g_, M, K).cuda()
+    w = randn_bf16(g_, N, K, scale=K ** -0.5).cuda()
+    got = hip_ops.bf16_logits(x, w)
+    assert got.dtype == torch.float32 and got.shape == (M, N)
+    rows = slice(0, M) if N <= 8192 else slice(0, 4)                  # the fp64 product of the large case on a few rows
+    ref = x[rows].double() @ w.double().t()
+    err = (got[rows].double() - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item(), err
+    # fp32 tolerance: bf16-rounded logits would be off by 2^-9 relative, far outside it
+    tok = hip_ops.argmax_rows(got)
+    torch.cuda.synchronize()
+    assert torch.equal(tok, got.argmax(-1))
+    ties = torch.zeros(3, 1024, device="cuda")
+    ties[0, 700] = ties[0, 9] = 5.0
+    ties[1, :] = -1.0
+    ties[2, 1023] = 1.0
+    assert hip_ops.argmax_rows(ties).tolist() == [9, 0, 1023]

@@ -227,6 +227,28 @@ extern "C" int hymeta_bf16_gemm_deferred(const hymeta_bf16_gemm_args* args, hyme
   return bf16_gemm_impl(args, stream, partials);
 }
 
+// fp32 result of bf16 operands, unrounded: the logits of a bf16 lm_head.  The streaming kernel without K slices only.
+extern "C" int hymeta_bf16_gemm_f32out(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream) {
+  using namespace hymeta;
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_bf16_gemm_args& a = *args;
+  if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.M == 0) return HYMETA_OK;
+  if (!a.x || !a.weight || !a.out) return HYMETA_ERR_INVALID_ARG;
+  if ((a.x_stride_m | a.w_stride_n) % 8 != 0 || a.out_stride_m % 4 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.weight) | reinterpret_cast<uintptr_t>(a.out) |
+       reinterpret_cast<uintptr_t>(a.bias)) % 16 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  StreamPlan plan;
+  if (a.K > (1 << 28) || !stream_gemm_plan(a.M, a.K * 2, a.N, false, &plan) || plan.splits != 1) return HYMETA_ERR_UNSUPPORTED;
+  StreamArgs sa = {};
+  sa.x = static_cast<const char*>(a.x), sa.w = static_cast<const char*>(a.weight);
+  sa.bias = static_cast<const uint16_t*>(a.bias), sa.out = static_cast<uint16_t*>(a.out);
+  sa.M = a.M, sa.N = a.N, sa.k_bytes = a.K * 2, sa.out_f32 = 1;
+  sa.x_stride_bytes = a.x_stride_m * 2, sa.w_stride_bytes = a.w_stride_n * 2, sa.out_stride = a.out_stride_m;
+  return stream_gemm_launch<false>(sa, plan, begin_launches(stream));
+}
+
 // Gate/up projection with the activation in the epilogue: out [M, N / 2] = silu(x gate^T) * (x up^T), weight = [gate rows |
 // up rows].  Only the shapes the streaming kernel takes whole (no K slices); others are HYMETA_ERR_UNSUPPORTED and the
 // caller runs hymeta_bf16_gemm + hymeta_silu_and_mul, which give the same bits.

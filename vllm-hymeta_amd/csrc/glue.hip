@@ -476,3 +476,43 @@ extern "C" int hymeta_add_rmsnorm_int8(const hymeta_add_rmsnorm_args* args, cons
   if (partials != nullptr && partials->splits > 0) return add_rmsnorm_partials_impl(args, partials, xq, x_scale, stream);
   return add_rmsnorm_impl(args, xq, x_scale, stream);
 }
+
+namespace hymeta {
+
+// Greedy sampling: index of the largest logit of each row (the lowest index among equals).  One workgroup per row;
+// a thread scans 4 columns at a time, the workgroup's 256 candidates are merged through LDS.
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* logits, int64_t stride, int n, int64_t* out) {
+  __shared__ float s_val[256];
+  __shared__ int s_idx[256];
+  const float* row = logits + static_cast<int64_t>(blockIdx.x) * stride;
+  float best = -INFINITY;
+  int best_i = 0x7fffffff;
+  for (int c = 4 * threadIdx.x; c < n; c += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (v[e] > best) best = v[e], best_i = c + e;       // ascending columns: the first of equals stays
+  }
+  s_val[threadIdx.x] = best, s_idx[threadIdx.x] = best_i;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (static_cast<int>(threadIdx.x) < off) {
+      const float v = s_val[threadIdx.x + off];
+      const int i = s_idx[threadIdx.x + off];
+      if (v > s_val[threadIdx.x] || (v == s_val[threadIdx.x] && i < s_idx[threadIdx.x])) s_val[threadIdx.x] = v, s_idx[threadIdx.x] = i;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = s_idx[0] == 0x7fffffff ? 0 : s_idx[0];
+}
+
+}  // namespace hymeta
+
+extern "C" int hymeta_argmax_rows(const float* logits, int64_t stride_m, int32_t M, int32_t N, int64_t* out, hymeta_stream_t stream) {
+  if (M < 0 || N <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (M == 0) return HYMETA_OK;
+  if (!logits || !out) return HYMETA_ERR_INVALID_ARG;
+  if (N % 4 != 0 || stride_m % 4 != 0 || reinterpret_cast<uintptr_t>(logits) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(hymeta::argmax_rows_kernel, dim3(M), dim3(256), 0, hymeta::begin_launches(stream), logits, stride_m, N, out);
+  return hymeta::launch_status();
+}

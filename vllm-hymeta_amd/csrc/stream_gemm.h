@@ -16,6 +16,7 @@ struct StreamArgs {
   int M, N;
   int k_bytes;            // bytes of one row of x / W that hold K (a multiple of 128)
   int64_t x_stride_bytes, w_stride_bytes, out_stride;
+  int out_f32;            // 1: out is fp32 [M, N] (out_stride in fp32 elements), the sums are stored unrounded; no K slices
   int gated;              // 1: W = [gate rows | up rows] (N / 2 each), out [M, N / 2] = bf16(silu(bf16(x gate^T)) * bf16(x up^T));
                           // no bias, no K slices
   int tiles, chunks, splits;    // filled from the plan

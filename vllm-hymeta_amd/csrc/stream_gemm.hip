@@ -267,6 +267,10 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& a, char* smem, con
       } else {
         y = sum + b;
       }
+      if (a.out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + static_cast<int64_t>(row) * a.out_stride + col) = y;
+        continue;
+      }
       const u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
       *reinterpret_cast<u32x2*>(a.out + static_cast<int64_t>(row) * a.out_stride + col) = o;
     }
@@ -418,6 +422,7 @@ int stream_gemm_launch(StreamArgs a, const StreamPlan& p, hipStream_t s, bool de
   a.tiles = p.tiles, a.chunks = p.chunks, a.splits = p.splits;
   if (a.k_bytes <= 0 || (a.k_bytes + kChunkBytes - 1) / kChunkBytes != p.chunks) return HYMETA_ERR_INVALID_ARG;
   if (a.gated && (p.splits != 1 || a.bias != nullptr || a.N % 128 != 0)) return HYMETA_ERR_INVALID_ARG;
+  if (a.out_f32 && (p.splits != 1 || a.gated)) return HYMETA_ERR_INVALID_ARG;
   const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
 #define HYMETA_STREAM_CASE(MT_, NF_) \
   if (mt == MT_ && p.nf == NF_) {                                                                   \

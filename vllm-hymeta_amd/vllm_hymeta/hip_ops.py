@@ -928,6 +928,47 @@ def bf16_gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor
     return out
 
 
+def logits_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Shapes ``bf16_logits`` takes (any number of rows: they go 64 at a time)."""
+    return (x.dim() == 2 and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.is_cuda
+            and x.stride(1) == 1 and weight.stride(1) == 1 and weight.shape[1] % 64 == 0 and weight.shape[1] >= 256
+            and weight.shape[0] % 64 == 0 and x.stride(0) % 8 == 0 and weight.stride(0) % 8 == 0)
+
+
+def bf16_logits(x: torch.Tensor, weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x bf16 [M, K] @ weight bf16 [N, K]^T -> fp32 [M, N], fp32 accumulation, result not rounded: the logits of a bf16
+    lm_head (the fp32 GEMM of the operands widened to fp32, up to the order of the sums).  Rows go through the
+    weight-streaming kernel 64 at a time."""
+    _dev(x, weight, out)
+    M, K = x.shape
+    N = weight.shape[0]
+    _require(logits_supported(x, weight) and weight.shape == (N, K), "bf16_logits: x bf16 [M, K], weight bf16 [N, K], K % 64 == 0, N % 64 == 0")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    _require(out.shape == (M, N) and out.dtype == torch.float32 and out.stride(1) == 1 and out.stride(0) % 4 == 0, "out must be fp32 [M, N]")
+    lib = _C.load()
+    for r0 in range(0, M, BF16_GEMM_MAX_ROWS):
+        xs, os_ = x[r0:r0 + BF16_GEMM_MAX_ROWS], out[r0:r0 + BF16_GEMM_MAX_ROWS]
+        a = _C.Bf16GemmArgs()
+        a.x, a.weight, a.out = _p(xs), _p(weight), _p(os_)
+        a.M, a.K, a.N = xs.shape[0], K, N
+        a.x_stride_m, a.w_stride_n, a.out_stride_m = x.stride(0), weight.stride(0), out.stride(0)
+        _C.check(lib.hymeta_bf16_gemm_f32out(C.byref(a), _stream(x)), "hymeta_bf16_gemm_f32out")
+    return out
+
+
+def argmax_rows(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Greedy sampling: int64 [M] indices of the largest fp32 logit of each row (the lowest index among equals)."""
+    _dev(logits, out)
+    _require(logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1, "logits must be row-contiguous fp32 [M, N]")
+    M, N = logits.shape
+    if out is None:
+        out = torch.empty(M, dtype=torch.int64, device=logits.device)
+    _require(out.shape == (M,) and out.dtype == torch.int64 and out.is_contiguous(), "out must be contiguous int64 [M]")
+    _C.check(_C.load().hymeta_argmax_rows(_p(logits), logits.stride(0), M, N, _p(out), _stream(logits)), "hymeta_argmax_rows")
+    return out
+
+
 def w8a8_gemm(x: torch.Tensor, qweight: torch.Tensor, w_scale: torch.Tensor,
               bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, defer: bool = False):
     """x bf16 [M,K] -> dynamic per-token int8; qweight int8 [N,K]; w_scale fp32 [N] -> bf16 [M,N].

@@ -26,6 +26,7 @@ import torch
 from .. import loader
 from .._compat import HasInnerState, IntermediateTensors, IsHybrid, SupportsPP, SupportsV0Only, model_build_args
 from ..linear import HymetaLinear
+from ..lm_head import LmHeadMixin, lm_head_logits
 from ..models.attention import bind_kv_cache, current_attn_metadata, forward_context, standalone_prefix
 from ..models.block import GLAswaBlock, HymetaRMSNorm
 from ..models.moe import HymetaMLP
@@ -125,7 +126,7 @@ class GLAswaModel(torch.nn.Module):
         return self.norm(hidden_states, residual)[0] if residual is not None else self.norm(hidden_states)
 
 
-class GLAswaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only, SupportsPP):
+class GLAswaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only, SupportsPP):
     packed_modules_mapping = {
         "qkv_proj": ["q_proj", "k_proj", "v_proj"],
         "gate_up_proj": ["gate_proj", "up_proj"],
@@ -151,7 +152,7 @@ class GLAswaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only
         self.unpadded_vocab_size = config.vocab_size
         self.model = GLAswaModel(config, max_num_seqs=max_num_seqs, quant=quant, tp_group=tp_group, device=device,
                                  state_per_kv_head=state_per_kv_head, cache_config=cache_config, prefix=model_prefix)
-        self.lm_head: Optional[torch.Tensor] = None             # [vocab, hidden] fp32 (the reference's lm_head.float())
+        self.lm_head = None             # [vocab, hidden]; reads as fp32 (the reference's lm_head.float()), see lm_head.py
         self.kv_cache = [torch.tensor([]) for _ in config.attn_layers]
 
     def copy_inputs_before_cuda_graphs(self, input_buffers, **kwargs):
@@ -172,7 +173,7 @@ class GLAswaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only
         idx = getattr(sampling_metadata, "selected_token_indices", None)
         if idx is not None:
             hidden_states = hidden_states.index_select(0, idx)
-        return torch.nn.functional.linear(hidden_states.float(), self.lm_head)
+        return lm_head_logits(hidden_states, self._lm_head)
 
     def make_empty_intermediate_tensors(self, batch_size: int, dtype: torch.dtype, device: torch.device) -> IntermediateTensors:
         return IntermediateTensors({
@@ -229,7 +230,7 @@ class GLAswaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only
 
         m.embeddings = lin("model.embeddings")["weight"].to(torch.bfloat16)
         m.norm = HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain["model.norm.weight"])
-        self.lm_head = lin("lm_head")["weight"].float()
+        self.lm_head = lin("lm_head")["weight"]
         m.layers = torch.nn.ModuleList()
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}"

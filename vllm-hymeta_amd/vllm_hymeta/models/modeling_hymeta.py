@@ -29,6 +29,7 @@ import torch
 from .. import loader
 from .._compat import HasInnerState, IntermediateTensors, IsHybrid, SupportsPP, SupportsV0Only, model_build_args
 from ..linear import HymetaLinear
+from ..lm_head import LmHeadMixin, lm_head_logits
 from ..model_for_7B.window_attention import rope_cos_sin_cache
 from ..parallel import shard_heads, tp_rank_and_size
 from .attention import MetaAttention, bind_kv_cache, current_attn_metadata, forward_context, standalone_prefix
@@ -165,7 +166,7 @@ class HymetaModel(torch.nn.Module):
         return self.norm(hidden_states, residual)[0] if residual is not None else self.norm(hidden_states)
 
 
-class HymetaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only, SupportsPP):
+class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only, SupportsPP):
     packed_modules_mapping = {
         "qkv_proj": ["q_proj", "k_proj", "v_proj"],
         "gate_up_proj": ["gate_proj", "up_proj"],
@@ -196,7 +197,7 @@ class HymetaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only
         self.unpadded_vocab_size = config.vocab_size
         self.model = HymetaModel(config, max_num_seqs=max_num_seqs, quant=quant, tp_group=tp_group, device=device,
                                  cache_config=cache_config, prefix=model_prefix)
-        self.lm_head: Optional[torch.Tensor] = None             # [vocab, hidden] fp32 (:1429)
+        self.lm_head = None             # [vocab, hidden]; reads as fp32 (:1429), see lm_head.py
         self.kv_cache = [torch.tensor([]) for _ in range(config.num_hidden_layers)]
 
     def copy_inputs_before_cuda_graphs(self, input_buffers, **kwargs):
@@ -217,7 +218,7 @@ class HymetaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only
         idx = getattr(sampling_metadata, "selected_token_indices", None)
         if idx is not None:
             hidden_states = hidden_states.index_select(0, idx)
-        return torch.nn.functional.linear(hidden_states.float(), self.lm_head)
+        return lm_head_logits(hidden_states, self._lm_head)
 
     def make_empty_intermediate_tensors(self, batch_size: int, dtype: torch.dtype, device: torch.device) -> IntermediateTensors:
         """Reference ``:1471-1483``."""
@@ -288,7 +289,7 @@ class HymetaForCausalLM(torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only
 
         m.embeddings = plain["model.embeddings.weight"].to(torch.bfloat16)
         m.norm = HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain["model.norm.weight"])
-        self.lm_head = plain["lm_head.weight"].float()
+        self.lm_head = plain["lm_head.weight"]
         if m.use_lower_bound:
             lb = plain["model.lower_bounds"].float().softmax(0)
             m.lower_bounds = (lb.cumsum(0) - lb[0]).contiguous()
