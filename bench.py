@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="skip the 32k TTFT / single-request latency side measurements")
     ap.add_argument("--prefill-ctx", type=int, default=32768)
+    ap.add_argument("--no-layers-only", action="store_true",
+                    help="skip the second timing of the step without lm_head and sampling (profiling runs: every step the same)")
     ap.add_argument("--no-side", action="store_true",
                     help="skip every side measurement (quantised models, kernel table, 70B shard): the timed region only")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs")
@@ -358,14 +360,19 @@ class PrefillRunner:
         self.capture_inputs = (cache, idx)
 
     def prefill(self):
-        return self.model(self.ids, self.pos, attn_metadata=self.md, kv_caches=self.kv,
-                          seqlen_agnostic_capture_inputs=self.capture_inputs)
+        """The prompt through the model, then the first generated token: the last position's logits and their argmax."""
+        from vllm_hymeta import hip_ops
+
+        h = self.model(self.ids, self.pos, attn_metadata=self.md, kv_caches=self.kv,
+                       seqlen_agnostic_capture_inputs=self.capture_inputs)
+        return hip_ops.argmax_rows(self.model.compute_logits(h[-1:]))
 
 
 def prefill_and_latency(model, dev, L, new_tokens=128, runs=5):
     """The reference's latency protocol (hf_7B_model/speed_7B.py:196-221, bench/speed_vllm.py:41-53): one request =
     an L-token prompt + 128 generated tokens, batch 1.  TTFT = the prompt through all 28 layers (projections and MLP
-    included, library GEMMs at this row count), p50 of ``runs``; decode = 128 replays of the batch-1 step graph."""
+    included, library GEMMs at this row count) and the first token's logits + argmax, p50 of ``runs``; decode = 128
+    replays of the batch-1 step graph (layers, logits, greedy token)."""
     pre = PrefillRunner(model, L, new_tokens, dev)
     pre.prefill()
     torch.cuda.synchronize()
@@ -627,11 +634,12 @@ def main():
         },
     }
     # the same step without lm_head and sampling (what a captured model forward of the engine holds)
-    runner.with_logits = False
-    runner.capture()
-    _, layers_ms = timed_steps(runner, args.warmup, args.steps)
-    line["layers_only_ms_per_step"] = round(layers_ms, 4)
-    runner.with_logits = True
+    if not args.no_layers_only:
+        runner.with_logits = False
+        runner.capture()
+        _, layers_ms = timed_steps(runner, args.warmup, args.steps)
+        line["layers_only_ms_per_step"] = round(layers_ms, 4)
+        runner.with_logits = True
     if not args.no_side:
         line["kernels"] = kernel_table(runner, args.quant)
         if not args.no_prefill:

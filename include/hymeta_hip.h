@@ -642,10 +642,14 @@ int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream);
 int hymeta_bf16_gemm_f32out(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream);
 
 /* Greedy sampling of a decode step: out[m] = index of the largest of logits[m, 0 .. N) (fp32 rows stride_m elements
- * apart; the lowest index among equals), as one launch that a captured decode step can hold.  N and stride_m
- * multiples of 4.  Stands in for the argmax of vLLM's sampler on greedy requests (the reference hands its logits to
- * that sampler: vllm_hymeta/model_for_7B/modeling_gla_swa.py:579-590). */
-int hymeta_argmax_rows(const float* logits, int64_t stride_m, int32_t M, int32_t N, int64_t* out, hymeta_stream_t stream);
+ * apart; the lowest index among equals), in launches that a captured decode step can hold.  N and stride_m
+ * multiples of 4.  workspace (hymeta_argmax_rows_workspace_bytes(M) bytes, or NULL) lets a wide row be scanned by 32
+ * workgroups with a second small launch picking among them; without it one workgroup scans a row.
+ * Stands in for the argmax of vLLM's sampler on greedy requests (the reference hands its logits to that sampler:
+ * vllm_hymeta/model_for_7B/modeling_gla_swa.py:579-590). */
+size_t hymeta_argmax_rows_workspace_bytes(int32_t M);
+int hymeta_argmax_rows(const float* logits, int64_t stride_m, int32_t M, int32_t N, int64_t* out, void* workspace,
+                       size_t workspace_bytes, hymeta_stream_t stream);
 
 /* The gate/up projection of a gated MLP with its activation in the GEMM's epilogue, for decode-sized batches:
  * weight = [gate rows | up rows] (N rows in all, the fused gate_up_proj), out bf16 [M, N / 2] =

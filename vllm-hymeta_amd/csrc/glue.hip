@@ -479,15 +479,20 @@ extern "C" int hymeta_add_rmsnorm_int8(const hymeta_add_rmsnorm_args* args, cons
 
 namespace hymeta {
 
-// Greedy sampling: index of the largest logit of each row (the lowest index among equals).  One workgroup per row;
-// a thread scans 4 columns at a time, the workgroup's 256 candidates are merged through LDS.
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* logits, int64_t stride, int n, int64_t* out) {
+// Greedy sampling: index of the largest logit of each row (the lowest index among equals).  A workgroup scans one of
+// ``segs`` column segments of a row, 4 columns per thread at a time, and merges its 256 candidates through LDS; with
+// more than one segment the candidates (value, index) go to ``part`` [M][segs] and a second launch picks among them.
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* logits, int64_t stride, int n, int segs, float* part_val,
+                                                          int* part_idx, int64_t* out) {
   __shared__ float s_val[256];
   __shared__ int s_idx[256];
-  const float* row = logits + static_cast<int64_t>(blockIdx.x) * stride;
+  const int m = blockIdx.x / segs, seg = blockIdx.x % segs;
+  const float* row = logits + static_cast<int64_t>(m) * stride;
+  const int per = ((n / 4 + segs - 1) / segs) * 4;            // columns per segment, a multiple of 4
+  const int lo = seg * per, hi = min(n, lo + per);
   float best = -INFINITY;
   int best_i = 0x7fffffff;
-  for (int c = 4 * threadIdx.x; c < n; c += 1024) {
+  for (int c = lo + 4 * threadIdx.x; c < hi; c += 1024) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -503,16 +508,46 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* logits, i
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = s_idx[0] == 0x7fffffff ? 0 : s_idx[0];
+  if (threadIdx.x == 0) {
+    if (segs == 1) out[m] = s_idx[0] == 0x7fffffff ? 0 : s_idx[0];
+    else part_val[blockIdx.x] = s_val[0], part_idx[blockIdx.x] = s_idx[0];
+  }
+}
+
+// One wave per row picks among the segments' candidates (segs <= 64).
+__global__ __launch_bounds__(64) void argmax_pick_kernel(const float* part_val, const int* part_idx, int segs, int64_t* out) {
+  const int m = blockIdx.x, lane = threadIdx.x;
+  float v = lane < segs ? part_val[m * segs + lane] : -INFINITY;
+  int i = lane < segs ? part_idx[m * segs + lane] : 0x7fffffff;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const float ov = __shfl_xor(v, off);
+    const int oi = __shfl_xor(i, off);
+    if (ov > v || (ov == v && oi < i)) v = ov, i = oi;
+  }
+  if (lane == 0) out[m] = i == 0x7fffffff ? 0 : i;
 }
 
 }  // namespace hymeta
 
-extern "C" int hymeta_argmax_rows(const float* logits, int64_t stride_m, int32_t M, int32_t N, int64_t* out, hymeta_stream_t stream) {
+extern "C" size_t hymeta_argmax_rows_workspace_bytes(int32_t M) { return static_cast<size_t>(M > 0 ? M : 0) * 32 * 8; }
+
+extern "C" int hymeta_argmax_rows(const float* logits, int64_t stride_m, int32_t M, int32_t N, int64_t* out, void* workspace,
+                                  size_t workspace_bytes, hymeta_stream_t stream) {
   if (M < 0 || N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (M == 0) return HYMETA_OK;
   if (!logits || !out) return HYMETA_ERR_INVALID_ARG;
   if (N % 4 != 0 || stride_m % 4 != 0 || reinterpret_cast<uintptr_t>(logits) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(hymeta::argmax_rows_kernel, dim3(M), dim3(256), 0, hymeta::begin_launches(stream), logits, stride_m, N, out);
+  // few rows of a wide vocabulary: 32 workgroups per row, so that the whole chip reads
+  const int segs = workspace != nullptr && workspace_bytes >= hymeta_argmax_rows_workspace_bytes(M) && N >= 32 * 1024 && M <= 1024 &&
+                           reinterpret_cast<uintptr_t>(workspace) % 4 == 0 ? 32 : 1;
+  float* part_val = static_cast<float*>(workspace);
+  int* part_idx = reinterpret_cast<int*>(part_val + static_cast<size_t>(M) * 32);
+  hipStream_t s = hymeta::begin_launches(stream);
+  hipLaunchKernelGGL(hymeta::argmax_rows_kernel, dim3(M * segs), dim3(256), 0, s, logits, stride_m, N, segs, part_val, part_idx, out);
+  if (segs > 1) {
+    if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+    hipLaunchKernelGGL(hymeta::argmax_pick_kernel, dim3(M), dim3(64), 0, s, part_val, part_idx, segs, out);
+  }
   return hymeta::launch_status();
 }

@@ -965,7 +965,10 @@ def argmax_rows(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> tor
     if out is None:
         out = torch.empty(M, dtype=torch.int64, device=logits.device)
     _require(out.shape == (M,) and out.dtype == torch.int64 and out.is_contiguous(), "out must be contiguous int64 [M]")
-    _C.check(_C.load().hymeta_argmax_rows(_p(logits), logits.stride(0), M, N, _p(out), _stream(logits)), "hymeta_argmax_rows")
+    lib = _C.load()
+    ws = _workspace(logits.device, int(lib.hymeta_argmax_rows_workspace_bytes(M)), "argmax_rows") if M > 0 else None
+    _C.check(lib.hymeta_argmax_rows(_p(logits), logits.stride(0), M, N, _p(out), _p(ws), ws.numel() if ws is not None else 0,
+                                    _stream(logits)), "hymeta_argmax_rows")
     return out
 
 
