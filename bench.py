@@ -645,9 +645,21 @@ def main():
         if not args.no_prefill:
             line["prefill"], line["latency_b1"] = prefill_and_latency(model, dev, args.prefill_ctx)
             line["ttft_ms_p50"] = line["prefill"]["ttft_ms_p50"]
-        del runner, model
+        del runner
         torch.cuda.empty_cache()
-        line["model_decode"] = {args.quant: {"ms_per_step": line["ms_per_step"], "tokens_per_s": line["value"]}}
+        b1_main = None if args.no_prefill else DecodeRunner(model, 1, args.prefill_ctx, total + 8, dev, seed=7)
+        if b1_main is not None:
+            b1_main.capture()
+            b1_main = round(timed_steps(b1_main, args.warmup, args.steps)[1], 4)
+        del model
+        torch.cuda.empty_cache()
+        def decode_b1(m):
+            """ms per generated token of ONE sequence at the prefill context (logits and sampling included)."""
+            r1 = DecodeRunner(m, 1, args.prefill_ctx, total + 8, dev, seed=7)
+            r1.capture()
+            return round(timed_steps(r1, args.warmup, args.steps)[1], 4)
+
+        line["model_decode"] = {args.quant: {"ms_per_step": line["ms_per_step"], "tokens_per_s": line["value"], "batch1_ms_per_token": b1_main}}
         for q in ("bf16", "gptq4", "w8a8"):
             if q == args.quant:
                 continue
@@ -658,7 +670,10 @@ def main():
             sb = linear_weight_bytes(q) + attention_bytes(B, args.ctx, state_heads=state_heads) + logits_bytes(B)
             line["model_decode"][q] = {"ms_per_step": round(ms, 4), "tokens_per_s": round(B / (ms * 1e-3), 1),
                                        "hbm_frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernels": kernel_table(rq, q)}
-            del rq, mq
+            del rq
+            torch.cuda.empty_cache()
+            line["model_decode"][q]["batch1_ms_per_token"] = decode_b1(mq)
+            del mq
             torch.cuda.empty_cache()
         line["shard_70b_tp4"] = shard70b_side_measurement(dev)
     if not args.no_cpu_baseline:

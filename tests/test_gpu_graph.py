@@ -129,7 +129,7 @@ def test_whole_model_decode_step_replays_from_a_graph(quant):
                 s = w.abs().amax(1, keepdim=True).clamp_min(1e-8) / 127
                 ckpt[name] = torch.clamp(torch.round(w / s), -127, 127).to(torch.int8)
                 ckpt[name + "_scale"] = s.float()
-    B, bs, ctx = 20, 16, 70          # 17 rows and more: the W8A8 linears take the streaming kernel too
+    B, bs, ctx = 20, 16, 70          # K-sliced streaming linears (bf16 and W8A8): the deferred sums are in the graph
     model = GLAswaForCausalLM(cfg, max_num_seqs=B, device=dev)
     model.load_weights(ckpt.items())
     lin = model.model.layers[0].mlp.down_proj

@@ -21,7 +21,7 @@ for M in ROWS:
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)
         # cold weights, as inside a model step: rotate over copies that together exceed the 256 MB
         # last-level cache several times
-        copies = max(2, min(40, int(1.2e9 // (N * K * 2))))
+        copies = int(os.environ.get("COPIES", 0)) or max(2, min(40, int(1.2e9 // (N * K * 2))))
         ws = [(torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(copies)]
         bias = torch.randn(N, device=dev).to(torch.bfloat16)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)

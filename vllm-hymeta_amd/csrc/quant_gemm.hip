@@ -1084,9 +1084,12 @@ static int w8a8_gemm_impl(const hymeta_w8a8_gemm_args* args, hymeta_stream_t str
        reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.xq) | reinterpret_cast<uintptr_t>(a.w_scale) |
        reinterpret_cast<uintptr_t>(a.workspace)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
-  // 17 rows and more: the streaming kernel (activations shared through LDS, whole-line weight loads) when the library
-  // chooses the decomposition; up to 16 rows the 64-column kernel below already streams the weights at 4.5-4.8 TB/s
-  static const int stream_from = [] { const char* e = getenv("HYMETA_W8A8_STREAM_FROM"); return e ? atoi(e) : 17; }();
+  // The streaming kernel (activations shared through LDS, whole-line weight loads) takes every shape it covers when the
+  // library chooses the decomposition -- with one workgroup per compute unit it is ahead of the 64-column kernel below
+  // at every row count (7B shapes at 1 / 16 rows, us: qkv 11.3 / 12.5 against 14.5 / 16.4, o 10.3 / 11.3 against
+  // 13.6 / 15.5, gate_up 27.9 / 28.8 against 32.4 / 34.0, down 24.1 / 26.1 against 38.3 / 39.9).
+  // HYMETA_W8A8_STREAM_FROM = first row count that goes there.
+  static const int stream_from = [] { const char* e = getenv("HYMETA_W8A8_STREAM_FROM"); return e ? atoi(e) : 1; }();
   if (a.split_k <= 0 && a.M >= stream_from) {
     StreamPlan plan;
     const bool have_ws = a.workspace != nullptr;
