@@ -391,13 +391,34 @@ __global__ __launch_bounds__(128) void paged_decode_merge_kernel(hymeta_paged_de
   const int64_t unit0 = static_cast<int64_t>(blockIdx.x) * num_splits;
   const float* ml = wo + static_cast<int64_t>(a.batch) * a.num_heads * num_splits * D + unit0 * 2;
   float m_tot = -INFINITY;
-  for (int s = 0; s < num_splits; ++s) m_tot = fmaxf(m_tot, ml[2 * s]);
   float acc = 0.f, l_tot = 0.f;
-  for (int s = 0; s < num_splits; ++s) {
-    const float ms = ml[2 * s];
-    const float f = ms == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms - m_tot);
-    l_tot += f * ml[2 * s + 1];
-    acc += f * wo[(unit0 + s) * D + d];
+  if (num_splits <= 16) {
+    // every load of every split in flight at once (a loop over the splits waits one cache round trip per split, twice);
+    // the same maxima, factors and sums in the same order as the loops below
+    float ms[16], ls[16], os[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int s = min(i, num_splits - 1);
+      ms[i] = ml[2 * s], ls[i] = ml[2 * s + 1], os[i] = wo[(unit0 + s) * D + d];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < num_splits) m_tot = fmaxf(m_tot, ms[i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < num_splits) {
+        const float f = ms[i] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms[i] - m_tot);
+        l_tot += f * ls[i];
+        acc += f * os[i];
+      }
+  } else {
+    for (int s = 0; s < num_splits; ++s) m_tot = fmaxf(m_tot, ml[2 * s]);
+    for (int s = 0; s < num_splits; ++s) {
+      const float ms = ml[2 * s];
+      const float f = ms == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms - m_tot);
+      l_tot += f * ml[2 * s + 1];
+      acc += f * wo[(unit0 + s) * D + d];
+    }
   }
   const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
   reinterpret_cast<uint16_t*>(a.out)[b * a.out_stride_b + static_cast<int64_t>(head) * a.out_stride_h + d] = f2bf(acc * inv);
