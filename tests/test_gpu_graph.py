@@ -109,7 +109,8 @@ def test_decode_step_replays_from_a_graph():
 def test_whole_model_decode_step_replays_from_a_graph(quant):
     """The 7B model class's decode step (streaming linears with K slices summed by the norms, the gate folded into qkv and
     gla_decode, int8 rows written by the norms for W8A8) captured after an eager warm-up and replayed three times with
-    eager work and new inputs between the replays: every replay equals the eager step on the same inputs and states."""
+    eager work and new inputs between the replays: every replay equals the eager step on the same inputs and states,
+    the fp32 logits and the greedy tokens included."""
     from test_gpu_layers import _md
     from test_gpu_model_7b import _checkpoint
     from vllm_hymeta import hip_ops
@@ -154,8 +155,15 @@ def test_whole_model_decode_step_replays_from_a_graph(quant):
         seq_lens.copy_((p + 1).to(torch.int32))
         slots.copy_(torch.gather(bt.long(), 1, (p // bs).unsqueeze(1)).squeeze(1) * bs + p % bs)
 
+    tok = torch.zeros(B, dtype=torch.int64, device=dev)
+    logits_buf = torch.zeros(B, cfg.vocab_size, dtype=torch.float32, device=dev)
+
     def run():
-        return model(ids, pos, attn_metadata=md, kv_caches=kv, seqlen_agnostic_capture_inputs=(cache, idx))
+        # the step as a greedy decode loop runs it: layers, fp32 logits of the bf16 lm_head, their argmax
+        h = model(ids, pos, attn_metadata=md, kv_caches=kv, seqlen_agnostic_capture_inputs=(cache, idx))
+        logits_buf.copy_(model.compute_logits(h))
+        hip_ops.argmax_rows(logits_buf, out=tok)
+        return h
 
     state0 = (torch.randn(cache[0].shape, device=dev) * 0.1).to(torch.bfloat16)
     kv0 = [k.clone() for k in kv]
@@ -179,10 +187,13 @@ def test_whole_model_decode_step_replays_from_a_graph(quant):
         set_inputs(step)
         reset()
         eager = run().clone()
+        tok_e, logits_e = tok.clone(), logits_buf.clone()
+        assert torch.equal(tok_e, logits_e.argmax(-1))
         state_e, kv_e = cache[0].clone(), [k.clone() for k in kv]
         lin(randn_bf16(g_, B, 2048).cuda())          # eager work of the same ops between replays
         reset()
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, eager), f"replay {step}: hidden states"
+        assert torch.equal(logits_buf, logits_e) and torch.equal(tok, tok_e), f"replay {step}: logits / greedy tokens"
         assert torch.equal(cache[0], state_e) and all(torch.equal(a, b) for a, b in zip(kv, kv_e)), f"replay {step}: caches"
