@@ -199,6 +199,7 @@ class DecodeRunner:
         self.graph = None
         self.out = None
         self.with_logits = True
+        self.sampler = None
 
     def _refresh_slots(self):
         blk = torch.gather(self.block_tables.long(), 1, (self.positions // BLOCK).unsqueeze(1)).squeeze(1)
@@ -218,7 +219,10 @@ class DecodeRunner:
         h = self.model(self.input_ids, self.positions, attn_metadata=self.md, kv_caches=self.kv,
                        seqlen_agnostic_capture_inputs=self.capture_inputs)
         if self.with_logits:
-            hip_ops.argmax_rows(self.model.compute_logits(h), out=self.input_ids)
+            if self.sampler is not None:
+                self.sampler(h, self.input_ids)           # tensor-parallel mode: vocabulary-parallel logits
+            else:
+                hip_ops.argmax_rows(self.model.compute_logits(h), out=self.input_ids)
         return h
 
     def capture(self, before_capture=None):

@@ -30,9 +30,9 @@ import bench as B1
 FULL_LAYERS = (3, 10, 17, 24)
 
 
-def config_70b(layers=28, vocab=4096):
-    """The published 70B geometry; the vocabulary is cut down (embedding and LM head are the engine's side).  ``layers``
-    below 28 keeps the first layers (a rehearsal on a GPU that cannot hold a 1/TP share of all experts)."""
+def config_70b(layers=28, vocab=B1.VOCAB):
+    """The published 70B geometry, vocabulary included.  ``layers`` below 28 keeps the first layers (a rehearsal on a
+    GPU that cannot hold a 1/TP share of all experts)."""
     from vllm_hymeta.models.configuration_hymeta import HymetaConfig
     return HymetaConfig(vocab_size=vocab, num_hidden_layers=layers)
 
@@ -105,6 +105,43 @@ def build_model_70b(dev, quant, max_num_seqs, tp_group, layers):
     return model, cfg
 
 
+class VocabParallelGreedy:
+    """Greedy sampling with the lm_head cut along the vocabulary (vLLM's ParallelLMHead; the reference builds it at
+    vllm_hymeta/models/modeling_hymeta.py:1412-1431): every rank multiplies the hidden states with its V / tp rows (fp32
+    logits of bf16 operands), takes its own argmax, and the ranks exchange one (value, index) pair per sequence -- a
+    [B, 2] fp32 all-gather -- instead of gathering [B, V] logits, which greedy sampling does not need.  The lowest rank
+    wins among equal values, i.e. the lowest index, as a single argmax would."""
+
+    def __init__(self, model, group, rank_in_group, tp, batch, dev):
+        from vllm_hymeta import parallel
+
+        V = model._lm_head.shape[0]
+        assert V % (64 * tp) == 0, "vocabulary must cut into multiples of 64 rows"
+        self.lo = rank_in_group * (V // tp)
+        self.weight = model._lm_head[self.lo:self.lo + V // tp].contiguous()
+        model._lm_head = self.weight                  # the rank keeps only its rows
+        self.group, self.tp = group, tp
+        self.exchange = tp > 1 or parallel.SINGLE_RANK_COLLECTIVES
+        self.pair = torch.zeros(batch, 2, dtype=torch.float32, device=dev)
+        self.all = torch.zeros(tp, batch, 2, dtype=torch.float32, device=dev)
+        self.rows = torch.arange(batch, device=dev)
+
+    def __call__(self, hidden, out_ids):
+        from vllm_hymeta import hip_ops
+        from vllm_hymeta.lm_head import lm_head_logits
+
+        logits = lm_head_logits(hidden, self.weight)
+        idx = hip_ops.argmax_rows(logits)
+        self.pair[:, 0] = logits.gather(1, idx.unsqueeze(1)).squeeze(1)
+        self.pair[:, 1] = (idx + self.lo).float()      # indices below 2^24: exact in fp32
+        if self.exchange:
+            dist.all_gather_into_tensor(self.all, self.pair, group=self.group)
+        else:
+            self.all[0].copy_(self.pair)
+        best = self.all[:, :, 0].argmax(0)
+        out_ids.copy_(self.all[best, self.rows, 1].long())
+
+
 def experts_hit(model, runner):
     """Distinct experts the batch routes to, per mixture layer (one eager step with a hook on each mixture: the host
     read stays outside the timed region)."""
@@ -144,8 +181,9 @@ def step_bytes_70b(cfg, quant, tp, batch, ctx, hit):
     full = [i for i in range(L) if i in FULL_LAYERS]
     kv = batch * 2 * kvh * D * 2 * ((L - len(full)) * (min(ctx + 1, cfg.sliding_window) + M_META) + len(full) * (ctx + 1 + M_META))
     gla = L * batch * 2 * heads * D * D * 2
+    logits = cfg.vocab_size // tp * HIDDEN * 2 + 2 * batch * (cfg.vocab_size // tp) * 4     # bf16 lm_head rows, fp32 logits out and back
     parts = {"attention_linears": attn_w, "dense_mlp": dense_w, "shared_expert": shared_w, "routed_experts": expert_w,
-             "kv_rows": kv, "gla_states": gla}
+             "kv_rows": kv, "gla_states": gla, "lm_head_and_logits": logits}
     return int(sum(parts.values())), {k: int(v) for k, v in parts.items()}
 
 
@@ -165,15 +203,18 @@ def note(rank, msg):
 
 def collectives_alone(cfg, batch, group, dev, reps=5):
     """ms of the step's collectives replayed alone from one graph (per layer: the [B, 2] fp32 statistics, the out_proj
-    output and the feed-forward output, [B, hidden] bf16 each), back to back with no compute between them."""
+    output and the feed-forward output, [B, hidden] bf16 each; per step: the sampler's [B, 2] all-gather), back to back
+    with no compute between them."""
     stats = torch.zeros(batch, 2, dtype=torch.float32, device=dev)
     y = torch.zeros(batch, cfg.hidden_size, dtype=torch.bfloat16, device=dev)
+    gathered = torch.zeros(dist.get_world_size(group), batch, 2, dtype=torch.float32, device=dev)
 
     def run():
         for _ in range(cfg.num_hidden_layers):
             dist.all_reduce(stats, group=group)
             dist.all_reduce(y, group=group)
             dist.all_reduce(y, group=group)
+        dist.all_gather_into_tensor(gathered, stats, group=group)
 
     run()
     graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
@@ -234,6 +275,7 @@ def tp_main(args):
     note(rank, f"{world} ranks: tp{tp} x {replicas}; building the model")
     model, cfg = build_model_70b(dev, args.quant, batch, tp_group, args.tp_layers)
     runner = B1.DecodeRunner(model, batch, ctx, total + 8, dev, seed=rank // tp)
+    runner.sampler = VocabParallelGreedy(model, tp_group, rank % tp, tp, batch, dev)
     hit = experts_hit(model, runner)
     note(rank, f"model built ({torch.cuda.memory_allocated(dev) / 2 ** 30:.1f} GiB allocated), experts hit {hit}")
     if args.tp_eager:
@@ -274,7 +316,9 @@ def tp_main(args):
             "workload": f"Hymeta-70B {args.quant} TP={tp} decode, ctx {ctx}, block_size {B1.BLOCK}, {batch} sequences per replica; step = "
                         f"one token per sequence through {cfg.num_hidden_layers} layers of HymetaForCausalLM (embedding, norms, both "
                         "attention branches on the rank's heads, out_proj, dense MLP / 16-expert top-1 mixture + shared expert, final "
-                        "norm) with the three all-reduces of every layer on RCCL; LM head and sampler (the engine's) not run.  "
+                        "norm) with the three all-reduces of every layer on RCCL, then greedy sampling with the lm_head cut along "
+                        "the vocabulary (fp32 logits of the rank's rows, local argmax, one [B, 2] all-gather), fed back as the "
+                        "next step's tokens.  "
                         "The N=1 line of this bench is the 7B model: a different workload, not the base of this curve",
             "batch_per_replica": batch,
             "global_batch": replicas * batch,
@@ -287,8 +331,9 @@ def tp_main(args):
             "graph": not args.tp_eager,
         },
         "collectives": {
-            "per_step": 3 * cfg.num_hidden_layers,
-            "messages": f"per layer: [{batch}, 2] fp32 statistics, 2 x [{batch}, {cfg.hidden_size}] bf16",
+            "per_step": 3 * cfg.num_hidden_layers + 1,
+            "messages": f"per layer: [{batch}, 2] fp32 statistics, 2 x [{batch}, {cfg.hidden_size}] bf16; per step: one [{batch}, 2] fp32 "
+                        "all-gather of the ranks' best (logit, token) pairs",
             "ms_per_step_alone": round(coll_ms, 4),
             "share_of_step": round(coll_ms / gpu_ms, 4),
         },
