@@ -664,6 +664,18 @@ def main():
             return round(timed_steps(r1, args.warmup, args.steps)[1], 4)
 
         line["model_decode"] = {args.quant: {"ms_per_step": line["ms_per_step"], "tokens_per_s": line["value"], "batch1_ms_per_token": b1_main}}
+        # the same step at other batch sizes (up to 128 rows the linears stream their weights once; beyond, library GEMMs)
+        line["decode_by_batch"] = {}
+        mb = build_model_7b(dev, args.quant, max_num_seqs=256, gla_state=args.gla_state)
+        for bb in (8, 128, 256):
+            rb = DecodeRunner(mb, bb, args.ctx, total + 8, dev, seed=bb)
+            rb.capture()
+            _, msb = timed_steps(rb, args.warmup, args.steps)
+            line["decode_by_batch"][str(bb)] = {"ms_per_step": round(msb, 4), "tokens_per_s": round(bb / (msb * 1e-3), 1)}
+            del rb
+            torch.cuda.empty_cache()
+        del mb
+        torch.cuda.empty_cache()
         for q in ("bf16", "gptq4", "w8a8"):
             if q == args.quant:
                 continue

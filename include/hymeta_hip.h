@@ -605,7 +605,8 @@ int hymeta_gptq_dequant(const int32_t* qweight, const int32_t* qzeros, const voi
                         int32_t zero_offset, hymeta_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * bf16 linear for decode-sized batches (M <= 64): out = bf16(x W^T + bias), fp32 accumulation,
+ * bf16 linear for decode-sized batches (M <= 128; 65 to 128 rows need K % 64 == 0, K >= 256 and split_k == 0):
+ * out = bf16(x W^T + bias), fp32 accumulation,
  * one rounding; W [N, K] as torch stores a Linear weight.  Replaces the un-quantised linear
  * method (F.linear through vLLM's ColumnParallelLinear / RowParallelLinear, third party) at the
  * call sites vllm_hymeta/models/modeling_hymeta.py:249-262,422-430,724-732,858-861 and
@@ -633,7 +634,7 @@ size_t hymeta_bf16_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream);
 
 /* Logits of a bf16 lm_head: out fp32 [M, N] (out_stride_m in fp32 elements, a multiple of 4) = x weight^T (+ bias)
- * with fp32 accumulation and no rounding of the result; workspace and split_k unused.  M <= 64, K a multiple of 64 and
+ * with fp32 accumulation and no rounding of the result; workspace and split_k unused.  M <= 128, K a multiple of 64 and
  * at least 256, N a multiple of 64; other shapes HYMETA_ERR_UNSUPPORTED.
  * Replaces lm_head.float() applied to hidden_states.float() in compute_logits
  * (vllm_hymeta/model_for_7B/modeling_gla_swa.py:548,579-583, vllm_hymeta/models/modeling_hymeta.py:1429,1462-1466):
@@ -658,7 +659,7 @@ int hymeta_argmax_rows(const float* logits, int64_t stride_m, int32_t M, int32_t
  * in one launch and without the [M, N] intermediate.
  * Replaces MergedColumnParallelLinear + SiluAndMul in the MLP forward
  * (vllm_hymeta/model_for_7B/modeling_gla_swa.py:108-121, vllm_hymeta/models/modeling_hymeta.py:262-271).
- * bias must be NULL, the workspace fields are ignored.  Takes M <= 64, K % 64 == 0, N % 128 == 0;
+ * bias must be NULL, the workspace fields are ignored.  Takes M <= 128, K % 64 == 0, N % 128 == 0;
  * other shapes are HYMETA_ERR_UNSUPPORTED: run the two calls. */
 int hymeta_bf16_gemm_silu_mul(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream);
 
@@ -694,7 +695,7 @@ size_t hymeta_w8a8_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream);
 
 /* W8A8 form of hymeta_bf16_gemm_silu_mul (same layout, same rule: equals hymeta_w8a8_gemm followed by
- * hymeta_silu_and_mul bit for bit).  bias must be NULL; M <= 64, K % 128 == 0, N % 128 == 0. */
+ * hymeta_silu_and_mul bit for bit).  bias must be NULL; M <= 128, K % 128 == 0, N % 128 == 0. */
 int hymeta_w8a8_gemm_silu_mul(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream);
 
 /* ------------------------------------------------------------------------

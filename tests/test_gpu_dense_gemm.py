@@ -28,6 +28,12 @@ pytestmark = pytest.mark.gpu
     (64, 18944, 3584, True, 0),        # 7B down projection: deep K in slices
     (5, 512, 320, True, 0),            # 64-column tiles (N not a multiple of 128), two chunks
     (20, 256, 64, False, 0),           # one tile, one chunk
+    # 65 to 128 rows: eight row fragments per wave, one x image (two barriers per chunk)
+    (128, 3584, 4608, True, 0),        # K slices
+    (100, 3584, 37888, False, 0),      # whole tiles of two widths, rows past M masked
+    (65, 18944, 3584, True, 0),        # deep K in slices
+    (128, 896, 3584, False, 0),        # partial last chunk
+    (96, 256, 64, True, 0),            # one tile, one chunk
 ])
 def test_bf16_gemm(M, K, N, bias, split_k):
     from vllm_hymeta import hip_ops
@@ -43,6 +49,10 @@ def test_bf16_gemm(M, K, N, bias, split_k):
     torch.cuda.synchronize()
     assert_bf16_close(out.cpu(), ref, f"bf16 gemm M={M} K={K} N={N} split={split_k}")
     assert torch.equal(out, again), "slice sums are taken in slice order: same bits on every run"
+    if M > 64:       # an explicit slice count selects the older kernel, which stops at 64 rows
+        with pytest.raises(Exception):
+            hip_ops.bf16_gemm(x.cuda(), w.cuda(), None if b is None else b.cuda(), split_k=1)
+        return
     one = hip_ops.bf16_gemm(x.cuda(), w.cuda(), None if b is None else b.cuda(), split_k=1)
     torch.cuda.synchronize()
     assert_bf16_ulp(out, one, "sliced vs unsliced", ulps=1)
@@ -50,7 +60,7 @@ def test_bf16_gemm(M, K, N, bias, split_k):
 
 def test_bf16_gemm_strided_views_and_linear_dispatch():
     """Rows of a wider buffer as input (the fused qkv buffer), a column slice as output; HymetaLinear
-    takes the kernel up to 64 rows and the library beyond, with the same result within rounding."""
+    takes the kernel up to 128 rows and the library beyond, with the same result within rounding."""
     from vllm_hymeta import hip_ops
     from vllm_hymeta.linear import HymetaLinear
 
@@ -65,7 +75,7 @@ def test_bf16_gemm_strided_views_and_linear_dispatch():
     assert_bf16_close(out_buf[:, 128:384].cpu(), ref, "strided bf16 gemm")
     assert float(out_buf[:, :128].abs().max()) == 0 and float(out_buf[:, 384:].abs().max()) == 0
 
-    small, big = randn_bf16(g_, 64, 512).cuda(), randn_bf16(g_, 65, 512).cuda()
+    small, big = randn_bf16(g_, 128, 512).cuda(), randn_bf16(g_, 129, 512).cuda()
     assert hip_ops.bf16_gemm_supported(small, w) and not hip_ops.bf16_gemm_supported(big, w)
     deep = randn_bf16(g_, 128, 512, scale=512 ** -0.5).cuda()          # K = 4 N
     assert hip_ops.bf16_gemm_preferred(small, w) and hip_ops.bf16_gemm_preferred(small, deep), "every decode-sized linear runs on the kernel"
@@ -80,7 +90,8 @@ def test_bf16_gemm_strided_views_and_linear_dispatch():
 
 
 @pytest.mark.parametrize("kind", ["bf16", "w8a8"])
-@pytest.mark.parametrize("M,K,I", [(64, 3584, 18944), (1, 3584, 18944), (33, 3584, 4736), (16, 320, 64), (40, 1024, 8256)])
+@pytest.mark.parametrize("M,K,I", [(64, 3584, 18944), (1, 3584, 18944), (33, 3584, 4736), (16, 320, 64), (40, 1024, 8256),
+                                   (128, 3584, 18944), (70, 1024, 8256)])
 def test_gate_up_projection_with_the_activation_in_its_epilogue(kind, M, K, I):
     """7B / 70B TP=4 gate_up shapes and small ones (one tile; two tile widths): the fused launch gives the bits of the
     linear followed by silu_and_mul (where that linear sums in the same order), and matches the fp64 restatement within the bf16 tolerance."""
@@ -119,7 +130,7 @@ def test_gate_up_projection_with_the_activation_in_its_epilogue(kind, M, K, I):
 
 
 @pytest.mark.parametrize("kind", ["bf16", "w8a8"])
-@pytest.mark.parametrize("M,K,N,bias", [(64, 3584, 3584, False), (33, 18944, 3584, True), (17, 896, 3584, False)])
+@pytest.mark.parametrize("M,K,N,bias", [(64, 3584, 3584, False), (33, 18944, 3584, True), (17, 896, 3584, False), (128, 18944, 3584, True)])
 def test_k_slice_sum_left_to_the_fused_add_rmsnorm(kind, M, K, N, bias):
     """o_proj / down_proj shapes: the linear stops at its K slices' partial sums and the residual add + RMS norm adds
     them while reading; normed output, updated residual and the materialised linear equal the plain calls bit for bit."""

@@ -161,9 +161,10 @@ def test_gptq_linear_large_m_uses_expanded_weights():
 
 
 @pytest.mark.parametrize("M,K,N", [(17, 3584, 4608), (33, 3584, 37888), (64, 18944, 3584), (64, 3584, 3584), (40, 512, 320),
-                                   (64, 4736, 3584), (24, 896, 3584), (64, 3584, 9472)])     # the last three: 70B TP=4 shards
+                                   (64, 4736, 3584), (24, 896, 3584), (64, 3584, 9472),      # these three: 70B TP=4 shards
+                                   (128, 3584, 4608), (100, 3584, 37888), (65, 18944, 3584), (1, 3584, 3584), (9, 18944, 3584)])
 def test_w8a8_streaming_kernel_matches_the_library_path_exactly(M, K, N):
-    """17 to 64 rows run on the weight-streaming int8 kernel (whole tiles or K slices + the reduce launch); the int32 sums
+    """Up to 128 rows run on the weight-streaming int8 kernel (whole tiles or K slices + the reduce launch); the int32 sums
     are exact, so the result equals quantise -> library int8 GEMM -> scale bit for bit, and the oracle within tolerance."""
     from oracle.quant import w8a8_gemm_ref
     from vllm_hymeta import hip_ops
@@ -185,15 +186,15 @@ def test_w8a8_streaming_kernel_matches_the_library_path_exactly(M, K, N):
     assert_bf16_close(out.cpu(), w8a8_gemm_ref(x, wq, ws, bias), f"w8a8 streaming M={M}", rel=6e-3)
 
 
-@pytest.mark.parametrize("M,K,N", [(300, 512, 256), (1024, 3584, 4608), (65, 3584, 4608), (72, 2048, 256)])
+@pytest.mark.parametrize("M,K,N", [(300, 512, 256), (1024, 3584, 4608), (129, 3584, 4608), (200, 2048, 256)])
 def test_w8a8_linear_prefill_regime_matches_fused_kernel_exactly(M, K, N):
-    """Above 64 rows the linear runs quantise -> library int8 GEMM -> scale; the int32 sums are exact on both
+    """Above 128 rows the linear runs quantise -> library int8 GEMM -> scale; the int32 sums are exact on both
     paths, so the outputs agree bit for bit with the fused kernel's and with the oracle within the bf16 tolerance."""
     from oracle.quant import w8a8_gemm_ref
     from vllm_hymeta import hip_ops
     from vllm_hymeta.linear import HymetaLinear, w8a8_use_library
 
-    assert w8a8_use_library(M, K, N) and not w8a8_use_library(64, K, N)
+    assert w8a8_use_library(M, K, N) and not w8a8_use_library(128, K, N)
     g_ = gen(21)
     x = randn_bf16(g_, M, K)
     wq = torch.randint(-127, 128, (N, K), generator=g_, dtype=torch.int8)

@@ -170,7 +170,7 @@ static int bf16_gemm_impl(const hymeta_bf16_gemm_args* args, hymeta_stream_t str
   if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;
   if (!a.x || !a.weight || !a.out) return HYMETA_ERR_INVALID_ARG;
-  if (a.M > 64 || a.K % 32 != 0 || a.N % kCols != 0) return HYMETA_ERR_UNSUPPORTED;
+  if (a.M > 128 || a.K % 32 != 0 || a.N % kCols != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((a.x_stride_m | a.w_stride_n | a.out_stride_m) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.weight) | reinterpret_cast<uintptr_t>(a.out) |
        reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.workspace)) % 16 != 0)
@@ -195,6 +195,7 @@ static int bf16_gemm_impl(const hymeta_bf16_gemm_args* args, hymeta_stream_t str
       return stream_gemm_launch<false>(sa, plan, begin_launches(stream), deferred != nullptr);
     }
   }
+  if (a.M > 64) return HYMETA_ERR_UNSUPPORTED;      // 65 to 128 rows: the streaming kernel only
   const int ksteps = a.K / 32;
   int splits = a.split_k > 0 ? a.split_k : (a.workspace != nullptr ? hymeta_bf16_gemm_split_k(a.M, a.K, a.N) : 1);
   if (splits > ksteps) splits = ksteps;

@@ -30,7 +30,7 @@ struct StreamPlan {
   int ring;      // pairs of k-steps each wave keeps in flight (2 or 4)
 };
 
-// Whether the streaming kernel takes the shape (M <= 64 rows, K a multiple of 128 bytes and at least 512, N of 64 columns), and how
+// Whether the streaming kernel takes the shape (M <= 128 rows, K a multiple of 128 bytes and at least 512, N of 64 columns), and how
 // it is cut (one workgroup per compute unit where the shape allows).  Without a workspace every workgroup owns whole tiles (no slabs).
 bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* plan);
 // Gated form (see StreamArgs::gated): N counts the gate and the up rows together and must be a multiple of 128.

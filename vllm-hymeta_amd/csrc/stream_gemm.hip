@@ -60,13 +60,14 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& a, char* smem, con
   constexpr int kRowsT = 16 * MT;
   constexpr int kPitch = 64 * NFT + 4;           // floats per row of the epilogue image
   constexpr int kBufBytes = kRowsT * kChunkBytes;
+  constexpr int kBufs = MT > 4 ? 1 : 2;            // x chunk images: 128 rows leave room for one (a second barrier per chunk instead)
   constexpr int kWaveImg = 2 * NFT * 2048;         // a wave's two weight images (one pair of k-steps each)
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int n = lane & 15, cq = lane >> 4;
-  char* wimg = smem + 2 * kBufBytes + wave * kWaveImg;
+  char* wimg = smem + kBufs * kBufBytes + wave * kWaveImg;
   const int c_lo = static_cast<int>(static_cast<int64_t>(split) * a.chunks / a.splits);
   const int c_hi = static_cast<int>(static_cast<int64_t>(split + 1) * a.chunks / a.splits);
   // The last chunk of a row may be partial (K a multiple of 128 bytes, not of 512): x is staged as zeros past the
@@ -160,7 +161,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& a, char* smem, con
       for (int cc = 0; cc < kUnroll; ++cc) {
         const int c = c0 + cc;
         if (c < c_hi) {
-          const char* cur = smem + ((c - c_lo) & 1) * kBufBytes;
+          const char* cur = smem + ((c - c_lo) & (kBufs - 1)) * kBufBytes;
           stage_load(kAhead == 2 ? (cc & 1) : 0, c + kAhead);
           __builtin_amdgcn_sched_barrier(0);
           const int pair0 = (c - c_lo) * (kChunkSteps / 2);
@@ -191,7 +192,8 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& a, char* smem, con
                 for (int i = 0; i < NF; ++i) acc[mt][i] = mma<I8>(af[mt], bfr[i], acc[mt][i]);
             }
           }
-          stage_store(kAhead == 2 ? ((cc + 1) & 1) : 0, smem + (((c - c_lo) & 1) ^ 1) * kBufBytes);
+          if constexpr (kBufs == 1) __syncthreads();       // every wave is done with the one image
+          stage_store(kAhead == 2 ? ((cc + 1) & 1) : 0, smem + (((c - c_lo) + 1) & (kBufs - 1)) * kBufBytes);
           __syncthreads();
         }
       }
@@ -338,7 +340,7 @@ template <int MT, int NF, bool I8, int RING>
 int launch_stream(const StreamArgs& a, hipStream_t s, bool defer_reduce) {
   constexpr int R = RING;     // pairs of k-steps in flight per wave
   constexpr size_t img = static_cast<size_t>(16 * MT) * (64 * NF + 4) * 4;                 // epilogue image
-  constexpr size_t stream = 2u * 16 * MT * kChunkBytes + 4u * 2 * NF * 2048;                  // x chunks + the waves' weight images
+  constexpr size_t stream = (MT > 4 ? 1u : 2u) * 16 * MT * kChunkBytes + 4u * 2 * NF * 2048;     // x chunks + the waves' weight images
   constexpr size_t lds = img > stream ? img : stream;
   auto kern = stream_gemm_kernel<MT, NF, R, I8, true>;
   static bool configured = false;
@@ -359,14 +361,14 @@ int launch_stream(const StreamArgs& a, hipStream_t s, bool defer_reduce) {
 }  // namespace
 
 // Tuning overrides, read once: HYMETA_STREAM_NF (uniform tile width, 1..4), HYMETA_STREAM_WGS (workgroups to aim for),
-// HYMETA_STREAM_SPLITS (K slices), HYMETA_STREAM_RING (2, 4, 8 or 16).
+// HYMETA_STREAM_SPLITS (K slices), HYMETA_STREAM_RING (2 or 4).
 static int tune(const char* name) {
   const char* e = getenv(name);
   return e == nullptr ? 0 : atoi(e);
 }
 
 bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* p) {
-  if (M <= 0 || M > 64 || K_bytes % 128 != 0 || K_bytes < kChunkBytes || N % 64 != 0) return false;
+  if (M <= 0 || M > 128 || K_bytes % 128 != 0 || K_bytes < kChunkBytes || N % 64 != 0) return false;
   static const int nf_forced = tune("HYMETA_STREAM_NF"), splits_forced = tune("HYMETA_STREAM_SPLITS");
   static const int ring_forced = tune("HYMETA_STREAM_RING"), want_forced = tune("HYMETA_STREAM_WGS");
   const int chunks = (K_bytes + kChunkBytes - 1) / kChunkBytes;
@@ -400,8 +402,9 @@ bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan
   if (splits < 1) splits = 1;
   p->nf = nf, p->tiles = tiles, p->chunks = chunks, p->splits = splits;
   // bytes in flight per wave = ring x fragments x 2 KB: one-fragment tiles need the deeper ring to cover the memory latency
-  p->ring = ring_forced == 2 || ring_forced == 4 || ring_forced == 8 || ring_forced == 16 ? ring_forced : (p->nf == 1 ? 4 : 2);
-  if (p->nf > 2 && p->ring > 4) p->ring = 4;            // deep rings are built for the narrow tiles only
+  // (rings of 8 and 16 pairs with x two chunks ahead -- the kUnroll / kAhead forms of the main loop -- were measured on the
+  // narrow 7B matrices: 1 to 7 us slower, the launches are bound by their fixed costs, not by loads in flight)
+  p->ring = ring_forced == 2 || ring_forced == 4 ? ring_forced : (p->nf == 1 ? 4 : 2);
   return p->nf <= 4 && tiles <= groups;      // every wave of every tile owns at least one fragment
 }
 
@@ -423,18 +426,15 @@ int stream_gemm_launch(StreamArgs a, const StreamPlan& p, hipStream_t s, bool de
   if (a.k_bytes <= 0 || (a.k_bytes + kChunkBytes - 1) / kChunkBytes != p.chunks) return HYMETA_ERR_INVALID_ARG;
   if (a.gated && (p.splits != 1 || a.bias != nullptr || a.N % 128 != 0)) return HYMETA_ERR_INVALID_ARG;
   if (a.out_f32 && (p.splits != 1 || a.gated)) return HYMETA_ERR_INVALID_ARG;
-  const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+  const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : (a.M <= 64 ? 4 : 8));
 #define HYMETA_STREAM_CASE(MT_, NF_) \
   if (mt == MT_ && p.nf == NF_) {                                                                   \
-    if constexpr (NF_ <= 2) {                                                                       \
-      if (p.ring == 16) return launch_stream<MT_, NF_, I8, 16>(a, s, defer_reduce);                 \
-      if (p.ring == 8) return launch_stream<MT_, NF_, I8, 8>(a, s, defer_reduce);                   \
-    }                                                                                               \
     return p.ring == 4 ? launch_stream<MT_, NF_, I8, 4>(a, s, defer_reduce) : launch_stream<MT_, NF_, I8, 2>(a, s, defer_reduce); \
   }
   HYMETA_STREAM_CASE(1, 1) HYMETA_STREAM_CASE(1, 2) HYMETA_STREAM_CASE(1, 3) HYMETA_STREAM_CASE(1, 4)
   HYMETA_STREAM_CASE(2, 1) HYMETA_STREAM_CASE(2, 2) HYMETA_STREAM_CASE(2, 3) HYMETA_STREAM_CASE(2, 4)
   HYMETA_STREAM_CASE(4, 1) HYMETA_STREAM_CASE(4, 2) HYMETA_STREAM_CASE(4, 3) HYMETA_STREAM_CASE(4, 4)
+  HYMETA_STREAM_CASE(8, 1) HYMETA_STREAM_CASE(8, 2) HYMETA_STREAM_CASE(8, 3) HYMETA_STREAM_CASE(8, 4)
 #undef HYMETA_STREAM_CASE
   return HYMETA_ERR_UNSUPPORTED;
 }

@@ -877,7 +877,7 @@ def gptq_dequant(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tens
     return out
 
 
-BF16_GEMM_MAX_ROWS = 64
+BF16_GEMM_MAX_ROWS = 128      # 65 to 128 rows: the streaming kernel only (K a multiple of 64, at least 256)
 
 
 def bf16_gemm_preferred(x: torch.Tensor, weight: torch.Tensor) -> bool:
@@ -892,12 +892,13 @@ def bf16_gemm_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return (x.dim() == 2 and 0 < x.shape[0] <= BF16_GEMM_MAX_ROWS and x.is_cuda and x.dtype == torch.bfloat16
             and weight.dtype == torch.bfloat16 and x.stride(1) == 1 and weight.stride(1) == 1
             and weight.shape[1] % 32 == 0 and weight.shape[0] % 64 == 0
+            and (x.shape[0] <= 64 or (weight.shape[1] % 64 == 0 and weight.shape[1] >= 256))
             and x.stride(0) % 8 == 0 and weight.stride(0) % 8 == 0)
 
 
 def bf16_gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
               out: Optional[torch.Tensor] = None, split_k: int = 0, defer: bool = False):
-    """x bf16 [M <= 64, K] @ weight bf16 [N, K]^T (+ bias bf16 [N]) -> bf16 [M, N]; ``split_k`` 0: library's choice.
+    """x bf16 [M <= 128, K] @ weight bf16 [N, K]^T (+ bias bf16 [N]) -> bf16 [M, N]; ``split_k`` 0: library's choice.
     ``defer``: when the library cuts K into slices, return their ``PartialSums`` instead of summing them."""
     _dev(x, weight, bias, out)
     M, K = x.shape
@@ -1021,7 +1022,7 @@ def gemm_silu_mul_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 def gemm_silu_mul(x: torch.Tensor, weight: torch.Tensor, w_scale: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``silu(x gate^T) * (x up^T)`` in one launch: x bf16 [M <= 64, K]; weight [2 I, K] bf16, or int8 with ``w_scale``
+    """``silu(x gate^T) * (x up^T)`` in one launch: x bf16 [M <= 128, K]; weight [2 I, K] bf16, or int8 with ``w_scale``
     fp32 [2 I] (dynamic per-token int8 activations) -> bf16 [M, I].  Bit for bit the linear followed by
     ``silu_and_mul``."""
     _dev(x, weight, w_scale, out)

@@ -1,5 +1,5 @@
 """Linear layers of the attention blocks: bf16 or one of the fused dequant-GEMMs (GPTQ 4/8-bit, W8A8).
-Decode-sized batches (up to 64 rows) always run on this package's weight-streaming kernels; prefill-sized
+Decode-sized batches (up to 128 rows; GPTQ up to 64) always run on this package's weight-streaming kernels; prefill-sized
 batches of bf16 / expanded GPTQ / int8 weights go to the library GEMM.  Stands where the reference puts vLLM's
 ``QKVParallelLinear`` / ``RowParallelLinear`` / ``ReplicatedLinear`` with a ``quant_config``
 (``vllm_hymeta/model_for_7B/gla_attention.py:147-176``): a tensor-parallel shard is simply a
@@ -18,9 +18,9 @@ from . import hip_ops
 # projection shapes: the fused kernel wins up to a few hundred rows, the library from there on).
 GPTQ_EXPAND_ROWS = 256
 # Rows above which a W8A8 linear puts the library int8 GEMM between its own quantisation and
-# scaling kernels: the streaming int8 kernel covers up to 64 rows (one pass over the weights); both
+# scaling kernels: the streaming int8 kernel covers up to 128 rows (one pass over the weights); both
 # paths give the same bits (exact int32 sums).
-W8A8_LIBRARY_ROWS = 64
+W8A8_LIBRARY_ROWS = 128
 
 
 def w8a8_use_library(rows: int, in_features: int, out_features: int) -> bool:
