@@ -123,7 +123,8 @@ class VocabParallelGreedy:
         self.group, self.tp = group, tp
         self.exchange = tp > 1 or parallel.SINGLE_RANK_COLLECTIVES
         self.pair = torch.zeros(batch, 2, dtype=torch.float32, device=dev)
-        self.all = torch.zeros(tp, batch, 2, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(tp * batch, 2, dtype=torch.float32, device=dev)     # the ranks' pairs, rank-major
+        self.all = self.flat.view(tp, batch, 2)
         self.rows = torch.arange(batch, device=dev)
 
     def __call__(self, hidden, out_ids):
@@ -131,11 +132,11 @@ class VocabParallelGreedy:
         from vllm_hymeta.lm_head import lm_head_logits
 
         logits = lm_head_logits(hidden, self.weight)
-        idx = hip_ops.argmax_rows(logits)
+        idx = hip_ops.argmax_rows(logits) if logits.is_cuda else logits.argmax(-1)     # (CPU: the gloo test of the exchange)
         self.pair[:, 0] = logits.gather(1, idx.unsqueeze(1)).squeeze(1)
         self.pair[:, 1] = (idx + self.lo).float()      # indices below 2^24: exact in fp32
         if self.exchange:
-            dist.all_gather_into_tensor(self.all, self.pair, group=self.group)
+            dist.all_gather_into_tensor(self.flat, self.pair, group=self.group)
         else:
             self.all[0].copy_(self.pair)
         best = self.all[:, :, 0].argmax(0)
@@ -207,7 +208,7 @@ def collectives_alone(cfg, batch, group, dev, reps=5):
     with no compute between them."""
     stats = torch.zeros(batch, 2, dtype=torch.float32, device=dev)
     y = torch.zeros(batch, cfg.hidden_size, dtype=torch.bfloat16, device=dev)
-    gathered = torch.zeros(dist.get_world_size(group), batch, 2, dtype=torch.float32, device=dev)
+    gathered = torch.zeros(dist.get_world_size(group) * batch, 2, dtype=torch.float32, device=dev)
 
     def run():
         for _ in range(cfg.num_hidden_layers):

@@ -90,3 +90,43 @@ def test_synthetic_70b_checkpoint_shards_over_two_ranks():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
+def _greedy_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+
+        from bench_tp import VocabParallelGreedy
+
+        g = torch.Generator().manual_seed(5)
+        B, V, hidden = 6, 256, 64
+        w = (torch.randn(V, hidden, generator=g) * 0.1).to(torch.bfloat16)
+        w[200] = w[17]                                   # two equal logits in different ranks' shares: the lower index wins
+        h = torch.randn(B, hidden, generator=g).to(torch.bfloat16)
+        h[0] = w[17].float().sign().to(torch.bfloat16)   # row 0 peaks at tokens 17 and 200 alike
+        model = SimpleNamespace(_lm_head=w.clone())
+        sampler = VocabParallelGreedy(model, dist.group.WORLD, rank, world, B, torch.device("cpu"))
+        assert model._lm_head.shape == (V // world, hidden) and torch.equal(model._lm_head, w[rank * V // world:(rank + 1) * V // world])
+        out = torch.zeros(B, dtype=torch.int64)
+        sampler(h, out)
+        full = torch.nn.functional.linear(h.float(), w.float())
+        assert torch.equal(out, full.argmax(-1)) or all(full[i, out[i]] == full[i].max() for i in range(B))
+        assert int(out[0]) == 17
+        ret[rank] = "ok"
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        ret[rank] = traceback.format_exc() + repr(e)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_vocabulary_parallel_greedy_sampling_equals_the_full_argmax():
+    """world_size 2 over gloo: every rank multiplies with its half of the lm_head, the ranks exchange one (logit, token)
+    pair per sequence, and all of them end up with the argmax of the full logits (the lowest index among equals)."""
+    world, port = 2, _free_port()
+    with mp.Manager() as man:
+        ret = man.dict()
+        mp.spawn(_greedy_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
