@@ -206,10 +206,10 @@ class DecodeRunner:
         self.slot_mapping.copy_(blk * BLOCK + self.positions % BLOCK)
 
     def advance(self):
-        """The next token's metadata, in place on the device (what the engine copies into its graph buffers)."""
-        self.positions += 1
-        self.seq_lens += 1
-        self._refresh_slots()
+        """The next token's metadata, in place on the device (the engine's multi-step advance: one launch)."""
+        from vllm_hymeta import hip_ops
+
+        hip_ops.advance_step(self.B, self.B, BLOCK, self.seq_lens, self.slot_mapping, self.block_tables, input_positions=self.positions)
 
     def eager_step(self):
         """One greedy decode step: the 28 layers, the lm_head logits of every sequence, their argmax -- which becomes the

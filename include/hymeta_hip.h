@@ -652,6 +652,17 @@ size_t hymeta_argmax_rows_workspace_bytes(int32_t M);
 int hymeta_argmax_rows(const float* logits, int64_t stride_m, int32_t M, int32_t N, int64_t* out, void* workspace,
                        size_t workspace_bytes, hymeta_stream_t stream);
 
+/* Multi-step decoding: sequence i < num_queries moves on by one token in place -- input_tokens[i] =
+ * sampled_token_ids[i] (either may be NULL), input_positions[i] = seq_lens[i] (may be NULL), seq_lens[i] += 1,
+ * slot_mapping[i] = block_tables[i][pos / block_size] * block_size + pos % block_size; the graph padding
+ * num_queries <= i < num_seqs gets slot -1.  int64 tokens, positions and slots, int32 lengths and block tables
+ * (rows block_table_stride entries apart).  One launch for the device update of
+ * MetaAttentionMetadata.advance_step (vllm_hymeta/attention/meta_attention.py:338-409, which calls vLLM's
+ * advance_step_flashattn, third party). */
+int hymeta_advance_step(int32_t num_seqs, int32_t num_queries, int32_t block_size, int64_t* input_tokens,
+                        const int64_t* sampled_token_ids, int64_t* input_positions, int32_t* seq_lens, int64_t* slot_mapping,
+                        const int32_t* block_tables, int64_t block_table_stride, hymeta_stream_t stream);
+
 /* The gate/up projection of a gated MLP with its activation in the GEMM's epilogue, for decode-sized batches:
  * weight = [gate rows | up rows] (N rows in all, the fused gate_up_proj), out bf16 [M, N / 2] =
  * silu(x gate^T) * (x up^T), both factors rounded to bf16 before the product -- the arithmetic of

@@ -164,3 +164,40 @@ def test_lowrank_gate_equals_the_two_linears(T, hidden, N, with_bias):
     again = hip_ops.lowrank_gate(buf[:, :hidden].contiguous(), w0.cuda(), w1.cuda(), None if b is None else b.cuda())
     torch.cuda.synchronize()
     assert torch.equal(wide[:, :N], again) and (wide[:, N:] == 0).all()
+
+
+def test_advance_step_on_the_device_equals_the_host_restatement():
+    """MetaAttentionMetadata.advance_step (multi-step decoding): the one-launch device update gives the integers of the
+    tensor-op restatement that CPU tensors take -- tokens, positions, lengths and cache slots bit for bit, padding
+    rows get slot -1 (reference meta_attention.py:338-409 -> vLLM's advance_step_flashattn)."""
+    from types import SimpleNamespace
+
+    from test_gpu_layers import _md
+
+    g_ = gen(81)
+    B, q, bs, nblk = 9, 7, 16, 6
+    lens = [int(v) for v in torch.randint(1, bs * nblk - 2, (B,), generator=g_)]
+    bt = torch.randperm(B * nblk, generator=g_).to(torch.int32).view(B, nblk)
+    sampled = torch.randint(0, 1000, (q, 1), generator=g_)
+
+    def make(dev):
+        slots = torch.full((B,), 5, dtype=torch.int64, device=dev)
+        md = _md(dev, decode_seq_lens=list(lens), block_tables=bt.to(dev), slot_mapping=slots)
+        md.use_cuda_graph = True
+        mi = SimpleNamespace(input_tokens=torch.zeros(B, dtype=torch.int64, device=dev),
+                             input_positions=torch.zeros(B, dtype=torch.int64, device=dev))
+        return md, mi
+
+    md_c, mi_c = make(torch.device("cpu"))
+    md_g, mi_g = make(torch.device("cuda"))
+    for _ in range(3):                                    # three steps in a row
+        md_c.advance_step(mi_c, sampled, bs, B, q)
+        md_g.advance_step(mi_g, sampled.cuda(), bs, B, q)
+    torch.cuda.synchronize()
+    assert md_g.seq_lens == md_c.seq_lens and md_g.max_decode_seq_len == md_c.max_decode_seq_len
+    assert torch.equal(md_g.seq_lens_tensor.cpu(), md_c.seq_lens_tensor)
+    assert torch.equal(mi_g.input_tokens.cpu()[:q], mi_c.input_tokens[:q]) and torch.equal(mi_g.input_positions.cpu()[:q], mi_c.input_positions[:q])
+    assert torch.equal(md_g.slot_mapping.cpu()[:q], md_c.slot_mapping[:q])
+    assert (md_g.slot_mapping.cpu()[q:] == -1).all()
+    pos = torch.tensor(lens[:q]) + 2                      # the position written by the third step
+    assert torch.equal(md_c.slot_mapping[:q], torch.gather(bt[:q].long(), 1, (pos // bs).unsqueeze(1)).squeeze(1) * bs + pos % bs)

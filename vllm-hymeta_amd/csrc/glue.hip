@@ -551,3 +551,37 @@ extern "C" int hymeta_argmax_rows(const float* logits, int64_t stride_m, int32_t
   }
   return hymeta::launch_status();
 }
+
+namespace hymeta {
+
+// Multi-step decoding: every live sequence moves on by one token, in place (one thread per sequence).
+__global__ __launch_bounds__(256) void advance_step_kernel(int num_seqs, int num_queries, int block_size, int64_t* input_tokens,
+                                                           const int64_t* sampled_token_ids, int64_t* input_positions, int32_t* seq_lens,
+                                                           int64_t* slot_mapping, const int32_t* block_tables, int64_t block_table_stride) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= num_seqs) return;
+  if (i >= num_queries) {        // graph padding
+    slot_mapping[i] = -1;
+    return;
+  }
+  if (input_tokens != nullptr && sampled_token_ids != nullptr) input_tokens[i] = sampled_token_ids[i];
+  const int pos = seq_lens[i];   // position of the next token = the length so far
+  seq_lens[i] = pos + 1;
+  if (input_positions != nullptr) input_positions[i] = pos;
+  const int64_t block = block_tables[i * block_table_stride + pos / block_size];
+  slot_mapping[i] = block * block_size + pos % block_size;
+}
+
+}  // namespace hymeta
+
+extern "C" int hymeta_advance_step(int32_t num_seqs, int32_t num_queries, int32_t block_size, int64_t* input_tokens,
+                                   const int64_t* sampled_token_ids, int64_t* input_positions, int32_t* seq_lens, int64_t* slot_mapping,
+                                   const int32_t* block_tables, int64_t block_table_stride, hymeta_stream_t stream) {
+  if (num_seqs < 0 || num_queries < 0 || num_queries > num_seqs || block_size <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (num_seqs == 0) return HYMETA_OK;
+  if (!seq_lens || !slot_mapping || !block_tables) return HYMETA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(hymeta::advance_step_kernel, dim3((num_seqs + 255) / 256), dim3(256), 0, hymeta::begin_launches(stream), num_seqs,
+                     num_queries, block_size, input_tokens, sampled_token_ids, input_positions, seq_lens, slot_mapping, block_tables,
+                     block_table_stride);
+  return hymeta::launch_status();
+}

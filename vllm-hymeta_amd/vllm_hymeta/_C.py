@@ -257,6 +257,7 @@ _SIGNATURES = {
     "hymeta_bf16_gemm_f32out": (C.c_int, [C.POINTER(Bf16GemmArgs), _ptr]),
     "hymeta_argmax_rows": (C.c_int, [_ptr, _i64, _i32, _i32, _ptr, _ptr, _sz, _ptr]),
     "hymeta_argmax_rows_workspace_bytes": (_sz, [_i32]),
+    "hymeta_advance_step": (C.c_int, [_i32, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
     "hymeta_bf16_gemm_deferred": (C.c_int, [C.POINTER(Bf16GemmArgs), C.POINTER(GemmPartials), _ptr]),
     "hymeta_w8a8_gemm_deferred": (C.c_int, [C.POINTER(W8A8GemmArgs), C.POINTER(GemmPartials), _ptr]),
     "hymeta_gptq_gemm_deferred": (C.c_int, [C.POINTER(GptqGemmArgs), C.POINTER(GemmPartials), _ptr]),

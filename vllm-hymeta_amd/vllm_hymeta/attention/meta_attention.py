@@ -244,6 +244,16 @@ class MetaAttentionMetadata(AttentionMetadata):
             self.seq_lens[i] += 1
         self.max_decode_seq_len = max(self.seq_lens)
         q = num_queries
+        tokens, positions = getattr(model_input, "input_tokens", None), getattr(model_input, "input_positions", None)
+        if (self.seq_lens_tensor.is_cuda and self.slot_mapping.dtype == torch.int64 and self.seq_lens_tensor.dtype == torch.int32
+                and self.block_tables.dtype == torch.int32 and self.block_tables.stride(1) == 1
+                and all(t is None or (t.dtype == torch.int64 and t.is_contiguous()) for t in (tokens, positions))
+                and (sampled_token_ids is None or (sampled_token_ids.dtype == torch.int64 and sampled_token_ids.is_contiguous()))):
+            from .. import hip_ops       # one launch on the device
+            hip_ops.advance_step(num_seqs, q, block_size, self.seq_lens_tensor, self.slot_mapping, self.block_tables,
+                                 input_tokens=tokens, sampled_token_ids=sampled_token_ids, input_positions=positions)
+            self._cached_decode_metadata = None
+            return
         if sampled_token_ids is not None and getattr(model_input, "input_tokens", None) is not None:
             model_input.input_tokens[:q] = sampled_token_ids[:q].view(-1).to(model_input.input_tokens.dtype)
         pos = self.seq_lens_tensor[:q].long()              # position of the next token

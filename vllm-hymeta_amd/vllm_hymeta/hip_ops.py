@@ -958,6 +958,28 @@ def bf16_logits(x: torch.Tensor, weight: torch.Tensor, out: Optional[torch.Tenso
     return out
 
 
+def advance_step(num_seqs: int, num_queries: int, block_size: int, seq_lens: torch.Tensor, slot_mapping: torch.Tensor,
+                 block_tables: torch.Tensor, input_tokens: Optional[torch.Tensor] = None,
+                 sampled_token_ids: Optional[torch.Tensor] = None, input_positions: Optional[torch.Tensor] = None) -> None:
+    """Multi-step decoding, in place and in one launch: sequence i < num_queries gets its sampled token as input, its
+    position (= its length so far), length + 1 and the cache slot of that position; padding rows get slot -1."""
+    _dev(seq_lens, slot_mapping, block_tables, input_tokens, sampled_token_ids, input_positions)
+    _require(seq_lens.dtype == torch.int32 and seq_lens.is_contiguous() and seq_lens.numel() >= num_seqs, "seq_lens must be contiguous int32 [num_seqs]")
+    _require(slot_mapping.dtype == torch.int64 and slot_mapping.is_contiguous() and slot_mapping.numel() >= num_seqs,
+             "slot_mapping must be contiguous int64 [num_seqs]")
+    _require(block_tables.dtype == torch.int32 and block_tables.dim() == 2 and block_tables.stride(1) == 1
+             and block_tables.shape[0] >= num_queries, "block_tables must be int32 [num_seqs, blocks]")
+    for name, t in (("input_tokens", input_tokens), ("input_positions", input_positions)):
+        _require(t is None or (t.dtype == torch.int64 and t.is_contiguous() and t.numel() >= num_queries), f"{name} must be contiguous int64")
+    if sampled_token_ids is not None:
+        sampled_token_ids = sampled_token_ids.reshape(-1)
+        _require(sampled_token_ids.dtype == torch.int64 and sampled_token_ids.is_contiguous() and sampled_token_ids.numel() >= num_queries,
+                 "sampled_token_ids must be contiguous int64 [num_queries(, 1)]")
+    _C.check(_C.load().hymeta_advance_step(num_seqs, num_queries, block_size, _p(input_tokens), _p(sampled_token_ids), _p(input_positions),
+                                           _p(seq_lens), _p(slot_mapping), _p(block_tables), block_tables.stride(0), _stream(seq_lens)),
+             "hymeta_advance_step")
+
+
 def argmax_rows(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Greedy sampling: int64 [M] indices of the largest fp32 logit of each row (the lowest index among equals)."""
     _dev(logits, out)
