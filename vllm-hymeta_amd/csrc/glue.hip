@@ -253,6 +253,11 @@ __global__ __launch_bounds__(256) void add_rmsnorm_partials_kernel(hymeta_add_rm
     }
     if (has_a) st16(out + 8 * ca, oa);
     if (has_b) st16(out + 8 * cb, ob);
+    if constexpr (Q) {       // the row is in registers: quantise it from there
+      const u32x4 rowv[2] = {oa, ob};
+      quantise_chunks_int8<2>(rowv, chunks, xq + t * a.hidden, x_scale + t, s_red);
+      return;
+    }
   } else {
     float ss = 0.f;
     for (int c = threadIdx.x; c < chunks; c += blockDim.x) {

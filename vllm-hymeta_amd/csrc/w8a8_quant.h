@@ -8,12 +8,10 @@
 namespace hymeta {
 
 // The row held in registers: NC chunks of 8 values per thread (chunks t, t + 256, ...), every load issued before the
-// first use (a loop over the chunks waits one cache round trip per chunk in each of its two passes), one read of x.
+// first use (a loop over the chunks waits one cache round trip per chunk in each of its two passes), one read of x --
+// or none, when the caller (a norm that has just formed the row) hands its registers over: quantise_chunks_int8.
 template <int NC>
-__device__ __forceinline__ void quantise_row_int8_regs(const uint16_t* x, int chunks, int8_t* q, float* scale_out, float* s_red) {
-  u32x4 v[NC];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) v[i] = ld16(x + 8 * min(static_cast<int>(threadIdx.x) + 256 * i, chunks - 1));
+__device__ __forceinline__ void quantise_chunks_int8(const u32x4 (&v)[NC], int chunks, int8_t* q, float* scale_out, float* s_red) {
   float mx = 0.f;
 #pragma unroll
   for (int i = 0; i < NC; ++i)
@@ -47,6 +45,14 @@ __device__ __forceinline__ void quantise_row_int8_regs(const uint16_t* x, int ch
     }
     *reinterpret_cast<u32x2*>(q + 8 * ch) = u32x2{w[0], w[1]};
   }
+}
+
+template <int NC>
+__device__ __forceinline__ void quantise_row_int8_regs(const uint16_t* x, int chunks, int8_t* q, float* scale_out, float* s_red) {
+  u32x4 v[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) v[i] = ld16(x + 8 * min(static_cast<int>(threadIdx.x) + 256 * i, chunks - 1));
+  quantise_chunks_int8<NC>(v, chunks, q, scale_out, s_red);
 }
 
 // One workgroup of 256 threads per row; thread t handles the 8-element chunks t, t + 256, ... in both passes (so a row
