@@ -54,6 +54,23 @@ def test_moe_forward(T, E, top_k, renorm, with_shared):
     assert_bf16_close(out.cpu(), ref, f"moe T={T} E={E} k={top_k}", rel=8e-3)
 
 
+@pytest.mark.parametrize("T,E,H,inter", [
+    (64, 16, 1024, 320),     # whole-line weight loads: 16 and 5 pairs of k-steps over the 4 waves (uneven shares)
+    (300, 16, 832, 448),     # the same with 64-row tiles: 13 and 7 pairs
+    (64, 16, 256, 160),      # K = 160 is no multiple of 64: the down GEMM takes the fragment-shaped loads
+    (3, 16, 64, 64),         # one pair: three of the four waves have no k-step at all
+])
+def test_moe_decode_gemm_k_shapes(T, E, H, inter):
+    from oracle.moe import moe_ref
+    from vllm_hymeta import hip_ops
+
+    x, gate_w, w13, w2, logits = _problem(5, T, H, inter, E)
+    ref = moe_ref(x, logits, w13, w2, 1, False, None)
+    out = hip_ops.moe_forward(x.cuda(), logits.cuda(), w13.cuda(), w2.cuda(), top_k=1)
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), ref, f"moe T={T} H={H} I={inter}", rel=8e-3)
+
+
 def test_moe_expert_parallel_shares_sum_to_the_whole():
     """Two expert-parallel ranks (emulated in one process): each computes only its experts' pairs;
     the sum of the two outputs (the layer's all-reduce) equals the single-rank result, and each

@@ -14,6 +14,9 @@
 //            (expert parallelism) carry pos = -1 and add nothing
 #include "common.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace hymeta {
 namespace {
 
@@ -185,6 +188,125 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(hymeta_moe_gemm_args a) {
           s += *reinterpret_cast<const f32x4*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kCols + 4 * cg);
         // routing weight applied to the fp32 sums, one rounding (as the fused expert kernel the
         // reference delegates to)
+        if (a.row_scale != nullptr) s *= a.row_scale[a.scale_rows != nullptr ? a.scale_rows[slot] : slot];
+        const u32x2 o = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(slot) * a.out_stride_m + col) = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// The same product for K a multiple of 64, with the weights fetched as whole 128-byte lines: a load
+// instruction of a wave covers 8 weight rows x 128 bytes (two 32-deep k-steps), lands in a wave-private
+// LDS image, and the MFMA B fragments are read back from there.  A load in fragment shape (16 rows x
+// 64 bytes) asks the memory system for half lines, and a CU keeps a fixed number of line requests in
+// flight whatever their size; whole lines carry twice the bytes per request.  The 16-byte pieces of a
+// row are XOR-ed with its row number on the way in, so that the fragment reads are free of bank
+// conflicts.  The 4 waves take alternate 64-deep pairs of k-steps.
+constexpr int kLineImageBytes = kCols * 128;   // per wave
+
+template <int MT>
+__global__ __launch_bounds__(256) void moe_gemm_lines_kernel(hymeta_moe_gemm_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s_red = reinterpret_cast<float*>(smem_raw);  // [4 waves][16 MT rows][64 cols], after the k loop
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int c = lane >> 4, n = lane & 15;
+  const int nb = blockIdx.x;
+  const int e = a.local_expert_begin + blockIdx.y;
+  const int row_lo = a.expert_offsets[e], row_hi = a.expert_offsets[e + 1];
+  if (row_lo >= row_hi) return;
+
+  char* img = smem_raw + wave * kLineImageBytes;
+  // load q of a pair covers image rows 8q .. 8q + 7; this lane: row 8q + (lane >> 3), piece
+  // (lane & 7) ^ swizzle(row within its 16-row fragment)
+  const int lr = lane >> 3, lp = lane & 7;
+  const uint16_t* wbase = reinterpret_cast<const uint16_t*>(a.weights) + static_cast<int64_t>(e) * a.w_stride_e +
+                          static_cast<int64_t>(nb * kCols + lr) * a.K;
+  const uint16_t* wld[2] = {wbase + 8 * (lp ^ (lr >> 1)), wbase + 8 * static_cast<int64_t>(a.K) + 8 * (lp ^ (4 + (lr >> 1)))};
+  const int64_t frag_stride = 16 * static_cast<int64_t>(a.K);
+  char* img_st = img + lane * 16;
+  const char* img_ld[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) img_ld[h] = img + n * 128 + (((4 * h + c) ^ ((n >> 1) & 7)) * 16);
+
+  const int pairs = a.K / 64;
+  const int nsteps = wave < pairs ? (pairs - wave + 3) / 4 : 0;   // this wave's pairs: wave, wave + 4, ...
+  const int last = nsteps - 1;
+
+  for (int r0 = row_lo; r0 < row_hi; r0 += 16 * MT) {
+    const uint16_t* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int slot = min(r0 + 16 * mt + n, row_hi - 1);   // rows past the expert's end re-read its last row
+      const int src = a.a_rows != nullptr ? a.a_rows[slot] / a.a_rows_div : slot;
+      xrow[mt] = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(src) * a.x_stride_m + 8 * c;
+    }
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[mt][i] = {0.f, 0.f, 0.f, 0.f};
+
+    // two register sets, unconditional loads (pairs past the end re-read the last pair)
+    u32x4 wa[8], xa[MT][2], wb[8], xb[MT][2];
+    auto load = [&](int s, u32x4 (&w)[8], u32x4 (&x)[MT][2]) {
+      const int k0 = 64 * (wave + 4 * min(s, last));
+#pragma unroll
+      for (int q = 0; q < 8; ++q) w[q] = ld16g(wld[q & 1] + (q >> 1) * frag_stride + k0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) x[mt][h] = ld16g(xrow[mt] + k0 + 32 * h);
+    };
+    auto fma_pair = [&](const u32x4 (&w)[8], const u32x4 (&x)[MT][2]) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) *reinterpret_cast<u32x4*>(img_st + q * 1024) = w[q];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const u32x4 b = *reinterpret_cast<const u32x4*>(img_ld[h] + i * 2048);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt][i] = mfma16(as_frag(x[mt][h]), as_frag(b), acc[mt][i]);
+        }
+    };
+    if (nsteps > 0) {
+      load(0, wa, xa);
+      for (int s = 0; s < nsteps; s += 2) {
+        load(s + 1, wb, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        fma_pair(wa, xa);
+        load(s + 2, wa, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nsteps) fma_pair(wb, xb);
+      }
+    }
+    __syncthreads();   // the images give way to the partial sums
+
+    // acc[mt][i][r] = C[row 16 mt + 4c + r][col 16 i + n]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          s_red[(static_cast<size_t>(wave) * 16 * MT + 16 * mt + 4 * c + r) * kCols + 16 * i + n] = acc[mt][i][r];
+    __syncthreads();
+    const int cg = tid & 15;
+    const int col = nb * kCols + 4 * cg;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int row = (tid >> 4) + 16 * j;
+      const int slot = r0 + row;
+      if (slot < row_hi) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          s += *reinterpret_cast<const f32x4*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kCols + 4 * cg);
         if (a.row_scale != nullptr) s *= a.row_scale[a.scale_rows != nullptr ? a.scale_rows[slot] : slot];
         const u32x2 o = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(slot) * a.out_stride_m + col) = o;
@@ -458,6 +580,16 @@ extern "C" int hymeta_moe_gemm(const hymeta_moe_gemm_args* args, hymeta_stream_t
       hipLaunchKernelGGL((moe_gemm_tiled_kernel<128, 128, 2, 2>), tgrid, dim3(256), 0, s, a);
       return launch_status();
     }
+  }
+  static const bool lines = [] {
+    const char* v = getenv("HYMETA_MOE_LINES");
+    return v == nullptr || atoi(v) != 0;
+  }();
+  if (lines && a.K % 64 == 0) {
+    const size_t images = 4 * static_cast<size_t>(kLineImageBytes);
+    if (small) hipLaunchKernelGGL((moe_gemm_lines_kernel<1>), grid, block, std::max(images, 4 * 16 * kCols * sizeof(float)), s, a);
+    else hipLaunchKernelGGL((moe_gemm_lines_kernel<4>), grid, block, std::max(images, 4 * 64 * kCols * sizeof(float)), s, a);
+    return launch_status();
   }
   if (small) hipLaunchKernelGGL((moe_gemm_kernel<1>), grid, block, 4 * 16 * kCols * sizeof(float), s, a);
   else hipLaunchKernelGGL((moe_gemm_kernel<4>), grid, block, 4 * 64 * kCols * sizeof(float), s, a);
