@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs")
     ap.add_argument("--tp-layers", type=int, default=28, help="tensor-parallel mode: layers of the 70B stack (28 = the model)")
     ap.add_argument("--tp-eager", action="store_true", help="tensor-parallel mode: launch the step eagerly instead of from a HIP graph")
+    ap.add_argument("--rccl-only", action="store_true",
+                    help="tensor-parallel mode: keep every all-reduce on RCCL (default: the small ones take the one-shot "
+                         "exchange over peer-mapped buffers when its self-check passes on every rank)")
     ap.add_argument("--force-tp", action="store_true",
                     help="run the tensor-parallel mode with whatever WORLD_SIZE the launcher set, 1 included (a one-GPU rehearsal "
                          "of the multi-GPU step: the collectives run over a one-rank group)")

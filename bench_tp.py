@@ -210,11 +210,13 @@ def collectives_alone(cfg, batch, group, dev, reps=5):
     y = torch.zeros(batch, cfg.hidden_size, dtype=torch.bfloat16, device=dev)
     gathered = torch.zeros(dist.get_world_size(group) * batch, 2, dtype=torch.float32, device=dev)
 
+    from vllm_hymeta import parallel
+
     def run():
         for _ in range(cfg.num_hidden_layers):
-            dist.all_reduce(stats, group=group)
-            dist.all_reduce(y, group=group)
-            dist.all_reduce(y, group=group)
+            parallel.all_reduce_variance(stats, group)      # the calls the layers make: one-shot exchange or RCCL
+            parallel.all_reduce_sum(y, group)
+            parallel.all_reduce_sum(y, group)
         dist.all_gather_into_tensor(gathered, stats, group=group)
 
     run()
@@ -272,6 +274,21 @@ def tp_main(args):
     if tp == 1:
         parallel.SINGLE_RANK_COLLECTIVES = True      # one-GPU rehearsal: keep the collectives in the step
 
+    # The layers' small all-reduces through the one-shot exchange over peer-mapped buffers, if it can be set up on every
+    # rank and reproduces the rank-ordered sums bit for bit here and now; RCCL otherwise (and for anything larger).
+    all_reduce_path, why = "rccl", "switched off (--rccl-only)"
+    if not args.rccl_only:
+        try:
+            parallel.enable_one_shot_all_reduce(tp_group, dev)
+            ok, why = parallel.one_shot_self_check(tp_group, dev)
+        except RuntimeError as exc:
+            ok, why = False, str(exc)
+        if ok:
+            all_reduce_path = "one-shot exchange over peer-mapped buffers (self-checked against rank-ordered sums); RCCL above 2 MiB"
+        else:
+            parallel.disable_one_shot_all_reduce(tp_group)
+    note(rank, f"all-reduce path: {all_reduce_path}" + ("" if all_reduce_path != "rccl" else f" ({why})"))
+
     batch, ctx, total = args.batch, args.ctx if args.ctx_given else 32768, args.warmup + args.steps
     note(rank, f"{world} ranks: tp{tp} x {replicas}; building the model")
     model, cfg = build_model_70b(dev, args.quant, batch, tp_group, args.tp_layers)
@@ -298,6 +315,11 @@ def tp_main(args):
     dist.all_reduce(c, op=dist.ReduceOp.MAX)
     coll_ms = float(c[0])
 
+    comm = parallel._ONE_SHOT.get(tp_group)
+    t = torch.tensor([float(comm.timeouts()) if comm is not None else 0.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    one_shot_timeouts = int(t[0])
+
     nbytes, parts = step_bytes_70b(cfg, args.quant, tp, batch, ctx, hit)
     achieved = nbytes / (gpu_ms * 1e-3) / 1e9
     line = {
@@ -317,7 +339,7 @@ def tp_main(args):
             "workload": f"Hymeta-70B {args.quant} TP={tp} decode, ctx {ctx}, block_size {B1.BLOCK}, {batch} sequences per replica; step = "
                         f"one token per sequence through {cfg.num_hidden_layers} layers of HymetaForCausalLM (embedding, norms, both "
                         "attention branches on the rank's heads, out_proj, dense MLP / 16-expert top-1 mixture + shared expert, final "
-                        "norm) with the three all-reduces of every layer on RCCL, then greedy sampling with the lm_head cut along "
+                        "norm) with the three all-reduces of every layer (config.all_reduce names their path), then greedy sampling with the lm_head cut along "
                         "the vocabulary (fp32 logits of the rank's rows, local argmax, one [B, 2] all-gather), fed back as the "
                         "next step's tokens.  "
                         "The N=1 line of this bench is the 7B model: a different workload, not the base of this curve",
@@ -329,6 +351,7 @@ def tp_main(args):
             "parallelism": f"tp{tp}" + (f" x {replicas} replicas" if replicas > 1 else ""),
             "rccl_ranks": world,
             "dist_backend": args.dist_backend,
+            "all_reduce": all_reduce_path,
             "graph": not args.tp_eager,
         },
         "collectives": {
@@ -337,6 +360,7 @@ def tp_main(args):
                         "all-gather of the ranks' best (logit, token) pairs",
             "ms_per_step_alone": round(coll_ms, 4),
             "share_of_step": round(coll_ms / gpu_ms, 4),
+            "one_shot_timeouts": one_shot_timeouts,      # not 0 = a wait for a peer ran into its limit: the line is void
         },
         "roofline": {
             "kernel": "whole decode step of one rank (one graph launch)",
@@ -354,5 +378,6 @@ def tp_main(args):
     }
     if rank == 0:
         print(json.dumps(line), flush=True)
+    parallel.disable_one_shot_all_reduce(tp_group)
     dist.barrier()
     dist.destroy_process_group()

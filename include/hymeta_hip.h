@@ -835,6 +835,47 @@ typedef struct hymeta_moe_combine_args {
 
 int hymeta_moe_combine(const hymeta_moe_combine_args* args, hymeta_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * One-shot all-reduce of the small messages of a tensor-parallel decode step over peer-mapped device
+ * memory (xGMI between the GPUs of a node): the row-parallel out_proj / down_proj outputs, bf16
+ * [<= 256, hidden], and the [T, 2] fp32 branch variances.  Replaces, for these sizes, vLLM's
+ * tensor_model_parallel_all_reduce as the reference calls it (vllm_hymeta/models/modeling_hymeta.py:
+ * 158-160 for the variances, 858-861 and the RowParallelLinear layers for the projections); larger
+ * messages stay with RCCL.  Every rank writes its message into a slot of every rank's exchange buffer,
+ * raises a flag there, waits for the flags of all ranks in its own buffer and adds the slots in rank
+ * order in fp32, rounding once: bit-identical results on all ranks.
+ *
+ *   hymeta_p2p_create            allocates this rank's exchange buffer (uncached device memory on the current device,
+ *                                room for messages of max_message_bytes) and, when ipc_handle is not NULL, writes its
+ *                                HYMETA_P2P_HANDLE_BYTES-byte HIP IPC handle there; world in {1, 2, 4, 8}
+ *   hymeta_p2p_connect           all_handles = the world handles in rank order (the caller gathers them, e.g. with an
+ *                                all-gather of its process group); maps the peers' buffers
+ *   hymeta_p2p_connect_pointers  the same for ranks that live in one process: buffers[q] = hymeta_p2p_local_buffer of
+ *                                rank q's communicator
+ *   hymeta_p2p_all_reduce        in place: data_bf16[0 .. n_bf16) and stats[0 .. n_stats) become their sums over the
+ *                                ranks, one exchange for both (either may be empty).  n_bf16 a multiple of 8, data 16-byte
+ *                                aligned; (n_stats * 4 rounded up to 16) + n_bf16 * 2 <= max_message_bytes, else
+ *                                HYMETA_ERR_SCRATCH_LIMIT.  One kernel launch, no host value that changes per call (the
+ *                                epoch lives in device memory), so a captured launch replays.  All ranks must make the
+ *                                same calls with the same sizes in the same order, and a rank's calls on one communicator
+ *                                must be ordered (one stream or one graph): calls that overlap on a rank race.
+ *   hymeta_p2p_set_wait_limit    bound of a wait for a peer in ticks of the 100 MHz wall clock (default 2 s).  A block
+ *                                that gives up counts a timeout and goes on with undefined output: every launch ends.
+ *   hymeta_p2p_timeouts          timeouts so far (reads device memory: synchronises; not for a captured region)
+ * -------------------------------------------------------------------------------------------- */
+#define HYMETA_P2P_HANDLE_BYTES 64
+typedef struct hymeta_p2p_comm hymeta_p2p_comm;
+
+int hymeta_p2p_create(int rank, int world, size_t max_message_bytes, hymeta_p2p_comm** comm, void* ipc_handle);
+void* hymeta_p2p_local_buffer(const hymeta_p2p_comm* comm);
+int hymeta_p2p_connect(hymeta_p2p_comm* comm, const void* all_handles);
+int hymeta_p2p_connect_pointers(hymeta_p2p_comm* comm, void* const* buffers);
+int hymeta_p2p_set_wait_limit(hymeta_p2p_comm* comm, uint64_t ticks_100mhz);
+int hymeta_p2p_all_reduce(hymeta_p2p_comm* comm, void* data_bf16, int64_t n_bf16, float* stats, int64_t n_stats,
+                          hymeta_stream_t stream);
+int hymeta_p2p_timeouts(hymeta_p2p_comm* comm, uint32_t* count);
+int hymeta_p2p_destroy(hymeta_p2p_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,3 +112,45 @@ def test_world_size_2_gloo_layer_collectives():
         ret = m.dict()
         mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
         assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def _order_worker(rank, world, port, ret):
+    """The sum the one-shot exchange computes (rank order, fp32, one rounding) against the group's own all-reduce, on the
+    decode step's messages; with no exchange registered for the group the collectives stay on the backend."""
+    from vllm_hymeta import parallel
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tp = dist.group.WORLD
+        assert parallel._ONE_SHOT.get(tp) is None
+        g = torch.Generator().manual_seed(100 + rank)
+        for rows in (1, 64):
+            x = torch.randn(rows, 3584, generator=g).to(torch.bfloat16)
+            st = torch.rand(rows, 2, generator=g)
+            gx = [torch.empty_like(x) for _ in range(world)]
+            gs = [torch.empty_like(st) for _ in range(world)]
+            dist.all_gather(gx, x)
+            dist.all_gather(gs, st)
+            ref_x = parallel.one_shot_reduce_ref(gx, torch.bfloat16)
+            ref_s = parallel.one_shot_reduce_ref(gs, torch.float32)
+            # two addends: the backend's bf16 sum is the correctly rounded sum too, whatever its order
+            assert torch.equal(all_reduce_sum(x.clone(), tp), ref_x)
+            assert torch.equal(all_reduce_variance(st.clone(), tp), ref_s / world)
+            # every rank computes the same bits from the same gathered messages
+            mine = ref_x.float().sum().reshape(1)
+            both = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            assert torch.equal(both[0], both[1])
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_shot_sum_order_equals_the_group_all_reduce_on_two_ranks():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_order_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok"}

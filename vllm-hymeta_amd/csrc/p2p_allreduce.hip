@@ -1,0 +1,295 @@
+// One-shot all-reduce for the small messages of a tensor-parallel decode step (the row-parallel
+// out_proj / down_proj outputs, [<= 256, hidden] bf16, and the [T, 2] fp32 branch variances;
+// reference: vllm_hymeta/models/modeling_hymeta.py:158-160,858-861, where vLLM's
+// tensor_model_parallel_all_reduce carries them).  A ring moves such a message in 2 (W - 1) hops of
+// a few microseconds each; here every rank writes its message straight into a slot of every peer's
+// exchange buffer over xGMI (one hop), raises a flag there, waits for the W flags in its OWN buffer
+// and sums the W slots in rank order.  Every rank adds the same values in the same order in fp32 and
+// rounds once, so the results are bit-identical on all ranks.
+//
+//   exchange buffer of a rank (device memory allocated uncached, so that neither the writer's nor the
+//   reader's L2 keeps lines of it; mapped into the peers through HIP IPC handles):
+//     flags [2 parities][kMaxWorld][kMaxBlocks] u32     the epoch a (rank, block) has delivered
+//     slots [2 parities][W][slot_bytes]                 the messages, fp32 part first, then bf16
+//   state of a rank (ordinary device memory, local): epoch, block ticket, timeouts
+//
+// The epoch lives in device memory and is advanced by the kernel itself (the last block of a launch),
+// so a launch carries no per-call host value and replays from a HIP graph.  Two parities are enough:
+// a rank can push epoch e + 2 only after its launch e + 1 has ended, which needed every peer's
+// flag e + 1, which a peer raises only in a launch that follows the end of its launch e, the last
+// reader of the parity's slots.  That argument needs the launches of one communicator to be ordered on
+// every rank (one stream, or one graph): calls that overlap on a rank race.
+//
+// Every wait is bounded by wall-clock ticks; a block that gives up counts a timeout in the state and
+// goes on (its output is then undefined), so that every launch ends whatever the peers do.
+#include "common.h"
+
+#include <cstring>
+#include <new>
+
+namespace hymeta {
+namespace {
+
+constexpr int kMaxWorld = 8;
+constexpr int kMaxBlocks = 64;
+constexpr int kThreads = 256;
+constexpr size_t kFlagBytes = 2ull * kMaxWorld * kMaxBlocks * sizeof(uint32_t);   // 4 KB
+constexpr uint64_t kDefaultSpinTicks = 200000000ull;   // 2 s of the 100 MHz wall clock
+
+struct P2pArgs {
+  char* peers[kMaxWorld];
+  uint32_t* state;          // [0] epoch, [1] ticket, [2] timeouts
+  uint16_t* data;           // bf16, n8 units of 8
+  float* stats;             // fp32, n_stats values
+  int64_t n_stats, units_stats, units;   // units of 16 bytes: the fp32 part first
+  int64_t slot_bytes;
+  uint64_t spin_ticks;
+  int rank, units_per_block;
+};
+
+__device__ __forceinline__ uint32_t* flag_ptr(char* buf, int parity, int rank, int block) {
+  return reinterpret_cast<uint32_t*>(buf) + (static_cast<size_t>(parity) * kMaxWorld + rank) * kMaxBlocks + block;
+}
+
+template <int W>
+__global__ __launch_bounds__(kThreads) void p2p_all_reduce_kernel(P2pArgs a) {
+  __shared__ uint32_t s_epoch;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  if (tid == 0) s_epoch = __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  __syncthreads();
+  const uint32_t epoch = s_epoch;
+  const int parity = epoch & 1;
+  const int64_t u_lo = static_cast<int64_t>(b) * a.units_per_block;
+  const int64_t u_hi = min(u_lo + a.units_per_block, a.units);
+  const size_t slots = kFlagBytes + static_cast<size_t>(parity) * W * a.slot_bytes;
+
+  // push this block's share of the message into slot [rank] of every rank's buffer (its own too)
+  for (int64_t u = u_lo + tid; u < u_hi; u += kThreads) {
+    u32x4 v;
+    if (u < a.units_stats) {
+      float f[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[i] = 4 * u + i < a.n_stats ? a.stats[4 * u + i] : 0.f;
+      v = {__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+    } else {
+      v = ld16g(a.data + 8 * (u - a.units_stats));
+    }
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      const int peer = (a.rank + q) % W;     // start with the own buffer, spread the first remote writes over the links
+      *reinterpret_cast<u32x4*>(a.peers[peer] + slots + static_cast<size_t>(a.rank) * a.slot_bytes + 16 * u) = v;
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < W) {
+    __hip_atomic_store(flag_ptr(a.peers[tid], parity, a.rank, b), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // wait for rank tid's share of this block in the own buffer
+    uint32_t* flag = flag_ptr(a.peers[a.rank], parity, tid, b);
+    const uint64_t t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+      if (wall_clock64() - t0 > a.spin_ticks) {
+        atomicAdd(a.state + 2, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+
+  // sum the W slots in rank order
+  const char* mine = a.peers[a.rank] + slots;
+  for (int64_t u = u_lo + tid; u < u_hi; u += kThreads) {
+    u32x4 v[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) v[q] = ld16g(mine + static_cast<size_t>(q) * a.slot_bytes + 16 * u);
+    if (u < a.units_stats) {
+      float f[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < W; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] += __uint_as_float(v[q][i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * u + i < a.n_stats) a.stats[4 * u + i] = f[i];
+    } else {
+      float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < W; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f[2 * i] += lo_bf(v[q][i]);
+          f[2 * i + 1] += hi_bf(v[q][i]);
+        }
+      const u32x4 o = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+      *reinterpret_cast<u32x4*>(a.data + 8 * (u - a.units_stats)) = o;
+    }
+  }
+
+  // the last block of the launch advances the epoch and puts the ticket back
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t t = atomicAdd(a.state + 1, 1u);
+    if (t == gridDim.x - 1) {
+      __hip_atomic_store(a.state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.state, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace
+}  // namespace hymeta
+
+struct hymeta_p2p_comm {
+  int rank = 0, world = 0, device = 0;
+  size_t max_bytes = 0, slot_bytes = 0, buffer_bytes = 0;
+  char* peers[hymeta::kMaxWorld] = {};
+  bool opened[hymeta::kMaxWorld] = {};
+  bool connected = false;
+  uint32_t* state = nullptr;
+  uint64_t spin_ticks = hymeta::kDefaultSpinTicks;
+};
+
+extern "C" int hymeta_p2p_create(int rank, int world, size_t max_message_bytes, hymeta_p2p_comm** comm, void* ipc_handle) {
+  using namespace hymeta;
+  if (comm == nullptr || world < 1 || world > kMaxWorld || rank < 0 || rank >= world || max_message_bytes == 0)
+    return HYMETA_ERR_INVALID_ARG;
+  if (world != 1 && world != 2 && world != 4 && world != 8) return HYMETA_ERR_UNSUPPORTED;
+  static_assert(sizeof(hipIpcMemHandle_t) == HYMETA_P2P_HANDLE_BYTES, "IPC handle size");
+  hymeta_p2p_comm* c = new (std::nothrow) hymeta_p2p_comm();
+  if (c == nullptr) return HYMETA_ERR_WORKSPACE;
+  c->rank = rank;
+  c->world = world;
+  c->max_bytes = max_message_bytes;
+  c->slot_bytes = (max_message_bytes + 255) / 256 * 256;
+  c->buffer_bytes = kFlagBytes + 2 * static_cast<size_t>(world) * c->slot_bytes;
+  void* buf = nullptr;
+  if (hipGetDevice(&c->device) != hipSuccess ||
+      hipExtMallocWithFlags(&buf, c->buffer_bytes, hipDeviceMallocUncached) != hipSuccess) {
+    delete c;
+    return HYMETA_ERR_WORKSPACE;
+  }
+  c->peers[rank] = static_cast<char*>(buf);
+  if (hipMalloc(reinterpret_cast<void**>(&c->state), 4 * sizeof(uint32_t)) != hipSuccess ||
+      hipMemset(c->state, 0, 4 * sizeof(uint32_t)) != hipSuccess || hipMemset(buf, 0, kFlagBytes) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(buf);
+    if (c->state) (void)hipFree(c->state);
+    delete c;
+    return HYMETA_ERR_WORKSPACE;
+  }
+  if (ipc_handle != nullptr) {
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, buf) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(buf);
+      (void)hipFree(c->state);
+      delete c;
+      return HYMETA_ERR_UNSUPPORTED;
+    }
+    memcpy(ipc_handle, &h, sizeof(h));
+  }
+  *comm = c;
+  return HYMETA_OK;
+}
+
+extern "C" void* hymeta_p2p_local_buffer(const hymeta_p2p_comm* comm) {
+  return comm != nullptr ? comm->peers[comm->rank] : nullptr;
+}
+
+extern "C" int hymeta_p2p_connect(hymeta_p2p_comm* comm, const void* all_handles) {
+  using namespace hymeta;
+  if (comm == nullptr || all_handles == nullptr || comm->connected) return HYMETA_ERR_INVALID_ARG;
+  for (int q = 0; q < comm->world; ++q) {
+    if (q == comm->rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, static_cast<const char*>(all_handles) + static_cast<size_t>(q) * sizeof(h), sizeof(h));
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || p == nullptr) {
+      (void)hipGetLastError();
+      for (int r = 0; r < q; ++r)
+        if (comm->opened[r]) {
+          (void)hipIpcCloseMemHandle(comm->peers[r]);
+          comm->opened[r] = false;
+          comm->peers[r] = nullptr;
+        }
+      return HYMETA_ERR_UNSUPPORTED;
+    }
+    comm->peers[q] = static_cast<char*>(p);
+    comm->opened[q] = true;
+  }
+  comm->connected = true;
+  return HYMETA_OK;
+}
+
+extern "C" int hymeta_p2p_connect_pointers(hymeta_p2p_comm* comm, void* const* buffers) {
+  if (comm == nullptr || buffers == nullptr || comm->connected) return HYMETA_ERR_INVALID_ARG;
+  for (int q = 0; q < comm->world; ++q) {
+    if (buffers[q] == nullptr) return HYMETA_ERR_INVALID_ARG;
+    if (q == comm->rank) {
+      if (buffers[q] != comm->peers[q]) return HYMETA_ERR_INVALID_ARG;
+      continue;
+    }
+    comm->peers[q] = static_cast<char*>(buffers[q]);
+  }
+  comm->connected = true;
+  return HYMETA_OK;
+}
+
+extern "C" int hymeta_p2p_set_wait_limit(hymeta_p2p_comm* comm, uint64_t ticks_100mhz) {
+  if (comm == nullptr || ticks_100mhz == 0) return HYMETA_ERR_INVALID_ARG;
+  comm->spin_ticks = ticks_100mhz;
+  return HYMETA_OK;
+}
+
+extern "C" int hymeta_p2p_all_reduce(hymeta_p2p_comm* comm, void* data_bf16, int64_t n_bf16, float* stats, int64_t n_stats,
+                                     hymeta_stream_t stream) {
+  using namespace hymeta;
+  if (comm == nullptr || n_bf16 < 0 || n_stats < 0) return HYMETA_ERR_INVALID_ARG;
+  if (!comm->connected) return HYMETA_ERR_INVALID_ARG;
+  if ((n_bf16 > 0 && data_bf16 == nullptr) || (n_stats > 0 && stats == nullptr)) return HYMETA_ERR_INVALID_ARG;
+  if (n_bf16 == 0 && n_stats == 0) return HYMETA_OK;
+  if (n_bf16 % 8 != 0 || reinterpret_cast<uintptr_t>(data_bf16) % 16 != 0 || reinterpret_cast<uintptr_t>(stats) % 4 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  P2pArgs a;
+  a.units_stats = (n_stats + 3) / 4;
+  a.units = a.units_stats + n_bf16 / 8;
+  if (static_cast<size_t>(a.units) * 16 > comm->max_bytes) return HYMETA_ERR_SCRATCH_LIMIT;
+  for (int q = 0; q < kMaxWorld; ++q) a.peers[q] = q < comm->world ? comm->peers[q] : nullptr;
+  a.state = comm->state;
+  a.data = static_cast<uint16_t*>(data_bf16);
+  a.stats = stats;
+  a.n_stats = n_stats;
+  a.slot_bytes = static_cast<int64_t>(comm->slot_bytes);
+  a.spin_ticks = comm->spin_ticks;
+  a.rank = comm->rank;
+  // 4 units per thread and block at least; every rank derives the same grid from the same sizes
+  const int64_t want = (a.units + 4 * kThreads - 1) / (4 * kThreads);
+  const int blocks = static_cast<int>(want < 1 ? 1 : want > kMaxBlocks ? kMaxBlocks : want);
+  a.units_per_block = static_cast<int>((a.units + blocks - 1) / blocks);
+  hipStream_t s = begin_launches(stream);
+  switch (comm->world) {
+    case 1: hipLaunchKernelGGL((p2p_all_reduce_kernel<1>), dim3(blocks), dim3(kThreads), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((p2p_all_reduce_kernel<2>), dim3(blocks), dim3(kThreads), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((p2p_all_reduce_kernel<4>), dim3(blocks), dim3(kThreads), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((p2p_all_reduce_kernel<8>), dim3(blocks), dim3(kThreads), 0, s, a); break;
+    default: return HYMETA_ERR_UNSUPPORTED;
+  }
+  return launch_status();
+}
+
+extern "C" int hymeta_p2p_timeouts(hymeta_p2p_comm* comm, uint32_t* count) {
+  if (comm == nullptr || count == nullptr) return HYMETA_ERR_INVALID_ARG;
+  return hipMemcpy(count, comm->state + 2, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? HYMETA_OK : HYMETA_ERR_LAUNCH;
+}
+
+extern "C" int hymeta_p2p_destroy(hymeta_p2p_comm* comm) {
+  if (comm == nullptr) return HYMETA_OK;
+  (void)hipDeviceSynchronize();
+  for (int q = 0; q < comm->world; ++q)
+    if (comm->opened[q]) (void)hipIpcCloseMemHandle(comm->peers[q]);
+  if (comm->peers[comm->rank]) (void)hipFree(comm->peers[comm->rank]);
+  if (comm->state) (void)hipFree(comm->state);
+  delete comm;
+  return HYMETA_OK;
+}

@@ -258,6 +258,14 @@ _SIGNATURES = {
     "hymeta_argmax_rows": (C.c_int, [_ptr, _i64, _i32, _i32, _ptr, _ptr, _sz, _ptr]),
     "hymeta_argmax_rows_workspace_bytes": (_sz, [_i32]),
     "hymeta_advance_step": (C.c_int, [_i32, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
+    "hymeta_p2p_create": (C.c_int, [C.c_int, C.c_int, _sz, C.POINTER(_ptr), _ptr]),
+    "hymeta_p2p_local_buffer": (_ptr, [_ptr]),
+    "hymeta_p2p_connect": (C.c_int, [_ptr, _ptr]),
+    "hymeta_p2p_connect_pointers": (C.c_int, [_ptr, C.POINTER(_ptr)]),
+    "hymeta_p2p_set_wait_limit": (C.c_int, [_ptr, C.c_uint64]),
+    "hymeta_p2p_all_reduce": (C.c_int, [_ptr, _ptr, _i64, _ptr, _i64, _ptr]),
+    "hymeta_p2p_timeouts": (C.c_int, [_ptr, C.POINTER(C.c_uint32)]),
+    "hymeta_p2p_destroy": (C.c_int, [_ptr]),
     "hymeta_bf16_gemm_deferred": (C.c_int, [C.POINTER(Bf16GemmArgs), C.POINTER(GemmPartials), _ptr]),
     "hymeta_w8a8_gemm_deferred": (C.c_int, [C.POINTER(W8A8GemmArgs), C.POINTER(GemmPartials), _ptr]),
     "hymeta_gptq_gemm_deferred": (C.c_int, [C.POINTER(GptqGemmArgs), C.POINTER(GemmPartials), _ptr]),

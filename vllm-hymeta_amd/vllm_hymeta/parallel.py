@@ -58,11 +58,201 @@ def _active(group: Optional[dist.ProcessGroup]) -> bool:
     return dist.get_world_size(group) > 1 or SINGLE_RANK_COLLECTIVES
 
 
+# Messages up to this size take the one-shot exchange when a group has one (``enable_one_shot_all_reduce``):
+# [256, 3584] bf16 with its [256, 2] fp32 statistics fits; anything larger stays with RCCL, whose rings win there.
+ONE_SHOT_MAX_BYTES = 2 * 1024 * 1024
+
+
+class OneShotAllReduce:
+    """One rank's end of the one-shot all-reduce over peer-mapped device memory (``hymeta_p2p_*``): every rank writes
+    its message into a slot of every rank's exchange buffer, raises a flag, waits for all flags in its own buffer and
+    adds the slots in rank order in fp32 -- one hop over xGMI where a ring takes 2 (W - 1), and bit-identical results
+    on all ranks.  Stands in, for the decode step's small messages, for the ``tensor_model_parallel_all_reduce`` calls
+    of the reference (``vllm_hymeta/models/modeling_hymeta.py:158-160,858-861``).
+
+    Build with ``for_group`` (one process per GPU; the IPC handles travel through the process group) or
+    ``in_process`` (all ranks in one process, e.g. on the streams of one GPU).  All ranks make the same calls in the
+    same order; a rank's calls must be ordered on one stream (or inside one graph)."""
+
+    def __init__(self, rank: int, world: int, device: torch.device, max_bytes: int = ONE_SHOT_MAX_BYTES):
+        import ctypes as C
+
+        from . import _C
+        self._lib, self._C, self._check = _C.load(), C, _C.check
+        self.rank, self.world, self.device, self.max_bytes = rank, world, torch.device(device), int(max_bytes)
+        self._comm = C.c_void_p()
+        handle = (C.c_ubyte * 64)()
+        with torch.cuda.device(self.device):
+            self._check(self._lib.hymeta_p2p_create(rank, world, self.max_bytes, C.byref(self._comm), handle), "hymeta_p2p_create")
+        self.handle = bytes(handle)
+        self.group = None
+
+    @classmethod
+    def for_group(cls, group: dist.ProcessGroup, device: torch.device, max_bytes: int = ONE_SHOT_MAX_BYTES) -> "OneShotAllReduce":
+        """Collective over the group.  A failure on any rank (no uncached memory, a handle that cannot be mapped) raises
+        RuntimeError on EVERY rank, after the same collectives, so that the callers fall back together."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        on_device = dist.get_backend(group) == "nccl"       # gloo moves host tensors only
+        where = torch.device(device) if on_device else torch.device("cpu")
+        self, err = None, ""
+        try:
+            self = cls(rank, world, device, max_bytes)
+            self.group = group
+        except Exception as exc:
+            err = f"rank {rank}: {exc}"
+        mine = torch.tensor(list(self.handle if self is not None else bytes(64)) + [0 if err else 1], dtype=torch.uint8).to(where)
+        gathered = torch.empty(world * 65, dtype=torch.uint8, device=where)
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+        rows = gathered.cpu().view(world, 65)
+        if bool(rows[:, 64].all()):
+            try:
+                with torch.cuda.device(self.device):
+                    self._check(self._lib.hymeta_p2p_connect(self._comm, bytes(rows[:, :64].reshape(-1).tolist())), "hymeta_p2p_connect")
+            except Exception as exc:
+                err = f"rank {rank}: {exc}"
+        elif not err:
+            err = "another rank could not create its exchange buffer"
+        ok = torch.tensor([0.0 if err else 1.0], device=where)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)      # also the barrier before the first exchange
+        if ok.item() != 1.0:
+            if self is not None:
+                self.group = None
+                self.close()
+            raise RuntimeError(f"one-shot all-reduce unavailable: {err or 'another rank could not map the exchange buffers'}")
+        return self
+
+    @classmethod
+    def in_process(cls, world: int, device: torch.device, max_bytes: int = ONE_SHOT_MAX_BYTES) -> list:
+        ranks = [cls(r, world, device, max_bytes) for r in range(world)]
+        C = ranks[0]._C
+        buffers = (C.c_void_p * world)(*[r._lib.hymeta_p2p_local_buffer(r._comm) for r in ranks])
+        for r in ranks:
+            r._check(r._lib.hymeta_p2p_connect_pointers(r._comm, buffers), "hymeta_p2p_connect_pointers")
+        return ranks
+
+    def supports(self, data: Optional[torch.Tensor], stats: Optional[torch.Tensor] = None) -> bool:
+        nbytes = 0
+        if data is not None:
+            if not (data.is_cuda and data.dtype == torch.bfloat16 and data.is_contiguous() and data.numel() % 8 == 0
+                    and data.data_ptr() % 16 == 0):
+                return False
+            nbytes += data.numel() * 2
+        if stats is not None:
+            if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous()):
+                return False
+            nbytes += (stats.numel() * 4 + 15) // 16 * 16
+        return 0 < nbytes <= self.max_bytes
+
+    def all_reduce(self, data: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None) -> None:
+        """``data`` (bf16) and ``stats`` (fp32) become their sums over the ranks, in place, in one exchange, on the
+        current stream of their device."""
+        if not self.supports(data, stats):
+            raise ValueError("one-shot all-reduce: contiguous bf16 data (a multiple of 8 values) and / or fp32 statistics "
+                             f"on the GPU, {self.max_bytes} bytes at most")
+        t = data if data is not None else stats
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        self._check(self._lib.hymeta_p2p_all_reduce(self._comm, data.data_ptr() if data is not None else None,
+                                                    data.numel() if data is not None else 0,
+                                                    stats.data_ptr() if stats is not None else None,
+                                                    stats.numel() if stats is not None else 0, stream), "hymeta_p2p_all_reduce")
+
+    def set_wait_limit(self, seconds: float) -> None:
+        self._check(self._lib.hymeta_p2p_set_wait_limit(self._comm, max(1, int(seconds * 1e8))), "hymeta_p2p_set_wait_limit")
+
+    def timeouts(self) -> int:
+        """Waits for a peer that ran into their time limit so far (synchronises the device)."""
+        n = self._C.c_uint32(0)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.hymeta_p2p_timeouts(self._comm, self._C.byref(n)), "hymeta_p2p_timeouts")
+        return int(n.value)
+
+    def close(self) -> None:
+        if self._comm:
+            if self.group is not None:
+                torch.cuda.synchronize(self.device)
+                dist.barrier(group=self.group)      # no peer writes into a buffer that is going away
+            with torch.cuda.device(self.device):
+                self._lib.hymeta_p2p_destroy(self._comm)
+            self._comm = None
+
+
+_ONE_SHOT: dict = {}
+
+
+def enable_one_shot_all_reduce(group: dist.ProcessGroup, device: torch.device, max_bytes: int = ONE_SHOT_MAX_BYTES) -> OneShotAllReduce:
+    """From now on ``all_reduce_sum`` / ``all_reduce_variance`` over ``group`` send what fits through the one-shot
+    exchange.  Collective over the group (every rank calls it)."""
+    if group not in _ONE_SHOT:
+        _ONE_SHOT[group] = OneShotAllReduce.for_group(group, device, max_bytes)
+    return _ONE_SHOT[group]
+
+
+def disable_one_shot_all_reduce(group: dist.ProcessGroup) -> None:
+    comm = _ONE_SHOT.pop(group, None)
+    if comm is not None:
+        comm.close()
+
+
+def one_shot_reduce_ref(parts, dtype):
+    """What the exchange computes from the ranks' messages: the sum in rank order in fp32, rounded once."""
+    acc = torch.zeros_like(parts[0], dtype=torch.float32)
+    for p in parts:
+        acc = acc + p.float()
+    return acc.to(dtype)
+
+
+def one_shot_self_check(group: dist.ProcessGroup, device: torch.device, rows=(1, 64, 256), hidden: int = 3584,
+                        rounds: int = 3) -> Tuple[bool, str]:
+    """Run the group's one-shot exchange on random messages of the decode step's shapes and compare, on every rank, with
+    the rank-ordered sum of the all-gathered inputs (RCCL) -- bit for bit -- and with zero timeouts.  Returns the same
+    verdict on all ranks."""
+    comm = _ONE_SHOT.get(group)
+    if comm is None:
+        return False, "not enabled"
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    why = ""
+    on_device = dist.get_backend(group) == "nccl"
+
+    def gather(t):       # gloo moves host tensors only
+        mine = t if on_device else t.cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        return [p.to(device) for p in parts]
+
+    try:
+        for it in range(rounds):
+            for r in rows:
+                x = torch.randn(r, hidden, generator=gen).to(torch.bfloat16).to(device)
+                st = torch.rand(r, 2, generator=gen).to(device)
+                gx, gs = gather(x), gather(st)
+                comm.all_reduce(stats=st)
+                comm.all_reduce(data=x)
+                both_x, both_s = gx[rank].clone(), gs[rank].clone()
+                comm.all_reduce(data=both_x, stats=both_s)
+                torch.cuda.synchronize(device)
+                rx, rs = one_shot_reduce_ref(gx, torch.bfloat16), one_shot_reduce_ref(gs, torch.float32)
+                if not (torch.equal(x, rx) and torch.equal(st, rs) and torch.equal(both_x, rx) and torch.equal(both_s, rs)):
+                    why = why or f"rank {rank}: [{r}, {hidden}] round {it} differs from the rank-ordered sum"
+        if comm.timeouts() != 0:
+            why = why or f"rank {rank}: {comm.timeouts()} waits timed out"
+    except Exception as exc:      # an error on one rank must not leave the others in a collective
+        why = f"rank {rank}: {type(exc).__name__}: {exc}"
+    ok = torch.tensor([0.0 if why else 1.0], device=device if on_device else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    good = bool(ok.item() == 1.0)
+    return good, ("" if good else (why or "another rank failed the check"))
+
+
 def all_reduce_sum(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """Sum over the tensor-parallel group, in place (the reduction behind ``RowParallelLinear``:
     ``out_proj`` / ``o_proj`` / ``down_proj``).  No-op for a single rank or without a group."""
     if _active(group):
-        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+        comm = _ONE_SHOT.get(group)
+        if comm is not None and comm.supports(x):
+            comm.all_reduce(data=x)
+        else:
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
     return x
 
 
@@ -71,7 +261,11 @@ def all_reduce_variance(stats: torch.Tensor, group: Optional[dist.ProcessGroup] 
     returns the mean over the full hidden size (sum over ranks / tp), one message for both norms
     where the reference sends two ``[T, 1]`` ones (``modeling_hymeta.py:158-160``)."""
     if _active(group):
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        comm = _ONE_SHOT.get(group)
+        if comm is not None and comm.supports(None, stats):
+            comm.all_reduce(stats=stats)
+        else:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
         stats /= dist.get_world_size(group)
     return stats
 
