@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs")
     ap.add_argument("--tp-layers", type=int, default=28, help="tensor-parallel mode: layers of the 70B stack (28 = the model)")
     ap.add_argument("--tp-eager", action="store_true", help="tensor-parallel mode: launch the step eagerly instead of from a HIP graph")
+    ap.add_argument("--emulate-tp", type=int, default=0, choices=[0, 2, 4],
+                    help="with --force-tp on one GPU: build and run rank 0's shard of a group of this size (weight cuts, heads, "
+                         "expert shares of one rank; the collectives run as one-rank exchanges) -- timing of one rank's kernels "
+                         "at the real shard shapes, not a throughput of the job")
     ap.add_argument("--rccl-only", action="store_true",
                     help="tensor-parallel mode: keep every all-reduce on RCCL (default: the small ones take the one-shot "
                          "exchange over peer-mapped buffers when its self-check passes on every rank)")

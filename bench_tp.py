@@ -112,8 +112,10 @@ class VocabParallelGreedy:
     [B, 2] fp32 all-gather -- instead of gathering [B, V] logits, which greedy sampling does not need.  The lowest rank
     wins among equal values, i.e. the lowest index, as a single argmax would."""
 
-    def __init__(self, model, group, rank_in_group, tp, batch, dev):
+    def __init__(self, model, group, rank_in_group, tp, batch, dev, ranks_in_exchange=None):
         from vllm_hymeta import parallel
+
+        n = ranks_in_exchange or tp           # differs from tp only when one process rehearses a larger group's shard
 
         V = model._lm_head.shape[0]
         assert V % (64 * tp) == 0, "vocabulary must cut into multiples of 64 rows"
@@ -123,8 +125,8 @@ class VocabParallelGreedy:
         self.group, self.tp = group, tp
         self.exchange = tp > 1 or parallel.SINGLE_RANK_COLLECTIVES
         self.pair = torch.zeros(batch, 2, dtype=torch.float32, device=dev)
-        self.flat = torch.zeros(tp * batch, 2, dtype=torch.float32, device=dev)     # the ranks' pairs, rank-major
-        self.all = self.flat.view(tp, batch, 2)
+        self.flat = torch.zeros(n * batch, 2, dtype=torch.float32, device=dev)     # the ranks' pairs, rank-major
+        self.all = self.flat.view(n, batch, 2)
         self.rows = torch.arange(batch, device=dev)
 
     def __call__(self, hidden, out_ids):
@@ -273,6 +275,10 @@ def tp_main(args):
     tp_group = groups[rank // tp]
     if tp == 1:
         parallel.SINGLE_RANK_COLLECTIVES = True      # one-GPU rehearsal: keep the collectives in the step
+    shard_tp = tp
+    if world == 1 and args.emulate_tp:
+        shard_tp = args.emulate_tp
+        parallel.EMULATED_TP = (0, shard_tp)         # rank 0's shard of a larger group, collectives as one-rank exchanges
 
     # The layers' small all-reduces through the one-shot exchange over peer-mapped buffers, if it can be set up on every
     # rank and reproduces the rank-ordered sums bit for bit here and now; RCCL otherwise (and for anything larger).
@@ -293,7 +299,7 @@ def tp_main(args):
     note(rank, f"{world} ranks: tp{tp} x {replicas}; building the model")
     model, cfg = build_model_70b(dev, args.quant, batch, tp_group, args.tp_layers)
     runner = B1.DecodeRunner(model, batch, ctx, total + 8, dev, seed=rank // tp)
-    runner.sampler = VocabParallelGreedy(model, tp_group, rank % tp, tp, batch, dev)
+    runner.sampler = VocabParallelGreedy(model, tp_group, rank % tp, shard_tp, batch, dev, ranks_in_exchange=tp)
     hit = experts_hit(model, runner)
     note(rank, f"model built ({torch.cuda.memory_allocated(dev) / 2 ** 30:.1f} GiB allocated), experts hit {hit}")
     if args.tp_eager:
@@ -320,7 +326,7 @@ def tp_main(args):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     one_shot_timeouts = int(t[0])
 
-    nbytes, parts = step_bytes_70b(cfg, args.quant, tp, batch, ctx, hit)
+    nbytes, parts = step_bytes_70b(cfg, args.quant, shard_tp, batch, ctx, hit)
     achieved = nbytes / (gpu_ms * 1e-3) / 1e9
     line = {
         "metric": "decode output tokens/s (whole model step)",
@@ -348,7 +354,9 @@ def tp_main(args):
             "ctx": ctx,
             "linears": args.quant,
             "layers": cfg.num_hidden_layers,
-            "parallelism": f"tp{tp}" + (f" x {replicas} replicas" if replicas > 1 else ""),
+            "parallelism": f"tp{tp}" + (f" x {replicas} replicas" if replicas > 1 else "") +
+                           (f"; REHEARSAL of rank 0's shard of tp{shard_tp} on one GPU (one rank's kernels at the shard shapes, "
+                            "collectives as one-rank exchanges): not a throughput of the job" if shard_tp != tp else ""),
             "rccl_ranks": world,
             "dist_backend": args.dist_backend,
             "all_reduce": all_reduce_path,

@@ -49,10 +49,18 @@ def shard_heads(total_heads: int, total_kv_heads: int, tp_size: int, tp_rank: in
 SINGLE_RANK_COLLECTIVES = False
 
 
+# Rehearsal switch: (rank, size) that ``tp_rank_and_size`` reports for any group, so that ONE process builds and runs
+# the shard of one rank of a larger tensor-parallel group (its weight cuts, head counts and expert shares) with the
+# collectives running over the real, smaller group.  Results are one rank's partial sums: for timing and profiling only.
+EMULATED_TP: Optional[Tuple[int, int]] = None
+
+
 def _active(group: Optional[dist.ProcessGroup]) -> bool:
     """``group is None`` means "no tensor parallelism" and is a strict no-op, whatever process group
     the program holds for other purposes (replicas, data or pipeline parallelism): a collective only
     runs over a group that was passed explicitly (``dist.group.WORLD`` for the whole job)."""
+    if isinstance(group, InProcessGroup):
+        return group.size > 1 or SINGLE_RANK_COLLECTIVES
     if group is None or not (dist.is_available() and dist.is_initialized()):
         return False
     return dist.get_world_size(group) > 1 or SINGLE_RANK_COLLECTIVES
@@ -176,7 +184,29 @@ class OneShotAllReduce:
             self._comm = None
 
 
+class InProcessGroup:
+    """A tensor-parallel group whose ranks all live in ONE process, each driving its own stream (and, to keep a host
+    wait of one rank from stalling the others, its own thread) of one GPU: (rank, size) plus the rank's end of a
+    one-shot exchange.  Accepted wherever the layers take a ``tp_group``; every all-reduce goes through the exchange
+    (there is no backend behind it, so a message it does not support raises).  For tests and rehearsals of the
+    sharded model on one GPU."""
+
+    def __init__(self, rank: int, size: int, comm: OneShotAllReduce):
+        self.rank, self.size, self.comm = rank, size, comm
+
+    @classmethod
+    def make(cls, size: int, device: torch.device, max_bytes: int = ONE_SHOT_MAX_BYTES, wait_seconds: float = 2.0) -> list:
+        comms = OneShotAllReduce.in_process(size, device, max_bytes)
+        for c in comms:
+            c.set_wait_limit(wait_seconds)
+        return [cls(r, size, c) for r, c in enumerate(comms)]
+
+
 _ONE_SHOT: dict = {}
+
+
+def _exchange_of(group) -> Optional[OneShotAllReduce]:
+    return group.comm if isinstance(group, InProcessGroup) else _ONE_SHOT.get(group)
 
 
 def enable_one_shot_all_reduce(group: dist.ProcessGroup, device: torch.device, max_bytes: int = ONE_SHOT_MAX_BYTES) -> OneShotAllReduce:
@@ -248,8 +278,8 @@ def all_reduce_sum(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -
     """Sum over the tensor-parallel group, in place (the reduction behind ``RowParallelLinear``:
     ``out_proj`` / ``o_proj`` / ``down_proj``).  No-op for a single rank or without a group."""
     if _active(group):
-        comm = _ONE_SHOT.get(group)
-        if comm is not None and comm.supports(x):
+        comm = _exchange_of(group)
+        if comm is not None and (comm.supports(x) or isinstance(group, InProcessGroup)):
             comm.all_reduce(data=x)
         else:
             dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
@@ -261,17 +291,21 @@ def all_reduce_variance(stats: torch.Tensor, group: Optional[dist.ProcessGroup] 
     returns the mean over the full hidden size (sum over ranks / tp), one message for both norms
     where the reference sends two ``[T, 1]`` ones (``modeling_hymeta.py:158-160``)."""
     if _active(group):
-        comm = _ONE_SHOT.get(group)
-        if comm is not None and comm.supports(None, stats):
+        comm = _exchange_of(group)
+        if comm is not None and (comm.supports(None, stats) or isinstance(group, InProcessGroup)):
             comm.all_reduce(stats=stats)
         else:
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-        stats /= dist.get_world_size(group)
+        stats /= tp_rank_and_size(group)[1]
     return stats
 
 
 def tp_rank_and_size(group: Optional[dist.ProcessGroup] = None) -> Tuple[int, int]:
     """Rank and size of the tensor-parallel group; ``(0, 1)`` without one (see ``_active``)."""
+    if isinstance(group, InProcessGroup):
+        return group.rank, group.size
     if group is not None and dist.is_available() and dist.is_initialized():
+        if EMULATED_TP is not None:
+            return EMULATED_TP
         return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
