@@ -802,6 +802,31 @@ typedef struct hymeta_moe_route_args {
 
 int hymeta_moe_route(const hymeta_moe_route_args* args, hymeta_stream_t stream);
 
+/* Decode-sized batches (num_tokens <= HYMETA_MOE_ROUTER_MAX_TOKENS): the router's linear layer and
+ * hymeta_moe_route in one launch -- logits = x gate_weight^T (fp32 sums of the bf16 products, rounded to bf16 as the
+ * reference's bf16 ReplicatedLinear gate rounds them: vllm_hymeta/models/modeling_hymeta.py:312-324), then the same
+ * softmax / top-k / offsets / scatter.  ticket: one device word, zero before the first call; every call leaves it zero
+ * (calls that share a ticket must not overlap).  logits_out: optional bf16 [num_tokens, num_experts], the logits that
+ * were routed.  hidden and x_stride_t multiples of 8; larger batches: HYMETA_ERR_UNSUPPORTED (run the linear layer and
+ * hymeta_moe_route). */
+#define HYMETA_MOE_ROUTER_MAX_TOKENS 256
+typedef struct hymeta_moe_router_args {
+  const void* x;               /* bf16 [num_tokens, hidden] */
+  const void* gate_weight;     /* bf16 [num_experts, hidden] contiguous */
+  void* logits_out;            /* bf16 [num_tokens, num_experts] or NULL */
+  int32_t* topk_ids;           /* out [num_tokens, top_k] */
+  float* topk_weights;         /* out [num_tokens, top_k] */
+  int32_t* expert_offsets;     /* out [num_experts + 1] */
+  int32_t* sorted_pair;        /* out [num_tokens * top_k] */
+  int32_t* pair_pos;           /* out [num_tokens * top_k] */
+  uint32_t* ticket;
+  int32_t num_tokens, num_experts, top_k, renormalize, hidden;
+  int32_t local_expert_begin, local_expert_end;
+  int64_t x_stride_t;
+} hymeta_moe_router_args;
+
+int hymeta_moe_router(const hymeta_moe_router_args* args, hymeta_stream_t stream);
+
 typedef struct hymeta_moe_gemm_args {
   const void* x;               /* bf16 rows of K */
   const void* weights;         /* bf16 [experts, N, K] */

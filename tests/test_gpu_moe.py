@@ -71,6 +71,39 @@ def test_moe_decode_gemm_k_shapes(T, E, H, inter):
     assert_bf16_close(out.cpu(), ref, f"moe T={T} H={H} I={inter}", rel=8e-3)
 
 
+@pytest.mark.parametrize("T,E,top_k,H", [(64, 16, 1, 3584), (1, 16, 1, 3584), (256, 16, 1, 512), (37, 8, 2, 320), (5, 64, 2, 256)])
+def test_router_in_the_routing_launch(T, E, top_k, H):
+    """Decode-sized batches: the router's linear layer runs inside the routing launch.  Its logits equal the bf16 linear
+    layer's within one bf16 ulp (another order of the fp32 sums); routed with exactly those logits, the block equals
+    the CPU restatement and, bit for bit, the block that is handed the same logits."""
+    from oracle.moe import moe_ref
+    from vllm_hymeta import hip_ops
+
+    inter = 192
+    x, gate_w, w13, w2, _ = _problem(6, T, H, inter, E)
+    shared = randn_bf16(gen(7), T, H)
+    xd, gd = x.cuda(), gate_w.cuda()
+    assert hip_ops.moe_router_fused(xd, gd)
+    logits = torch.empty(T, E, dtype=torch.bfloat16, device="cuda")
+    for _ in range(2):       # twice: the launch leaves its ticket as it found it
+        out = hip_ops.moe_forward(xd, None, w13.cuda(), w2.cuda(), top_k=top_k, shared=shared.cuda(), gate_weight=gd, logits_out=logits)
+    torch.cuda.synchronize()
+    lin = torch.nn.functional.linear(x.float(), gate_w.float())
+    assert_bf16_ulp(logits.cpu(), lin, "router logits", 1)
+    ref = moe_ref(x, logits.cpu(), w13, w2, top_k, False, shared)
+    assert_bf16_close(out.cpu(), ref, f"fused router T={T} E={E} k={top_k}", rel=8e-3)
+    same = hip_ops.moe_forward(xd, logits, w13.cuda(), w2.cuda(), top_k=top_k, shared=shared.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(out, same)
+    # a batch above the limit takes the linear layer and the separate routing launches
+    xb = randn_bf16(gen(8), 300, H).cuda()
+    assert not hip_ops.moe_router_fused(xb, gd)
+    big = hip_ops.moe_forward(xb, None, w13.cuda(), w2.cuda(), top_k=top_k, gate_weight=gd)
+    ref_big = hip_ops.moe_forward(xb, torch.nn.functional.linear(xb, gd), w13.cuda(), w2.cuda(), top_k=top_k)
+    torch.cuda.synchronize()
+    assert torch.equal(big, ref_big)
+
+
 def test_moe_expert_parallel_shares_sum_to_the_whole():
     """Two expert-parallel ranks (emulated in one process): each computes only its experts' pairs;
     the sum of the two outputs (the layer's all-reduce) equals the single-rank result, and each

@@ -14,8 +14,8 @@ E, H, inter = 16, 3584, 18944 // 4
 w13 = (torch.randn(E, 2 * inter, H, device=dev) * H ** -0.5).to(torch.bfloat16)
 w2 = (torch.randn(E, H, inter, device=dev) * inter ** -0.5).to(torch.bfloat16)
 x = torch.randn(T, H, device=dev).to(torch.bfloat16)
-logits = torch.randn(T, E, device=dev).to(torch.bfloat16)
+gate = (torch.randn(E, H, device=dev) * 0.5).to(torch.bfloat16)
 out = torch.empty(T, H, device=dev, dtype=torch.bfloat16)
 for _ in range(10):
-    hip_ops.moe_forward(x, logits, w13, w2, out=out)
+    hip_ops.moe_forward(x, None, w13, w2, out=out, gate_weight=gate)
 torch.cuda.synchronize()

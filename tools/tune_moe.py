@@ -20,9 +20,10 @@ def main():
     wbytes = (w13.numel() + w2.numel()) * 2
     for T in (1, 16, 64, 256, 512, 1024, 2048, 4096, 8192):
         x = torch.randn(T, H, device=dev).to(torch.bfloat16)
-        logits = torch.randn(T, E, device=dev).to(torch.bfloat16)
+        gate = (torch.randn(E, H, device=dev) * 0.5).to(torch.bfloat16)
         out = torch.empty(T, H, device=dev, dtype=torch.bfloat16)
-        us = bench(lambda: hip_ops.moe_forward(x, logits, w13, w2, out=out), iters=5)
+        # the block as the model runs it: router included (inside the routing launch up to 256 tokens)
+        us = bench(lambda: hip_ops.moe_forward(x, None, w13, w2, out=out, gate_weight=gate), iters=5)
         touched = min(T, E) / E * wbytes if T < 64 else wbytes
         flops = 2.0 * T * 3 * inter * H
         print(f"moe T={T:5d}: {us:9.1f} us   ~{touched / us / 1e3:7.1f} GB/s weights   {flops / us / 1e6:7.1f} TFLOP/s", flush=True)

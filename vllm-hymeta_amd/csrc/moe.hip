@@ -74,6 +74,10 @@ __global__ __launch_bounds__(256) void moe_route_kernel(hymeta_moe_route_args a)
   }
 }
 
+__global__ __launch_bounds__(64) void moe_zero_counts_kernel(hymeta_moe_route_args a) {
+  if (static_cast<int>(threadIdx.x) < a.num_experts) a.counts[threadIdx.x] = 0;
+}
+
 // offsets[0..E] = exclusive prefix of counts; cursors zeroed.
 __global__ __launch_bounds__(64) void moe_offsets_kernel(hymeta_moe_route_args a) {
   if (threadIdx.x == 0) {
@@ -98,6 +102,124 @@ __global__ __launch_bounds__(256) void moe_scatter_kernel(hymeta_moe_route_args 
     a.sorted_pair[pos] = p;
   }
   a.pair_pos[p] = pos;
+}
+
+// Decode-sized batches: the router's linear layer, the routing, the expert offsets and the scatter in ONE launch.
+// grid = tokens.  A workgroup computes its token's E logits (x row times the [E, H] gate weight, fp32 sums of bf16
+// products, rounded to bf16 as the bf16 linear layer's output is), one thread routes them as moe_route_kernel does, and
+// the workgroup that draws the last ticket counts the pairs per expert in LDS, writes the offsets and scatters the
+// pairs.  The ticket word must be zero on entry and is zero again on exit.
+__global__ __launch_bounds__(256) void moe_router_kernel(hymeta_moe_router_args a) {
+  __shared__ float s_part[4][kMaxExperts];
+  __shared__ float s_logit[kMaxExperts];
+  __shared__ int s_count[kMaxExperts], s_cur[kMaxExperts], s_off[kMaxExperts + 1];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int t = blockIdx.x;
+  const int E = a.num_experts;
+  const int chunks = a.hidden / 8;
+  const uint16_t* xrow = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(t) * a.x_stride_t;
+  const uint16_t* w = reinterpret_cast<const uint16_t*>(a.gate_weight);
+
+  for (int e0 = 0; e0 < E; e0 += 16) {
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int ch = tid; ch < chunks; ch += 256) {
+      const u32x4 xv = ld16g(xrow + 8 * ch);
+      u32x4 wv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) wv[j] = ld16g(w + static_cast<int64_t>(min(e0 + j, E - 1)) * a.hidden + 8 * ch);
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[j] = __builtin_fmaf(lo_bf(xv[i]), lo_bf(wv[j][i]), acc[j]);
+          acc[j] = __builtin_fmaf(hi_bf(xv[i]), hi_bf(wv[j][i]), acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float v = acc[j];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0 && e0 + j < E) s_part[wave][e0 + j] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < E) {
+    const float v = bf16_round(((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid]);
+    s_logit[tid] = v;
+    if (a.logits_out != nullptr) reinterpret_cast<uint16_t*>(a.logits_out)[static_cast<int64_t>(t) * E + tid] = f2bf(v);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mx = -INFINITY;
+    for (int e = 0; e < E; ++e) mx = fmaxf(mx, s_logit[e]);
+    float denom = 0.f;
+    for (int e = 0; e < E; ++e) {
+      s_logit[e] = expf(s_logit[e] - mx);
+      denom += s_logit[e];
+    }
+    int pick[2] = {0, 0};
+    float pw[2] = {0.f, 0.f};
+    for (int j = 0; j < a.top_k; ++j) {
+      int best = -1;
+      float bv = -1.f;
+      for (int e = 0; e < E; ++e) {
+        const bool taken = j == 1 && e == pick[0];
+        if (!taken && s_logit[e] > bv) {   // first maximum wins
+          bv = s_logit[e];
+          best = e;
+        }
+      }
+      pick[j] = best;
+      pw[j] = bv / denom;
+    }
+    if (a.renormalize) {
+      float sum = 0.f;
+      for (int j = 0; j < a.top_k; ++j) sum += pw[j];
+      for (int j = 0; j < a.top_k; ++j) pw[j] /= sum;
+    }
+    for (int j = 0; j < a.top_k; ++j) {
+      __hip_atomic_store(a.topk_ids + t * a.top_k + j, pick[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.topk_weights[t * a.top_k + j] = pw[j];
+    }
+    __threadfence();
+    s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+
+  // the last workgroup: every token's picks are in memory
+  __threadfence();
+  if (tid < kMaxExperts) s_count[tid] = 0, s_cur[tid] = 0;
+  __syncthreads();
+  const int pairs = a.num_tokens * a.top_k;
+  for (int p = tid; p < pairs; p += 256)
+    atomicAdd(&s_count[__hip_atomic_load(a.topk_ids + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int e = 0; e < E; ++e) {
+      s_off[e] = run;
+      a.expert_offsets[e] = run;
+      run += s_count[e];
+    }
+    s_off[E] = run;
+    a.expert_offsets[E] = run;
+    __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  for (int p = tid; p < pairs; p += 256) {
+    const int e = __hip_atomic_load(a.topk_ids + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int pos = -1;
+    if (e >= a.local_expert_begin && e < a.local_expert_end) {
+      pos = s_off[e] + atomicAdd(&s_cur[e], 1);
+      a.sorted_pair[pos] = p;
+    }
+    a.pair_pos[p] = pos;
+  }
 }
 
 // grid = (N / 64, local experts); rows of expert e = sorted slots [offsets[e], offsets[e + 1]).
@@ -539,7 +661,7 @@ extern "C" int hymeta_moe_route(const hymeta_moe_route_args* args, hymeta_stream
     return HYMETA_ERR_INVALID_ARG;
   if (!a.counts || !a.expert_offsets || !a.cursors) return HYMETA_ERR_INVALID_ARG;
   hipStream_t s = begin_launches(stream);
-  if (hipMemsetAsync(a.counts, 0, sizeof(int32_t) * a.num_experts, s) != hipSuccess) return HYMETA_ERR_LAUNCH;
+  hipLaunchKernelGGL(moe_zero_counts_kernel, dim3(1), dim3(64), 0, s, a);      // a kernel, not a memset node: see the header
   if (a.num_tokens > 0) {
     if (!a.router_logits || !a.topk_ids || !a.topk_weights || !a.sorted_pair || !a.pair_pos) return HYMETA_ERR_INVALID_ARG;
     hipLaunchKernelGGL(moe_route_kernel, dim3((a.num_tokens + 255) / 256), dim3(256), 0, s, a);
@@ -547,6 +669,23 @@ extern "C" int hymeta_moe_route(const hymeta_moe_route_args* args, hymeta_stream
   hipLaunchKernelGGL(moe_offsets_kernel, dim3(1), dim3(64), 0, s, a);
   if (a.num_tokens > 0)
     hipLaunchKernelGGL(moe_scatter_kernel, dim3((a.num_tokens * a.top_k + 255) / 256), dim3(256), 0, s, a);
+  return launch_status();
+}
+
+extern "C" int hymeta_moe_router(const hymeta_moe_router_args* args, hymeta_stream_t stream) {
+  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_moe_router_args& a = *args;
+  if (a.num_tokens < 0 || a.num_experts <= 0 || a.top_k <= 0 || a.hidden <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (a.num_experts > kMaxExperts || a.top_k > 2 || a.top_k > a.num_experts) return HYMETA_ERR_UNSUPPORTED;
+  if (a.num_tokens == 0 || a.num_tokens > HYMETA_MOE_ROUTER_MAX_TOKENS || a.hidden % 8 != 0 || a.x_stride_t % 8 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  if (a.local_expert_begin < 0 || a.local_expert_end > a.num_experts || a.local_expert_begin > a.local_expert_end)
+    return HYMETA_ERR_INVALID_ARG;
+  if (!a.x || !a.gate_weight || !a.topk_ids || !a.topk_weights || !a.expert_offsets || !a.sorted_pair || !a.pair_pos || !a.ticket)
+    return HYMETA_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.gate_weight)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  hipStream_t s = begin_launches(stream);
+  hipLaunchKernelGGL(moe_router_kernel, dim3(a.num_tokens), dim3(256), 0, s, a);
   return launch_status();
 }
 

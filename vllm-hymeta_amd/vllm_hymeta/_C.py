@@ -208,6 +208,19 @@ class MoeRouteArgs(C.Structure):
     ]
 
 
+class MoeRouterArgs(C.Structure):
+    _fields_ = [
+        ("x", _ptr), ("gate_weight", _ptr), ("logits_out", _ptr), ("topk_ids", _ptr), ("topk_weights", _ptr),
+        ("expert_offsets", _ptr), ("sorted_pair", _ptr), ("pair_pos", _ptr), ("ticket", _ptr),
+        ("num_tokens", _i32), ("num_experts", _i32), ("top_k", _i32), ("renormalize", _i32), ("hidden", _i32),
+        ("local_expert_begin", _i32), ("local_expert_end", _i32),
+        ("x_stride_t", _i64),
+    ]
+
+
+MOE_ROUTER_MAX_TOKENS = 256
+
+
 class MoeGemmArgs(C.Structure):
     _fields_ = [
         ("x", _ptr), ("weights", _ptr), ("out", _ptr), ("expert_offsets", _ptr), ("a_rows", _ptr), ("scale_rows", _ptr),
@@ -278,6 +291,7 @@ _SIGNATURES = {
     "hymeta_w8a8_gemm": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),
     "hymeta_w8a8_gemm_silu_mul": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),
     "hymeta_moe_route": (C.c_int, [C.POINTER(MoeRouteArgs), _ptr]),
+    "hymeta_moe_router": (C.c_int, [C.POINTER(MoeRouterArgs), _ptr]),
     "hymeta_moe_gemm": (C.c_int, [C.POINTER(MoeGemmArgs), _ptr]),
     "hymeta_silu_and_mul": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),
     "hymeta_moe_combine": (C.c_int, [C.POINTER(MoeCombineArgs), _ptr]),

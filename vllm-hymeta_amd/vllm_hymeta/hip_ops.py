@@ -327,7 +327,7 @@ def reshape_and_cache(
 # ---------------------------------------------------------------------------
 _workspaces = {}
 _retired = []
-_TICKETED = ("gptq_gemm", "bf16_gemm", "w8a8_gemm")     # workspaces that start with split-K ticket counters
+_TICKETED = ("gptq_gemm", "bf16_gemm", "w8a8_gemm", "moe_router")     # workspaces that start with split-K ticket counters
 
 
 class _Workspace:
@@ -1127,21 +1127,39 @@ def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None, num_rows_d
     return out
 
 
-def moe_forward(x: torch.Tensor, router_logits: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, top_k: int = 1,
+def moe_router_fused(x: torch.Tensor, gate_weight: torch.Tensor) -> bool:
+    """Whether ``moe_forward`` routes this batch with the one-launch router (linear layer + routing)."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and gate_weight.dtype == torch.bfloat16 and gate_weight.is_contiguous()
+            and 0 < x.shape[0] <= _C.MOE_ROUTER_MAX_TOKENS and x.shape[1] % 8 == 0 and x.stride(0) % 8 == 0
+            and gate_weight.shape[0] <= 64)
+
+
+def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: torch.Tensor, w2: torch.Tensor, top_k: int = 1,
                 renormalize: bool = False, shared: Optional[torch.Tensor] = None,
-                local_experts: Optional[tuple] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                local_experts: Optional[tuple] = None, out: Optional[torch.Tensor] = None,
+                gate_weight: Optional[torch.Tensor] = None, logits_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Sparse MoE block: x bf16 [T,H], router_logits [T,E] (bf16 | fp32), w13 bf16 [E,2I,H], w2 bf16
     [E,H,I]; ``shared`` bf16 [T,H] is added to the result; ``local_experts = (lo, hi)`` computes only
-    this rank's experts (the caller all-reduces).  Returns bf16 [T,H]."""
-    _dev(x, router_logits, w13, w2, shared, out)
+    this rank's experts (the caller all-reduces).  Returns bf16 [T,H].
+    With ``router_logits=None`` and ``gate_weight`` bf16 [E,H] the block computes the logits itself: decode-sized batches
+    in the routing launch (``moe_router_fused``; ``logits_out`` bf16 [T,E] then receives them), larger ones through the
+    linear layer."""
+    _dev(x, router_logits, w13, w2, shared, out, gate_weight)
     T, H = x.shape
     E, two_i, Hw = w13.shape
     inter = two_i // 2
+    _require(router_logits is not None or gate_weight is not None, "router_logits or gate_weight must be given")
+    fused_router = router_logits is None and T > 0 and moe_router_fused(x, gate_weight)
+    if router_logits is None and not fused_router:
+        _require(gate_weight.shape == (E, H), "gate_weight must be [E, H]")
+        router_logits = torch.nn.functional.linear(x, gate_weight)
+        if logits_out is not None:
+            logits_out.copy_(router_logits)
     _require(x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [T, H]")
     _require(w13.dtype == torch.bfloat16 and w13.is_contiguous() and Hw == H, "w13 must be contiguous bf16 [E, 2I, H]")
     _require(w2.dtype == torch.bfloat16 and w2.is_contiguous() and w2.shape == (E, H, inter),
              "w2 must be contiguous bf16 [E, H, I]")
-    _require(router_logits.shape == (T, E) and router_logits.dtype in _DT and router_logits.stride(1) == 1,
+    _require(fused_router or (router_logits.shape == (T, E) and router_logits.dtype in _DT and router_logits.stride(1) == 1),
              "router_logits must be [T, E] bf16 | fp32")
     lo, hi = local_experts if local_experts is not None else (0, E)
     dev = x.device
@@ -1157,15 +1175,29 @@ def moe_forward(x: torch.Tensor, router_logits: torch.Tensor, w13: torch.Tensor,
     if T == 0:
         return out
     lib, st = _C.load(), _stream(x)
-    r = _C.MoeRouteArgs()
-    r.router_logits, r.topk_ids, r.topk_weights = _p(router_logits), _p(ids), _p(wts)
-    r.counts, r.cursors, r.expert_offsets = _p(counts), _p(cursors), _p(offsets)
-    r.sorted_pair, r.pair_pos = _p(sorted_pair), _p(pair_pos)
-    r.num_tokens, r.num_experts, r.top_k, r.renormalize = T, E, top_k, int(bool(renormalize))
-    r.logits_dtype = _DT[router_logits.dtype]
-    r.local_expert_begin, r.local_expert_end = lo, hi
-    r.logits_stride_t = router_logits.stride(0)
-    _C.check(lib.hymeta_moe_route(C.byref(r), st), "hymeta_moe_route")
+    if fused_router:
+        _require(gate_weight.shape == (E, H), "gate_weight must be [E, H]")
+        _require(logits_out is None or (logits_out.shape == (T, E) and logits_out.dtype == torch.bfloat16 and logits_out.is_contiguous()),
+                 "logits_out must be contiguous bf16 [T, E]")
+        r = _C.MoeRouterArgs()
+        r.x, r.gate_weight, r.logits_out = _p(x), _p(gate_weight), _p(logits_out)
+        r.topk_ids, r.topk_weights, r.expert_offsets = _p(ids), _p(wts), _p(offsets)
+        r.sorted_pair, r.pair_pos = _p(sorted_pair), _p(pair_pos)
+        r.ticket = _p(_workspace(dev, 64, "moe_router"))
+        r.num_tokens, r.num_experts, r.top_k, r.renormalize, r.hidden = T, E, top_k, int(bool(renormalize)), H
+        r.local_expert_begin, r.local_expert_end = lo, hi
+        r.x_stride_t = x.stride(0)
+        _C.check(lib.hymeta_moe_router(C.byref(r), st), "hymeta_moe_router")
+    else:
+        r = _C.MoeRouteArgs()
+        r.router_logits, r.topk_ids, r.topk_weights = _p(router_logits), _p(ids), _p(wts)
+        r.counts, r.cursors, r.expert_offsets = _p(counts), _p(cursors), _p(offsets)
+        r.sorted_pair, r.pair_pos = _p(sorted_pair), _p(pair_pos)
+        r.num_tokens, r.num_experts, r.top_k, r.renormalize = T, E, top_k, int(bool(renormalize))
+        r.logits_dtype = _DT[router_logits.dtype]
+        r.local_expert_begin, r.local_expert_end = lo, hi
+        r.logits_stride_t = router_logits.stride(0)
+        _C.check(lib.hymeta_moe_route(C.byref(r), st), "hymeta_moe_route")
 
     h13 = torch.empty(P, two_i, dtype=torch.bfloat16, device=dev)
     g = _C.MoeGemmArgs()

@@ -70,12 +70,13 @@ class HymetaMoE(torch.nn.Module):
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
         x = hidden_states.reshape(-1, hidden_states.shape[-1])
-        router_logits = torch.nn.functional.linear(x, self.gate_weight)
         shared = None
         if self.shared_mlp is not None:
             # the shared expert is tensor-parallel like a dense MLP; its partial sums ride in the
             # same all-reduce as the experts' when it is built with reduce_results=False
             shared = self.shared_mlp(x)
-        out = hip_ops.moe_forward(x, router_logits, self.w13, self.w2, top_k=self.top_k, renormalize=self.renormalize,
-                                  shared=shared, local_experts=self.local_experts)
+        # the router (a replicated linear layer, reference modeling_hymeta.py:312-324) runs inside the block: in the
+        # routing launch itself for decode-sized batches
+        out = hip_ops.moe_forward(x, None, self.w13, self.w2, top_k=self.top_k, renormalize=self.renormalize,
+                                  shared=shared, local_experts=self.local_experts, gate_weight=self.gate_weight)
         return all_reduce_sum(out, self.group).view_as(hidden_states)
