@@ -840,9 +840,22 @@ typedef struct hymeta_moe_gemm_args {
   int32_t K, N;
   int32_t local_expert_begin, local_expert_end;
   int64_t x_stride_m, out_stride_m, w_stride_e;
+  /* The combine inside the down projection of a decode-sized batch (hymeta_moe_gemm_fuses(...) == 1; otherwise leave
+   * these NULL or get HYMETA_ERR_UNSUPPORTED):
+   *  combine_tokens [slots]: row `slot` is written to out[combine_tokens[slot]] instead of out[slot] -- with one choice
+   *                 per token and every expert local (sorted_pair is then the token of a slot) this is hymeta_moe_combine
+   *  combine_shared bf16 [num_tokens, N] or NULL: the shared expert's rows, added to the rounded row as
+   *                 hymeta_moe_combine adds them
+   * (Folding the activation into this GEMM's operand loads was built and measured too: 7 % slower than the separate
+   * launch -- the sigmoid sits between a load and its use, and its registers cost the kernel a wave per SIMD.) */
+  const int32_t* combine_tokens;
+  const void* combine_shared;
+  int64_t combine_shared_stride_m;
 } hymeta_moe_gemm_args;
 
 int hymeta_moe_gemm(const hymeta_moe_gemm_args* args, hymeta_stream_t stream);
+/* 1 when hymeta_moe_gemm runs a problem of these sizes in the kernel that has the fused combine. */
+int hymeta_moe_gemm_fuses(int32_t max_rows, int32_t experts, int32_t K, int32_t N);
 
 /* num_rows_dev: optional device count of the rows in use (e.g. expert_offsets + E); NULL: num_rows. */
 int hymeta_silu_and_mul(const void* in, void* out, const int32_t* num_rows_dev, int32_t num_rows,
@@ -878,7 +891,9 @@ int hymeta_moe_combine(const hymeta_moe_combine_args* args, hymeta_stream_t stre
  *   hymeta_p2p_connect_pointers  the same for ranks that live in one process: buffers[q] = hymeta_p2p_local_buffer of
  *                                rank q's communicator
  *   hymeta_p2p_all_reduce        in place: data_bf16[0 .. n_bf16) and stats[0 .. n_stats) become their sums over the
- *                                ranks, one exchange for both (either may be empty).  n_bf16 a multiple of 8, data 16-byte
+ *                                ranks, one exchange for both (either may be empty); the fp32 sums are multiplied by
+ *                                stats_scale (1 for a plain sum; 1 / world for the mean of the ranks' mean squares, which
+ *                                is what the branch norms need).  n_bf16 a multiple of 8, data 16-byte
  *                                aligned; (n_stats * 4 rounded up to 16) + n_bf16 * 2 <= max_message_bytes, else
  *                                HYMETA_ERR_SCRATCH_LIMIT.  One kernel launch, no host value that changes per call (the
  *                                epoch lives in device memory), so a captured launch replays.  All ranks must make the
@@ -897,7 +912,7 @@ int hymeta_p2p_connect(hymeta_p2p_comm* comm, const void* all_handles);
 int hymeta_p2p_connect_pointers(hymeta_p2p_comm* comm, void* const* buffers);
 int hymeta_p2p_set_wait_limit(hymeta_p2p_comm* comm, uint64_t ticks_100mhz);
 int hymeta_p2p_all_reduce(hymeta_p2p_comm* comm, void* data_bf16, int64_t n_bf16, float* stats, int64_t n_stats,
-                          hymeta_stream_t stream);
+                          float stats_scale, hymeta_stream_t stream);
 int hymeta_p2p_timeouts(hymeta_p2p_comm* comm, uint32_t* count);
 int hymeta_p2p_destroy(hymeta_p2p_comm* comm);
 

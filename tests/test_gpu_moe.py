@@ -104,6 +104,35 @@ def test_router_in_the_routing_launch(T, E, top_k, H):
     assert torch.equal(big, ref_big)
 
 
+@pytest.mark.parametrize("T,E,top_k,with_shared,H", [
+    (64, 16, 1, True, 256), (1, 16, 1, False, 256), (12, 4, 2, True, 256), (100, 16, 1, True, 256),
+    (100, 4, 1, True, 192),       # 25 rows per expert with 192 columns: the 64-row tiles of the decode-sized kernel
+])
+def test_combine_inside_the_down_gemm_equals_the_separate_launch(T, E, top_k, with_shared, H):
+    """Decode-sized batches with one choice per token fold the combine with the shared expert into the down GEMM's
+    epilogue: the same bits as the separate launch (two choices per token keep the launch)."""
+    from vllm_hymeta import hip_ops
+
+    inter = 192
+    x, gate_w, w13, w2, logits = _problem(9, T, H, inter, E)
+    shared = randn_bf16(gen(10), T, H).cuda() if with_shared else None
+    args = (x.cuda(), logits.cuda(), w13.cuda(), w2.cuda())
+    assert hip_ops.MOE_FUSE_DOWN and _C_fuses(T * top_k, E, inter, H)
+    fused = hip_ops.moe_forward(*args, top_k=top_k, shared=shared)
+    hip_ops.MOE_FUSE_DOWN = False
+    try:
+        plain = hip_ops.moe_forward(*args, top_k=top_k, shared=shared)
+    finally:
+        hip_ops.MOE_FUSE_DOWN = True
+    torch.cuda.synchronize()
+    assert torch.equal(fused, plain)
+
+
+def _C_fuses(rows, experts, K, N):
+    from vllm_hymeta import _C
+    return bool(_C.load().hymeta_moe_gemm_fuses(rows, experts, K, N))
+
+
 def test_moe_expert_parallel_shares_sum_to_the_whole():
     """Two expert-parallel ranks (emulated in one process): each computes only its experts' pairs;
     the sum of the two outputs (the layer's all-reduce) equals the single-rank result, and each

@@ -61,6 +61,15 @@ def test_every_rank_gets_the_rank_ordered_sum(world):
                 assert torch.equal(xs[r], ref_x), f"rank {r} of {world}: data of {rows} rows"
             if with_stats:
                 assert torch.equal(ss[r], ref_s), f"rank {r} of {world}: statistics of {rows} rows"
+    # the mean of the ranks' statistics: the scale rides in the exchange
+    _, ss = _messages(g_, world, 64, False, True, dev)
+    ref_mean = _reference(ss, torch.float32) * (1.0 / world)
+    torch.cuda.synchronize()
+    for c, st, s in zip(comms, streams, ss):
+        with torch.cuda.stream(st):
+            c.all_reduce(stats=s, stats_scale=1.0 / world)
+    torch.cuda.synchronize()
+    assert all(torch.equal(s, ref_mean) for s in ss)
     assert all(c.timeouts() == 0 for c in comms)
     _close(comms)
 
@@ -126,8 +135,8 @@ def test_limits_and_unsupported_messages():
     # the C entry point itself refuses what the wrapper filters
     big = torch.zeros(4096, dtype=torch.bfloat16, device=dev)
     lib = _C.load()
-    assert lib.hymeta_p2p_all_reduce(c._comm, big.data_ptr(), big.numel(), None, 0, None) == _C.ERR_SCRATCH_LIMIT
-    assert lib.hymeta_p2p_all_reduce(c._comm, big.data_ptr(), 12, None, 0, None) == -2
+    assert lib.hymeta_p2p_all_reduce(c._comm, big.data_ptr(), big.numel(), None, 0, 1.0, None) == _C.ERR_SCRATCH_LIMIT
+    assert lib.hymeta_p2p_all_reduce(c._comm, big.data_ptr(), 12, None, 0, 1.0, None) == -2
     x = torch.ones(2048, dtype=torch.bfloat16, device=dev)
     c.all_reduce(data=x)                 # a world of one: the sum is the message
     torch.cuda.synchronize()

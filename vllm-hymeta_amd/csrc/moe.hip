@@ -430,8 +430,20 @@ __global__ __launch_bounds__(256) void moe_gemm_lines_kernel(hymeta_moe_gemm_arg
         for (int w = 0; w < 4; ++w)
           s += *reinterpret_cast<const f32x4*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kCols + 4 * cg);
         if (a.row_scale != nullptr) s *= a.row_scale[a.scale_rows != nullptr ? a.scale_rows[slot] : slot];
+        int64_t out_row = slot;
+        if (a.combine_tokens != nullptr) {
+          // one choice per token, every expert local: the row goes straight to its token, the shared expert added
+          // as moe_combine_kernel adds it (to the rounded row)
+          out_row = a.combine_tokens[slot];
+          if (a.combine_shared != nullptr) {
+            const u32x2 sh = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.combine_shared) +
+                                                             out_row * a.combine_shared_stride_m + col);
+            s[0] = bf16_round(s[0]) + lo_bf(sh[0]), s[1] = bf16_round(s[1]) + hi_bf(sh[0]);
+            s[2] = bf16_round(s[2]) + lo_bf(sh[1]), s[3] = bf16_round(s[3]) + hi_bf(sh[1]);
+          }
+        }
         const u32x2 o = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
-        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + static_cast<int64_t>(slot) * a.out_stride_m + col) = o;
+        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + out_row * a.out_stride_m + col) = o;
       }
     }
     __syncthreads();
@@ -689,7 +701,31 @@ extern "C" int hymeta_moe_router(const hymeta_moe_router_args* args, hymeta_stre
   return launch_status();
 }
 
+namespace hymeta {
+namespace {
+enum class MoeGemmKind { kBigTiles, kTiles, kLines, kFragments };
+
+MoeGemmKind moe_gemm_kind(int64_t max_rows, int experts, int K, int N) {
+  // tiled grouped GEMM once the experts average more than a few rows (prefill chunks); the large tile when they fill it
+  if (max_rows > static_cast<int64_t>(kTiledMinRowsPerExpert) * experts && K % kTK == 0) {
+    if (max_rows >= static_cast<int64_t>(kBigTileMinRowsPerExpert) * experts && N % 256 == 0) return MoeGemmKind::kBigTiles;
+    if (N % 128 == 0) return MoeGemmKind::kTiles;
+  }
+  static const bool lines = [] {
+    const char* v = getenv("HYMETA_MOE_LINES");
+    return v == nullptr || atoi(v) != 0;
+  }();
+  return lines && K % 64 == 0 ? MoeGemmKind::kLines : MoeGemmKind::kFragments;
+}
+}  // namespace
+}  // namespace hymeta
+
+extern "C" int hymeta_moe_gemm_fuses(int32_t max_rows, int32_t experts, int32_t K, int32_t N) {
+  return experts > 0 && hymeta::moe_gemm_kind(max_rows, experts, K, N) == hymeta::MoeGemmKind::kLines ? 1 : 0;
+}
+
 extern "C" int hymeta_moe_gemm(const hymeta_moe_gemm_args* args, hymeta_stream_t stream) {
+  using namespace hymeta;
   if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
   const hymeta_moe_gemm_args& a = *args;
   if (a.max_rows < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
@@ -701,30 +737,30 @@ extern "C" int hymeta_moe_gemm(const hymeta_moe_gemm_args* args, hymeta_stream_t
   if ((a.x_stride_m | a.out_stride_m | a.w_stride_e) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.weights) | reinterpret_cast<uintptr_t>(a.out)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
-  hipStream_t s = begin_launches(stream);
   const int experts = a.local_expert_end - a.local_expert_begin;
+  const MoeGemmKind kind = moe_gemm_kind(a.max_rows, experts, a.K, a.N);
+  if (a.combine_tokens != nullptr || a.combine_shared != nullptr) {
+    // the fused combine exists in the decode-sized kernel with whole-line loads only (hymeta_moe_gemm_fuses)
+    if (kind != MoeGemmKind::kLines) return HYMETA_ERR_UNSUPPORTED;
+    if (a.combine_shared != nullptr && (a.combine_tokens == nullptr || a.combine_shared_stride_m % 8 != 0 ||
+                                        reinterpret_cast<uintptr_t>(a.combine_shared) % 16 != 0))
+      return HYMETA_ERR_INVALID_ARG;
+  }
+  hipStream_t s = begin_launches(stream);
   dim3 grid(a.N / kCols, experts), block(256);
   // few rows per expert on average (decode): 16-row tiles; otherwise 64-row tiles
   const bool small = static_cast<int64_t>(a.max_rows) <= 8LL * experts;
-  // tiled grouped GEMM once the experts average more than a few rows (prefill chunks); the large
-  // tile when they fill it
-  if (static_cast<int64_t>(a.max_rows) > static_cast<int64_t>(kTiledMinRowsPerExpert) * experts && a.K % kTK == 0) {
-    if (static_cast<int64_t>(a.max_rows) >= static_cast<int64_t>(kBigTileMinRowsPerExpert) * experts && a.N % 256 == 0) {
-      const dim3 tgrid(a.N / 256, (a.max_rows + 255) / 256 + experts);
-      hipLaunchKernelGGL((moe_gemm_tiled_kernel<256, 256, 4, 2>), tgrid, dim3(512), 0, s, a);
-      return launch_status();
-    }
-    if (a.N % 128 == 0) {
-      const dim3 tgrid(a.N / 128, (a.max_rows + 127) / 128 + experts);
-      hipLaunchKernelGGL((moe_gemm_tiled_kernel<128, 128, 2, 2>), tgrid, dim3(256), 0, s, a);
-      return launch_status();
-    }
+  if (kind == MoeGemmKind::kBigTiles) {
+    const dim3 tgrid(a.N / 256, (a.max_rows + 255) / 256 + experts);
+    hipLaunchKernelGGL((moe_gemm_tiled_kernel<256, 256, 4, 2>), tgrid, dim3(512), 0, s, a);
+    return launch_status();
   }
-  static const bool lines = [] {
-    const char* v = getenv("HYMETA_MOE_LINES");
-    return v == nullptr || atoi(v) != 0;
-  }();
-  if (lines && a.K % 64 == 0) {
+  if (kind == MoeGemmKind::kTiles) {
+    const dim3 tgrid(a.N / 128, (a.max_rows + 127) / 128 + experts);
+    hipLaunchKernelGGL((moe_gemm_tiled_kernel<128, 128, 2, 2>), tgrid, dim3(256), 0, s, a);
+    return launch_status();
+  }
+  if (kind == MoeGemmKind::kLines) {
     const size_t images = 4 * static_cast<size_t>(kLineImageBytes);
     if (small) hipLaunchKernelGGL((moe_gemm_lines_kernel<1>), grid, block, std::max(images, 4 * 16 * kCols * sizeof(float)), s, a);
     else hipLaunchKernelGGL((moe_gemm_lines_kernel<4>), grid, block, std::max(images, 4 * 64 * kCols * sizeof(float)), s, a);

@@ -45,6 +45,7 @@ struct P2pArgs {
   int64_t slot_bytes;
   uint64_t spin_ticks;
   int rank, units_per_block;
+  float stats_scale;        // the fp32 sums are multiplied by it (1 / W turns the sum of the ranks' means into the mean)
 };
 
 __device__ __forceinline__ uint32_t* flag_ptr(char* buf, int parity, int rank, int block) {
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void p2p_all_reduce_kernel(P2pArgs a) {
         for (int i = 0; i < 4; ++i) f[i] += __uint_as_float(v[q][i]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (4 * u + i < a.n_stats) a.stats[4 * u + i] = f[i];
+        if (4 * u + i < a.n_stats) a.stats[4 * u + i] = f[i] * a.stats_scale;
     } else {
       float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -243,7 +244,7 @@ extern "C" int hymeta_p2p_set_wait_limit(hymeta_p2p_comm* comm, uint64_t ticks_1
 }
 
 extern "C" int hymeta_p2p_all_reduce(hymeta_p2p_comm* comm, void* data_bf16, int64_t n_bf16, float* stats, int64_t n_stats,
-                                     hymeta_stream_t stream) {
+                                     float stats_scale, hymeta_stream_t stream) {
   using namespace hymeta;
   if (comm == nullptr || n_bf16 < 0 || n_stats < 0) return HYMETA_ERR_INVALID_ARG;
   if (!comm->connected) return HYMETA_ERR_INVALID_ARG;
@@ -263,6 +264,7 @@ extern "C" int hymeta_p2p_all_reduce(hymeta_p2p_comm* comm, void* data_bf16, int
   a.slot_bytes = static_cast<int64_t>(comm->slot_bytes);
   a.spin_ticks = comm->spin_ticks;
   a.rank = comm->rank;
+  a.stats_scale = stats_scale;
   // 4 units per thread and block at least; every rank derives the same grid from the same sizes
   const int64_t want = (a.units + 4 * kThreads - 1) / (4 * kThreads);
   const int blocks = static_cast<int>(want < 1 ? 1 : want > kMaxBlocks ? kMaxBlocks : want);

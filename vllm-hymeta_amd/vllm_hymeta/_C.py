@@ -228,6 +228,7 @@ class MoeGemmArgs(C.Structure):
         ("a_rows_div", _i32), ("max_rows", _i32), ("K", _i32), ("N", _i32),
         ("local_expert_begin", _i32), ("local_expert_end", _i32),
         ("x_stride_m", _i64), ("out_stride_m", _i64), ("w_stride_e", _i64),
+        ("combine_tokens", _ptr), ("combine_shared", _ptr), ("combine_shared_stride_m", _i64),
     ]
 
 
@@ -276,7 +277,7 @@ _SIGNATURES = {
     "hymeta_p2p_connect": (C.c_int, [_ptr, _ptr]),
     "hymeta_p2p_connect_pointers": (C.c_int, [_ptr, C.POINTER(_ptr)]),
     "hymeta_p2p_set_wait_limit": (C.c_int, [_ptr, C.c_uint64]),
-    "hymeta_p2p_all_reduce": (C.c_int, [_ptr, _ptr, _i64, _ptr, _i64, _ptr]),
+    "hymeta_p2p_all_reduce": (C.c_int, [_ptr, _ptr, _i64, _ptr, _i64, _f32, _ptr]),
     "hymeta_p2p_timeouts": (C.c_int, [_ptr, C.POINTER(C.c_uint32)]),
     "hymeta_p2p_destroy": (C.c_int, [_ptr]),
     "hymeta_bf16_gemm_deferred": (C.c_int, [C.POINTER(Bf16GemmArgs), C.POINTER(GemmPartials), _ptr]),
@@ -292,6 +293,7 @@ _SIGNATURES = {
     "hymeta_w8a8_gemm_silu_mul": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),
     "hymeta_moe_route": (C.c_int, [C.POINTER(MoeRouteArgs), _ptr]),
     "hymeta_moe_router": (C.c_int, [C.POINTER(MoeRouterArgs), _ptr]),
+    "hymeta_moe_gemm_fuses": (C.c_int, [_i32, _i32, _i32, _i32]),
     "hymeta_moe_gemm": (C.c_int, [C.POINTER(MoeGemmArgs), _ptr]),
     "hymeta_silu_and_mul": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),
     "hymeta_moe_combine": (C.c_int, [C.POINTER(MoeCombineArgs), _ptr]),

@@ -8,6 +8,7 @@ runs in libhymeta_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -1127,6 +1128,11 @@ def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None, num_rows_d
     return out
 
 
+# Switch for A/B timing and for tests of both forms: fold the combine into the experts' down GEMM at decode sizes (see
+# moe_forward).
+MOE_FUSE_DOWN = os.environ.get("HYMETA_MOE_FUSE_DOWN", "1") != "0"
+
+
 def moe_router_fused(x: torch.Tensor, gate_weight: torch.Tensor) -> bool:
     """Whether ``moe_forward`` routes this batch with the one-launch router (linear layer + routing)."""
     return (x.is_cuda and x.dtype == torch.bfloat16 and gate_weight.dtype == torch.bfloat16 and gate_weight.is_contiguous()
@@ -1207,26 +1213,37 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
     g.x_stride_m, g.out_stride_m, g.w_stride_e = x.stride(0), h13.stride(0), w13.stride(0)
     _C.check(lib.hymeta_moe_gemm(C.byref(g), st), "hymeta_moe_gemm (w13)")
 
+    if shared is not None:
+        _require(shared.shape == (T, H) and shared.dtype == torch.bfloat16 and shared.stride(1) == 1,
+                 "shared must be bf16 [T, H]")
+    # decode-sized batches with one choice per token and every expert local: the down GEMM writes its rows straight to
+    # their tokens with the shared expert added -- no combine launch
+    fuse_combine = (MOE_FUSE_DOWN and top_k == 1 and (lo, hi) == (0, E) and bool(lib.hymeta_moe_gemm_fuses(P, hi - lo, inter, H))
+                    and (shared is None or shared.stride(0) % 8 == 0))
     # slots in use are a prefix only when lo == 0; otherwise act on all P rows (unused rows are never read)
     hact = torch.empty(P, inter, dtype=torch.bfloat16, device=dev)
     silu_and_mul(h13, out=hact)
-
-    y = torch.empty(P, H, dtype=torch.bfloat16, device=dev)
     d = _C.MoeGemmArgs()
-    d.x, d.weights, d.out, d.expert_offsets = _p(hact), _p(w2), _p(y), _p(offsets)
+    d.x, d.x_stride_m = _p(hact), hact.stride(0)
+    y = out if fuse_combine else torch.empty(P, H, dtype=torch.bfloat16, device=dev)
+    d.weights, d.out, d.expert_offsets = _p(w2), _p(y), _p(offsets)
     d.scale_rows, d.row_scale = _p(sorted_pair), _p(wts)
     d.a_rows_div, d.max_rows, d.K, d.N = 1, P, inter, H
     d.local_expert_begin, d.local_expert_end = lo, hi
-    d.x_stride_m, d.out_stride_m, d.w_stride_e = hact.stride(0), y.stride(0), w2.stride(0)
+    d.out_stride_m, d.w_stride_e = y.stride(0), w2.stride(0)
+    if fuse_combine:
+        d.combine_tokens = _p(sorted_pair)       # one choice per token: the pair index is the token
+        if shared is not None:
+            d.combine_shared, d.combine_shared_stride_m = _p(shared), shared.stride(0)
     _C.check(lib.hymeta_moe_gemm(C.byref(d), st), "hymeta_moe_gemm (w2)")
+    if fuse_combine:
+        return out
 
     c = _C.MoeCombineArgs()
     c.y, c.shared, c.out, c.pair_pos, c.topk_weights = _p(y), _p(shared), _p(out), _p(pair_pos), _p(wts)
     c.num_tokens, c.hidden, c.top_k = T, H, top_k
     c.y_stride_m, c.out_stride_m = y.stride(0), out.stride(0)
     if shared is not None:
-        _require(shared.shape == (T, H) and shared.dtype == torch.bfloat16 and shared.stride(1) == 1,
-                 "shared must be bf16 [T, H]")
         c.shared_stride_m = shared.stride(0)
     _C.check(lib.hymeta_moe_combine(C.byref(c), st), "hymeta_moe_combine")
     return out

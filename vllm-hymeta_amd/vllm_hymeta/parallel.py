@@ -151,9 +151,9 @@ class OneShotAllReduce:
             nbytes += (stats.numel() * 4 + 15) // 16 * 16
         return 0 < nbytes <= self.max_bytes
 
-    def all_reduce(self, data: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None) -> None:
+    def all_reduce(self, data: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, stats_scale: float = 1.0) -> None:
         """``data`` (bf16) and ``stats`` (fp32) become their sums over the ranks, in place, in one exchange, on the
-        current stream of their device."""
+        current stream of their device; the fp32 sums are multiplied by ``stats_scale``."""
         if not self.supports(data, stats):
             raise ValueError("one-shot all-reduce: contiguous bf16 data (a multiple of 8 values) and / or fp32 statistics "
                              f"on the GPU, {self.max_bytes} bytes at most")
@@ -162,7 +162,8 @@ class OneShotAllReduce:
         self._check(self._lib.hymeta_p2p_all_reduce(self._comm, data.data_ptr() if data is not None else None,
                                                     data.numel() if data is not None else 0,
                                                     stats.data_ptr() if stats is not None else None,
-                                                    stats.numel() if stats is not None else 0, stream), "hymeta_p2p_all_reduce")
+                                                    stats.numel() if stats is not None else 0, float(stats_scale), stream),
+                    "hymeta_p2p_all_reduce")
 
     def set_wait_limit(self, seconds: float) -> None:
         self._check(self._lib.hymeta_p2p_set_wait_limit(self._comm, max(1, int(seconds * 1e8))), "hymeta_p2p_set_wait_limit")
@@ -292,11 +293,12 @@ def all_reduce_variance(stats: torch.Tensor, group: Optional[dist.ProcessGroup] 
     where the reference sends two ``[T, 1]`` ones (``modeling_hymeta.py:158-160``)."""
     if _active(group):
         comm = _exchange_of(group)
+        size = tp_rank_and_size(group)[1]
         if comm is not None and (comm.supports(None, stats) or isinstance(group, InProcessGroup)):
-            comm.all_reduce(stats=stats)
+            comm.all_reduce(stats=stats, stats_scale=1.0 / size)      # the division rides in the exchange: no launch of its own
         else:
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-        stats /= tp_rank_and_size(group)[1]
+            stats /= size
     return stats
 
 
