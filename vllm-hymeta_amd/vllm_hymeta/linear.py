@@ -90,3 +90,42 @@ class HymetaLinear(torch.nn.Module):
             acc = torch._int_mm(xq, self.qweight.t())
             return hip_ops.w8a8_scale_out(acc, xs, self.w_scale, bias=self.bias)
         return hip_ops.w8a8_gemm(x, self.qweight, self.w_scale, bias=self.bias, defer=defer)
+
+
+class LinearColumns(torch.nn.Module):
+    """Output columns ``[lo, hi)`` of a linear layer that several consumers share: the qkv projections of the two
+    branches of the 70B attention read the same input, so the layer holds them as ONE linear (one weight stream, one
+    launch) and hands each branch its columns; a branch called on its own (the meta tokens' one-off pass, a test of one
+    branch) runs the shared linear through this view.  ``kind`` / ``weight`` / ``qweight`` / ``bias`` read as the
+    branch's own projection would."""
+
+    def __init__(self, parent: HymetaLinear, lo: int, hi: int):
+        super().__init__()
+        self._shared = (parent,)      # in a tuple: the owner registers the module, this view does not register it again
+        self.lo, self.hi = lo, hi
+
+    @property
+    def parent(self) -> HymetaLinear:
+        return self._shared[0]
+
+    @property
+    def kind(self) -> str:
+        return self.parent.kind
+
+    @property
+    def weight(self) -> torch.Tensor:
+        return self.parent.weight[self.lo:self.hi]
+
+    @property
+    def qweight(self) -> torch.Tensor:
+        q = self.parent.qweight
+        return q[:, self.lo:self.hi] if self.kind == "gptq" else q[self.lo:self.hi]
+
+    @property
+    def bias(self) -> Optional[torch.Tensor]:
+        b = self.parent.bias
+        return None if b is None else b[self.lo:self.hi]
+
+    def forward(self, x: torch.Tensor, defer: bool = False) -> torch.Tensor:
+        return self.parent(x)[:, self.lo:self.hi]
+

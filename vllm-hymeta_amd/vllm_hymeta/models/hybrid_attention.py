@@ -49,10 +49,11 @@ class HLinearAttention(torch.nn.Module):
         lb = lower_bound.view(-1, D)[self.shard.head_start:self.shard.head_start + H].contiguous().float()
         return dict(gate_mode=_C.GATE_70B_LOWER_BOUND, lower_bound=lb)
 
-    def _qkv(self, hidden_states: torch.Tensor):
+    def _qkv(self, hidden_states: torch.Tensor, qkv: Optional[torch.Tensor] = None):
         H, Hkv, D = self.shard.num_heads, self.shard.num_kv_heads, self.head_dim
         T = hidden_states.shape[0]
-        qkv = self.qkv_proj(hidden_states)
+        if qkv is None:
+            qkv = self.qkv_proj(hidden_states)
         return (qkv[:, : H * D].view(T, H, D), qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D),
                 qkv[:, (H + Hkv) * D:].view(T, Hkv, D))
 
@@ -71,10 +72,11 @@ class HLinearAttention(torch.nn.Module):
 
     def forward(self, hidden_states: torch.Tensor, hymeta_cache: torch.Tensor, meta_linear_cache: torch.Tensor,
                 state_indices_tensor: torch.Tensor, attn_metadata,
-                lower_bound: Optional[torch.Tensor] = None) -> torch.Tensor:
+                lower_bound: Optional[torch.Tensor] = None, qkv: Optional[torch.Tensor] = None) -> torch.Tensor:
         """hidden_states ``[T, hidden]`` real tokens (prefills first, then decodes); returns
-        ``[T, H_local * D]`` (no norm, no projection: those belong to ``IntraHybridAttention``)."""
-        q, k, v = self._qkv(hidden_states)
+        ``[T, H_local * D]`` (no norm, no projection: those belong to ``IntraHybridAttention``).
+        ``qkv``: this branch's projection of ``hidden_states`` when the caller has computed it already."""
+        q, k, v = self._qkv(hidden_states, qkv)
         T, H, D = q.shape
         out = torch.empty(T, H, D, dtype=hidden_states.dtype, device=hidden_states.device)
         gate = self._gate(lower_bound)
@@ -121,10 +123,11 @@ class MetaFlashAttention(torch.nn.Module):
             raise ValueError("attention layer and head shard disagree on the head geometry")
         self.attn = attn
 
-    def _qkv(self, hidden_states, positions, offset):
+    def _qkv(self, hidden_states, positions, offset, qkv=None):
         H, Hkv, D = self.shard.num_heads, self.shard.num_kv_heads, self.head_dim
         T = hidden_states.shape[0]
-        qkv = self.qkv_proj(hidden_states)
+        if qkv is None:
+            qkv = self.qkv_proj(hidden_states)
         q = qkv[:, : H * D].view(T, H, D)
         k = qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
         v = qkv[:, (H + Hkv) * D:].view(T, Hkv, D)
@@ -145,15 +148,16 @@ class MetaFlashAttention(torch.nn.Module):
         return out.view(M, -1)
 
     def forward(self, hidden_states: torch.Tensor, positions: torch.Tensor, kv_cache: Optional[torch.Tensor],
-                meta_fattn_cache: torch.Tensor, attn_metadata=None) -> torch.Tensor:
+                meta_fattn_cache: torch.Tensor, attn_metadata=None, qkv: Optional[torch.Tensor] = None) -> torch.Tensor:
         """positions are the sequence positions of the real tokens; the meta tokens occupy 0..M-1, so
         real token p is roped at p + M (reference ``modeling_hymeta.py:1314-1323``).
 
         The attention itself runs through the registered layer ``self.attn`` and the opaque op
         (reference ``:795``), which reads the paged cache bound to that layer and the step's metadata from
         the forward context.  ``kv_cache`` / ``attn_metadata`` given explicitly (callers without an engine)
-        are bound / set for the call."""
-        q, k, v = self._qkv(hidden_states, positions, self.num_meta_tokens)
+        are bound / set for the call.  ``qkv``: this branch's projection of ``hidden_states`` when the caller has
+        computed it already (roped in place here)."""
+        q, k, v = self._qkv(hidden_states, positions, self.num_meta_tokens, qkv)
         T, H, D = q.shape
         if kv_cache is not None:
             bind_kv_cache(self.attn, kv_cache)
@@ -167,11 +171,17 @@ class MetaFlashAttention(torch.nn.Module):
 
 class IntraHybridAttention(torch.nn.Module):
     def __init__(self, vanilla_attn: MetaFlashAttention, linear_attn: HLinearAttention, out_proj: HymetaLinear,
-                 norm1_weight: torch.Tensor, norm2_weight: torch.Tensor, norm_eps: float = 1e-6, tp_group=None):
+                 norm1_weight: torch.Tensor, norm2_weight: torch.Tensor, norm_eps: float = 1e-6, tp_group=None,
+                 merged_qkv: Optional[HymetaLinear] = None):
         """``norm1_weight`` / ``norm2_weight``: this rank's slice (fp32 ``[hidden / tp]``) of the two
-        full-hidden RMS-norm weights (reference ``HymetaRMSNormTP.weight_loader``, ``:138-149``)."""
+        full-hidden RMS-norm weights (reference ``HymetaRMSNormTP.weight_loader``, ``:138-149``).
+
+        ``merged_qkv``: the two branches' qkv projections as one linear (output = the softmax branch's columns, then
+        the GLA branch's; the branches then hold ``LinearColumns`` views of it): both read the same normed input, so
+        the layer runs one GEMM over one weight stream and hands each branch its columns."""
         super().__init__()
         self.vanilla_attn, self.linear_attn, self.out_proj = vanilla_attn, linear_attn, out_proj
+        self.merged_qkv = merged_qkv
         self.register_buffer("norm1_weight", norm1_weight.float().contiguous())
         self.register_buffer("norm2_weight", norm2_weight.float().contiguous())
         self.norm_eps = norm_eps
@@ -200,9 +210,14 @@ class IntraHybridAttention(torch.nn.Module):
                 state_indices_tensor, attn_metadata=None, lower_bound=None, defer_out: bool = False):
         if attn_metadata is None:
             attn_metadata = current_attn_metadata()
-        out_attn = self.vanilla_attn(hidden_states, positions, kv_cache, meta_fattn_cache, attn_metadata)
+        qkv_attn = qkv_linear = None
+        if self.merged_qkv is not None:
+            both = self.merged_qkv(hidden_states)
+            half = both.shape[1] // 2
+            qkv_attn, qkv_linear = both[:, :half], both[:, half:]
+        out_attn = self.vanilla_attn(hidden_states, positions, kv_cache, meta_fattn_cache, attn_metadata, qkv=qkv_attn)
         out_linear = self.linear_attn(hidden_states, hymeta_cache, meta_linear_cache, state_indices_tensor,
-                                      attn_metadata, lower_bound)
+                                      attn_metadata, lower_bound, qkv=qkv_linear)
         reduce = parallel._active(self.tp_group)
         y = self.out_proj(self.combine(out_attn, out_linear), defer=defer_out and not reduce)
         return all_reduce_sum(y, self.tp_group) if reduce else y

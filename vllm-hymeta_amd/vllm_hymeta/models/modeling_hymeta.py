@@ -28,7 +28,7 @@ import torch
 
 from .. import loader
 from .._compat import HasInnerState, IntermediateTensors, IsHybrid, SupportsPP, SupportsV0Only, model_build_args
-from ..linear import HymetaLinear
+from ..linear import HymetaLinear, LinearColumns
 from ..lm_head import LmHeadMixin, lm_head_logits
 from ..model_for_7B.window_attention import rope_cos_sin_cache
 from ..parallel import shard_heads, tp_rank_and_size
@@ -299,14 +299,17 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}"
 
-            def qkv(branch: str) -> HymetaLinear:
-                return make(loader.concat_out_features([lin(f"{p}.attn.{branch}.qkv_proj", s) for s in ("q", "k", "v")]))
-
-            vanilla = MetaFlashAttention(cfg.hidden_size, H, KVH, qkv("vanilla_attn"), m.cos_sin_cache, _layer_window(cfg, i),
-                                         num_meta_tokens=m.num_meta_tokens, shard=sh, attn=m.attn_layers[i])
-            linear = HLinearAttention(cfg.hidden_size, H, KVH, qkv("linear_attn"), i, num_meta_tokens=m.num_meta_tokens, shard=sh)
+            # both branches project the same normed input: one linear for the six projections (the softmax branch's
+            # q | k | v columns, then the GLA branch's), each branch a view of its columns
+            both = make(loader.concat_out_features([lin(f"{p}.attn.{branch}.qkv_proj", s)
+                                                    for branch in ("vanilla_attn", "linear_attn") for s in ("q", "k", "v")]))
+            width = (sh.num_heads + 2 * sh.num_kv_heads) * cfg.head_dim
+            vanilla = MetaFlashAttention(cfg.hidden_size, H, KVH, LinearColumns(both, 0, width), m.cos_sin_cache,
+                                         _layer_window(cfg, i), num_meta_tokens=m.num_meta_tokens, shard=sh, attn=m.attn_layers[i])
+            linear = HLinearAttention(cfg.hidden_size, H, KVH, LinearColumns(both, width, 2 * width), i,
+                                      num_meta_tokens=m.num_meta_tokens, shard=sh)
             attn = IntraHybridAttention(vanilla, linear, make(lin(f"{p}.attn.out_proj")), plain[f"{p}.attn.norm1.weight"],
-                                        plain[f"{p}.attn.norm2.weight"], cfg.norm_eps, tp_group=m.tp_group)
+                                        plain[f"{p}.attn.norm2.weight"], cfg.norm_eps, tp_group=m.tp_group, merged_qkv=both)
             n_experts = _layer_experts(cfg, i)
             if n_experts == 1:
                 ffn = mlp(f"{p}.mlp")
