@@ -887,7 +887,12 @@ int hymeta_moe_combine(const hymeta_moe_combine_args* args, hymeta_stream_t stre
  *                                room for messages of max_message_bytes) and, when ipc_handle is not NULL, writes its
  *                                HYMETA_P2P_HANDLE_BYTES-byte HIP IPC handle there; world in {1, 2, 4, 8}
  *   hymeta_p2p_connect           all_handles = the world handles in rank order (the caller gathers them, e.g. with an
- *                                all-gather of its process group); maps the peers' buffers
+ *                                all-gather of its process group); peer_devices = the ranks' device ordinals as THIS
+ *                                process numbers them, or NULL.  Checks peer access, maps the peers' buffers and writes a
+ *                                token into each with a runtime copy; anything that does not work is an error code here
+ *                                (HYMETA_ERR_UNSUPPORTED), never a fault in a kernel later
+ *   hymeta_p2p_verify            after every rank has connected (a barrier of the caller's): HYMETA_OK when the token of
+ *                                every mapped peer has arrived in this rank's buffer
  *   hymeta_p2p_connect_pointers  the same for ranks that live in one process: buffers[q] = hymeta_p2p_local_buffer of
  *                                rank q's communicator
  *   hymeta_p2p_all_reduce        in place: data_bf16[0 .. n_bf16) and stats[0 .. n_stats) become their sums over the
@@ -908,7 +913,8 @@ typedef struct hymeta_p2p_comm hymeta_p2p_comm;
 
 int hymeta_p2p_create(int rank, int world, size_t max_message_bytes, hymeta_p2p_comm** comm, void* ipc_handle);
 void* hymeta_p2p_local_buffer(const hymeta_p2p_comm* comm);
-int hymeta_p2p_connect(hymeta_p2p_comm* comm, const void* all_handles);
+int hymeta_p2p_connect(hymeta_p2p_comm* comm, const void* all_handles, const int32_t* peer_devices);
+int hymeta_p2p_verify(hymeta_p2p_comm* comm);
 int hymeta_p2p_connect_pointers(hymeta_p2p_comm* comm, void* const* buffers);
 int hymeta_p2p_set_wait_limit(hymeta_p2p_comm* comm, uint64_t ticks_100mhz);
 int hymeta_p2p_all_reduce(hymeta_p2p_comm* comm, void* data_bf16, int64_t n_bf16, float* stats, int64_t n_stats,

@@ -10,6 +10,7 @@
 //   exchange buffer of a rank (device memory allocated uncached, so that neither the writer's nor the
 //   reader's L2 keeps lines of it; mapped into the peers through HIP IPC handles):
 //     flags [2 parities][kMaxWorld][kMaxBlocks] u32     the epoch a (rank, block) has delivered
+//     probe [kMaxWorld] u32 (+ padding)                 set-up only: every peer writes a token here with a runtime copy
 //     slots [2 parities][W][slot_bytes]                 the messages, fp32 part first, then bf16
 //   state of a rank (ordinary device memory, local): epoch, block ticket, timeouts
 //
@@ -33,7 +34,9 @@ namespace {
 constexpr int kMaxWorld = 8;
 constexpr int kMaxBlocks = 64;
 constexpr int kThreads = 256;
-constexpr size_t kFlagBytes = 2ull * kMaxWorld * kMaxBlocks * sizeof(uint32_t);   // 4 KB
+constexpr size_t kProbeOffset = 2ull * kMaxWorld * kMaxBlocks * sizeof(uint32_t);   // behind the 4 KB of flags
+constexpr size_t kFlagBytes = kProbeOffset + 256;    // flags + one probe word per rank (set-up check of the mappings)
+constexpr uint32_t kProbeToken = 0xA5C30000u;
 constexpr uint64_t kDefaultSpinTicks = 200000000ull;   // 2 s of the 100 MHz wall clock
 
 struct P2pArgs {
@@ -198,9 +201,23 @@ extern "C" void* hymeta_p2p_local_buffer(const hymeta_p2p_comm* comm) {
   return comm != nullptr ? comm->peers[comm->rank] : nullptr;
 }
 
-extern "C" int hymeta_p2p_connect(hymeta_p2p_comm* comm, const void* all_handles) {
+extern "C" int hymeta_p2p_connect(hymeta_p2p_comm* comm, const void* all_handles, const int32_t* peer_devices) {
   using namespace hymeta;
   if (comm == nullptr || all_handles == nullptr || comm->connected) return HYMETA_ERR_INVALID_ARG;
+  // Every way in which a mapping can be unusable must show up HERE as an error code: a kernel that stores through a
+  // bad peer pointer faults the GPU.  So: peer access must be reported possible, the handle must open, and a runtime
+  // copy of a token into the peer's probe word must succeed (hymeta_p2p_verify then checks that every peer's token
+  // has arrived in the own buffer).
+  if (peer_devices != nullptr) {
+    for (int q = 0; q < comm->world; ++q) {
+      if (q == comm->rank || peer_devices[q] == comm->device) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, comm->device, peer_devices[q]) != hipSuccess || !can) {
+        (void)hipGetLastError();
+        return HYMETA_ERR_UNSUPPORTED;
+      }
+    }
+  }
   for (int q = 0; q < comm->world; ++q) {
     if (q == comm->rank) continue;
     hipIpcMemHandle_t h;
@@ -219,7 +236,34 @@ extern "C" int hymeta_p2p_connect(hymeta_p2p_comm* comm, const void* all_handles
     comm->peers[q] = static_cast<char*>(p);
     comm->opened[q] = true;
   }
+  for (int q = 0; q < comm->world; ++q) {
+    if (q == comm->rank) continue;
+    const uint32_t token = kProbeToken | static_cast<uint32_t>(comm->rank);
+    if (hipMemcpy(comm->peers[q] + kProbeOffset + sizeof(uint32_t) * comm->rank, &token, sizeof(token), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipGetLastError();
+      for (int r = 0; r < comm->world; ++r)
+        if (comm->opened[r]) {
+          (void)hipIpcCloseMemHandle(comm->peers[r]);
+          comm->opened[r] = false;
+          comm->peers[r] = nullptr;
+        }
+      return HYMETA_ERR_UNSUPPORTED;
+    }
+  }
   comm->connected = true;
+  return HYMETA_OK;
+}
+
+extern "C" int hymeta_p2p_verify(hymeta_p2p_comm* comm) {
+  using namespace hymeta;
+  if (comm == nullptr || !comm->connected) return HYMETA_ERR_INVALID_ARG;
+  uint32_t probe[kMaxWorld] = {};
+  if (hipMemcpy(probe, comm->peers[comm->rank] + kProbeOffset, sizeof(probe), hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return HYMETA_ERR_LAUNCH;
+  }
+  for (int q = 0; q < comm->world; ++q)
+    if (q != comm->rank && comm->opened[q] && probe[q] != (kProbeToken | static_cast<uint32_t>(q))) return HYMETA_ERR_UNSUPPORTED;
   return HYMETA_OK;
 }
 

@@ -274,7 +274,8 @@ _SIGNATURES = {
     "hymeta_advance_step": (C.c_int, [_i32, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
     "hymeta_p2p_create": (C.c_int, [C.c_int, C.c_int, _sz, C.POINTER(_ptr), _ptr]),
     "hymeta_p2p_local_buffer": (_ptr, [_ptr]),
-    "hymeta_p2p_connect": (C.c_int, [_ptr, _ptr]),
+    "hymeta_p2p_connect": (C.c_int, [_ptr, _ptr, _ptr]),
+    "hymeta_p2p_verify": (C.c_int, [_ptr]),
     "hymeta_p2p_connect_pointers": (C.c_int, [_ptr, C.POINTER(_ptr)]),
     "hymeta_p2p_set_wait_limit": (C.c_int, [_ptr, C.c_uint64]),
     "hymeta_p2p_all_reduce": (C.c_int, [_ptr, _ptr, _i64, _ptr, _i64, _f32, _ptr]),

@@ -108,21 +108,39 @@ class OneShotAllReduce:
             self.group = group
         except Exception as exc:
             err = f"rank {rank}: {exc}"
-        mine = torch.tensor(list(self.handle if self is not None else bytes(64)) + [0 if err else 1], dtype=torch.uint8).to(where)
-        gathered = torch.empty(world * 65, dtype=torch.uint8, device=where)
+        # per rank: the 64-byte handle, a success byte, the device ordinal (one process per GPU on one node sees all of the
+        # node's GPUs under the same ordinals)
+        dev_index = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        mine = torch.tensor(list(self.handle if self is not None else bytes(64)) + [0 if err else 1, dev_index],
+                            dtype=torch.uint8).to(where)
+        gathered = torch.empty(world * 66, dtype=torch.uint8, device=where)
         dist.all_gather_into_tensor(gathered, mine, group=group)
-        rows = gathered.cpu().view(world, 65)
+        rows = gathered.cpu().view(world, 66)
+
+        def agree(err_now: str) -> bool:      # the same verdict on every rank; also a barrier
+            ok = torch.tensor([0.0 if err_now else 1.0], device=where)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            return ok.item() == 1.0
+
         if bool(rows[:, 64].all()):
             try:
+                devices = (self._C.c_int32 * world)(*[int(d) for d in rows[:, 65]])
                 with torch.cuda.device(self.device):
-                    self._check(self._lib.hymeta_p2p_connect(self._comm, bytes(rows[:, :64].reshape(-1).tolist())), "hymeta_p2p_connect")
+                    self._check(self._lib.hymeta_p2p_connect(self._comm, bytes(rows[:, :64].reshape(-1).tolist()), devices),
+                                "hymeta_p2p_connect")
             except Exception as exc:
                 err = f"rank {rank}: {exc}"
         elif not err:
             err = "another rank could not create its exchange buffer"
-        ok = torch.tensor([0.0 if err else 1.0], device=where)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)      # also the barrier before the first exchange
-        if ok.item() != 1.0:
+        good = agree(err)
+        if good:
+            try:      # every rank has written its token into every buffer: look for them in the own one
+                with torch.cuda.device(self.device):
+                    self._check(self._lib.hymeta_p2p_verify(self._comm), "hymeta_p2p_verify")
+            except Exception as exc:
+                err = f"rank {rank}: {exc}"
+            good = agree(err)
+        if not good:
             if self is not None:
                 self.group = None
                 self.close()
