@@ -17,6 +17,7 @@ connectors (``:286-314``) are vLLM's and are not restated.
 from __future__ import annotations
 
 import contextlib
+import threading
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -26,19 +27,26 @@ from ..attention.meta_attention import MetaAttentionBackend
 
 # ------------------------------------------------------------------ forward context without vLLM
 _LAYERS: Dict[str, "MetaAttention"] = {}      # static_forward_context / no_compile_layers
-_STEP: Dict[str, Any] = {"attn_metadata": None, "virtual_engine": 0}
+class _Step(threading.local):
+    """The step a thread is running: per thread, so that ranks which share a process (each on its own thread and
+    stream) do not see each other's metadata."""
+    attn_metadata: Any = None
+    virtual_engine: int = 0
+
+
+_STEP = _Step()
 
 
 @contextlib.contextmanager
 def forward_context(attn_metadata, virtual_engine: int = 0):
     """The step's attention metadata for every ``MetaAttention`` layer called inside the block
     (what ``vllm.forward_context.set_forward_context`` provides under vLLM)."""
-    saved = dict(_STEP)
-    _STEP.update(attn_metadata=attn_metadata, virtual_engine=virtual_engine)
+    saved = (_STEP.attn_metadata, _STEP.virtual_engine)
+    _STEP.attn_metadata, _STEP.virtual_engine = attn_metadata, virtual_engine
     try:
         yield
     finally:
-        _STEP.update(saved)
+        _STEP.attn_metadata, _STEP.virtual_engine = saved
 
 
 _standalone = [0]
@@ -69,11 +77,11 @@ def bind_kv_cache(layer: "MetaAttention", kv_cache: torch.Tensor, virtual_engine
 def _context():
     """``(attn_metadata, virtual_engine, layers by name)`` of the current step: what a caller set with
     ``forward_context()`` if anything, else vLLM's forward context."""
-    if HAVE_VLLM and _STEP["attn_metadata"] is None:   # pragma: no cover - only where vLLM is installed
+    if HAVE_VLLM and _STEP.attn_metadata is None:   # pragma: no cover - only where vLLM is installed
         from vllm.forward_context import get_forward_context
         ctx = get_forward_context()
         return ctx.attn_metadata, ctx.virtual_engine, ctx.no_compile_layers
-    return _STEP["attn_metadata"], _STEP["virtual_engine"], _LAYERS
+    return _STEP.attn_metadata, _STEP.virtual_engine, _LAYERS
 
 
 class MetaAttention(torch.nn.Module):
