@@ -117,7 +117,7 @@ class OneShotAllReduce:
         dist.all_gather_into_tensor(gathered, mine, group=group)
         rows = gathered.cpu().view(world, 66)
 
-        def agree(err_now: str) -> bool:      # the same verdict on every rank; also a barrier
+        def agree(err_now: str) -> bool:      # the same answer on every rank; also a barrier
             ok = torch.tensor([0.0 if err_now else 1.0], device=where)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
             return ok.item() == 1.0
@@ -254,7 +254,7 @@ def one_shot_self_check(group: dist.ProcessGroup, device: torch.device, rows=(1,
                         rounds: int = 3) -> Tuple[bool, str]:
     """Run the group's one-shot exchange on random messages of the decode step's shapes and compare, on every rank, with
     the rank-ordered sum of the all-gathered inputs (RCCL) -- bit for bit -- and with zero timeouts.  Returns the same
-    verdict on all ranks."""
+    answer on all ranks."""
     comm = _ONE_SHOT.get(group)
     if comm is None:
         return False, "not enabled"
