@@ -123,3 +123,39 @@ def test_swa_32k_chunked_paged_prefill_and_decode_agree_with_single_pass(H, Hkv,
     rhs = attn(va, v2) + attn(vb, v2b)
     torch.cuda.synchronize()
     assert_bf16_close(lhs.cpu(), rhs.cpu(), "linearity in V", rel=8e-3, frac=2.0 ** -5)
+
+
+@pytest.mark.parametrize("T", [64, 256])
+def test_expert_mixture_at_the_tp4_rank_size_against_fp32_torch(T):
+    """The sparse mixture at the size one TP=4 rank of the 70B model runs it (16 experts, hidden 3584, a quarter of the
+    18944-wide experts, top-1 with the softmax probability as weight, shared expert added; 64 tokens = the 16-row tiles of
+    the whole-line expert GEMM, 256 tokens = its 64-row tiles), router inside the routing launch, against plain fp32
+    torch GEMMs on the GPU with the block's rounding points (every projection, the activation and the weighted expert
+    output rounded to bf16; the routing on the logits the block itself routed)."""
+    from vllm_hymeta import hip_ops
+
+    dev = torch.device("cuda")
+    g_ = torch.Generator(device=dev).manual_seed(77 + T)
+    E, H, inter = 16, 3584, 18944 // 4
+    rnd = lambda *shape, scale=1.0: (torch.randn(*shape, generator=g_, device=dev) * scale).to(torch.bfloat16)
+    x, gate = rnd(T, H), rnd(E, H, scale=0.02)
+    w13, w2 = rnd(E, 2 * inter, H, scale=H ** -0.5), rnd(E, H, inter, scale=inter ** -0.5)
+    shared = rnd(T, H)
+    logits = torch.empty(T, E, dtype=torch.bfloat16, device=dev)
+    assert hip_ops.moe_router_fused(x, gate)
+    out = hip_ops.moe_forward(x, None, w13, w2, top_k=1, shared=shared, gate_weight=gate, logits_out=logits)
+    torch.cuda.synchronize()
+
+    lin = torch.nn.functional.linear(x.float(), gate.float())
+    assert float((logits.float() - lin).abs().max()) <= 2.0 ** -7 * float(lin.abs().max()) + 2e-5      # one bf16 ulp
+    probs = torch.softmax(logits.float(), dim=-1)
+    w, ids = probs.max(dim=-1)
+    assert ids.unique().numel() >= 8, "the test is meant to spread its tokens over the experts"
+    ref = torch.empty(T, H, dtype=torch.bfloat16, device=dev)
+    for e in ids.unique().tolist():
+        rows = (ids == e).nonzero().squeeze(1)
+        h = (x[rows].float() @ w13[e].float().t()).to(torch.bfloat16)
+        act = (torch.nn.functional.silu(h[:, :inter].float()) * h[:, inter:].float()).to(torch.bfloat16)
+        y = ((act.float() @ w2[e].float().t()) * w[rows].unsqueeze(1)).to(torch.bfloat16)
+        ref[rows] = (y.float() + shared[rows].float()).to(torch.bfloat16)
+    assert_bf16_close(out.cpu(), ref.cpu(), f"expert mixture, {T} tokens at the TP=4 rank size", rel=8e-3)
