@@ -919,6 +919,12 @@ int hymeta_p2p_connect_pointers(hymeta_p2p_comm* comm, void* const* buffers);
 int hymeta_p2p_set_wait_limit(hymeta_p2p_comm* comm, uint64_t ticks_100mhz);
 int hymeta_p2p_all_reduce(hymeta_p2p_comm* comm, void* data_bf16, int64_t n_bf16, float* stats, int64_t n_stats,
                           float stats_scale, hymeta_stream_t stream);
+/* The same exchange for a K-sliced linear's result that is still in its partial sums (hymeta_*_gemm_deferred): the
+ * push adds the slices while it reads them -- the bits hymeta_gemm_partials_reduce would have written -- and the sum over
+ * the ranks goes to out_bf16 [M, N] contiguous: the row-parallel projection's reduce launch disappears into its
+ * all-reduce.  M * N * 2 <= max_message_bytes, N a multiple of 8. */
+int hymeta_p2p_all_reduce_partials(hymeta_p2p_comm* comm, const hymeta_gemm_partials* partials, void* out_bf16,
+                                   hymeta_stream_t stream);
 int hymeta_p2p_timeouts(hymeta_p2p_comm* comm, uint32_t* count);
 int hymeta_p2p_destroy(hymeta_p2p_comm* comm);
 

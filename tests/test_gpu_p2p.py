@@ -142,3 +142,41 @@ def test_limits_and_unsupported_messages():
     torch.cuda.synchronize()
     assert torch.equal(x, torch.ones_like(x)) and c.timeouts() == 0
     _close(comms)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "w8a8"])
+def test_exchange_takes_a_k_sliced_linear_straight_from_its_partial_sums(kind):
+    """A row-parallel projection in front of its all-reduce: each rank's K-sliced linear leaves its slices' sum to the
+    exchange, which adds them as it reads its message -- the same bits as reduce launch + exchange of the tensor."""
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta.linear import HymetaLinear
+
+    world, rows, K, N = 2, 20, 2048, 1024
+    comms, streams, dev = _ranks(world)
+    g_ = gen(70)
+    lins, xs = [], []
+    for r in range(world):
+        w = randn_bf16(g_, N, K, scale=K ** -0.5)
+        if kind == "w8a8":
+            s = w.float().abs().amax(1, keepdim=True).clamp_min(1e-8) / 127
+            lins.append(HymetaLinear.from_w8a8(torch.clamp(torch.round(w.float() / s), -127, 127).to(torch.int8).to(dev), s.float().to(dev)))
+        else:
+            lins.append(HymetaLinear.from_weight(w.to(dev)))
+        xs.append(randn_bf16(g_, rows, K).to(dev))
+    torch.cuda.synchronize()
+    plain = []
+    for lin, x, st in zip(lins, xs, streams):
+        with torch.cuda.stream(st):
+            plain.append(lin(x))
+    torch.cuda.synchronize()
+    ref = _reference(plain, torch.bfloat16)
+    outs = []
+    for c, lin, x, st in zip(comms, lins, xs, streams):
+        with torch.cuda.stream(st):
+            p = lin(x, defer=True)
+            assert isinstance(p, hip_ops.PartialSums), "the case is meant to be K-sliced"
+            outs.append(c.all_reduce_partials(p))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for o in outs) and all(c.timeouts() == 0 for c in comms)
+    _close(comms)
+

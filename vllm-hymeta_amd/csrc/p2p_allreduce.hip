@@ -24,6 +24,7 @@
 // Every wait is bounded by wall-clock ticks; a block that gives up counts a timeout in the state and
 // goes on (its output is then undefined), so that every launch ends whatever the peers do.
 #include "common.h"
+#include "partial_sums.h"
 
 #include <cstring>
 #include <new>
@@ -49,13 +50,18 @@ struct P2pArgs {
   uint64_t spin_ticks;
   int rank, units_per_block;
   float stats_scale;        // the fp32 sums are multiplied by it (1 / W turns the sum of the ranks' means into the mean)
+  hymeta_gemm_partials partials;   // MODE 1 / 2: the message is a K-sliced linear's result, still in its partial sums
+  uint16_t* out;                   // MODE 1 / 2: where the sum over the ranks goes (bf16 [M, N] contiguous)
 };
 
 __device__ __forceinline__ uint32_t* flag_ptr(char* buf, int parity, int rank, int block) {
   return reinterpret_cast<uint32_t*>(buf) + (static_cast<size_t>(parity) * kMaxWorld + rank) * kMaxBlocks + block;
 }
 
-template <int W>
+// MODE 0: the message is data / stats.  MODE 1 (fp32 slabs) / 2 (int32 slabs, W8A8): the message is the bf16 result
+// of a K-sliced linear that has not run its reduce launch; the push adds the slices while it reads them (the bits that
+// launch would have written) and the sum over the ranks goes to a.out.
+template <int W, int MODE>
 __global__ __launch_bounds__(kThreads) void p2p_all_reduce_kernel(P2pArgs a) {
   __shared__ uint32_t s_epoch;
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -70,7 +76,13 @@ __global__ __launch_bounds__(kThreads) void p2p_all_reduce_kernel(P2pArgs a) {
   // push this block's share of the message into slot [rank] of every rank's buffer (its own too)
   for (int64_t u = u_lo + tid; u < u_hi; u += kThreads) {
     u32x4 v;
-    if (u < a.units_stats) {
+    if constexpr (MODE != 0) {
+      const int64_t t = 8 * u / a.partials.N;
+      const int col = static_cast<int>(8 * u - t * a.partials.N);
+      float x[8];
+      partial_row8<MODE == 2>(a.partials, t, col, x);
+      v = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
+    } else if (u < a.units_stats) {
       float f[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) f[i] = 4 * u + i < a.n_stats ? a.stats[4 * u + i] : 0.f;
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void p2p_all_reduce_kernel(P2pArgs a) {
           f[2 * i + 1] += hi_bf(v[q][i]);
         }
       const u32x4 o = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
-      *reinterpret_cast<u32x4*>(a.data + 8 * (u - a.units_stats)) = o;
+      *reinterpret_cast<u32x4*>((MODE != 0 ? a.out : a.data) + 8 * (u - a.units_stats)) = o;
     }
   }
 
@@ -139,6 +151,23 @@ __global__ __launch_bounds__(kThreads) void p2p_all_reduce_kernel(P2pArgs a) {
       __hip_atomic_store(a.state, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+template <int MODE>
+int launch_exchange(int world, P2pArgs& a, hymeta_stream_t stream) {
+  // 4 units per thread and block at least; every rank derives the same grid from the same sizes
+  const int64_t want = (a.units + 4 * kThreads - 1) / (4 * kThreads);
+  const int blocks = static_cast<int>(want < 1 ? 1 : want > kMaxBlocks ? kMaxBlocks : want);
+  a.units_per_block = static_cast<int>((a.units + blocks - 1) / blocks);
+  hipStream_t s = begin_launches(stream);
+  switch (world) {
+    case 1: hipLaunchKernelGGL((p2p_all_reduce_kernel<1, MODE>), dim3(blocks), dim3(kThreads), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((p2p_all_reduce_kernel<2, MODE>), dim3(blocks), dim3(kThreads), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((p2p_all_reduce_kernel<4, MODE>), dim3(blocks), dim3(kThreads), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((p2p_all_reduce_kernel<8, MODE>), dim3(blocks), dim3(kThreads), 0, s, a); break;
+    default: return HYMETA_ERR_UNSUPPORTED;
+  }
+  return launch_status();
 }
 
 }  // namespace
@@ -309,19 +338,37 @@ extern "C" int hymeta_p2p_all_reduce(hymeta_p2p_comm* comm, void* data_bf16, int
   a.spin_ticks = comm->spin_ticks;
   a.rank = comm->rank;
   a.stats_scale = stats_scale;
-  // 4 units per thread and block at least; every rank derives the same grid from the same sizes
-  const int64_t want = (a.units + 4 * kThreads - 1) / (4 * kThreads);
-  const int blocks = static_cast<int>(want < 1 ? 1 : want > kMaxBlocks ? kMaxBlocks : want);
-  a.units_per_block = static_cast<int>((a.units + blocks - 1) / blocks);
-  hipStream_t s = begin_launches(stream);
-  switch (comm->world) {
-    case 1: hipLaunchKernelGGL((p2p_all_reduce_kernel<1>), dim3(blocks), dim3(kThreads), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((p2p_all_reduce_kernel<2>), dim3(blocks), dim3(kThreads), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((p2p_all_reduce_kernel<4>), dim3(blocks), dim3(kThreads), 0, s, a); break;
-    case 8: hipLaunchKernelGGL((p2p_all_reduce_kernel<8>), dim3(blocks), dim3(kThreads), 0, s, a); break;
-    default: return HYMETA_ERR_UNSUPPORTED;
-  }
-  return launch_status();
+  a.partials = hymeta_gemm_partials{};
+  a.out = nullptr;
+  return launch_exchange<0>(comm->world, a, stream);
+}
+
+extern "C" int hymeta_p2p_all_reduce_partials(hymeta_p2p_comm* comm, const hymeta_gemm_partials* partials, void* out_bf16,
+                                              hymeta_stream_t stream) {
+  using namespace hymeta;
+  if (comm == nullptr || partials == nullptr || out_bf16 == nullptr || !comm->connected) return HYMETA_ERR_INVALID_ARG;
+  const hymeta_gemm_partials& p = *partials;
+  if (p.splits <= 0 || p.slabs == nullptr || p.M <= 0 || p.N <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (p.is_int32 && (p.x_scale == nullptr || p.w_scale == nullptr)) return HYMETA_ERR_INVALID_ARG;
+  if (p.N % 8 != 0 || reinterpret_cast<uintptr_t>(out_bf16) % 16 != 0 || reinterpret_cast<uintptr_t>(p.slabs) % 16 != 0 ||
+      reinterpret_cast<uintptr_t>(p.bias) % 16 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  P2pArgs a;
+  a.units_stats = 0;
+  a.n_stats = 0;
+  a.units = static_cast<int64_t>(p.M) * p.N / 8;
+  if (static_cast<size_t>(a.units) * 16 > comm->max_bytes) return HYMETA_ERR_SCRATCH_LIMIT;
+  for (int q = 0; q < kMaxWorld; ++q) a.peers[q] = q < comm->world ? comm->peers[q] : nullptr;
+  a.state = comm->state;
+  a.data = nullptr;
+  a.stats = nullptr;
+  a.slot_bytes = static_cast<int64_t>(comm->slot_bytes);
+  a.spin_ticks = comm->spin_ticks;
+  a.rank = comm->rank;
+  a.stats_scale = 1.f;
+  a.partials = p;
+  a.out = static_cast<uint16_t*>(out_bf16);
+  return p.is_int32 ? launch_exchange<2>(comm->world, a, stream) : launch_exchange<1>(comm->world, a, stream);
 }
 
 extern "C" int hymeta_p2p_timeouts(hymeta_p2p_comm* comm, uint32_t* count) {

@@ -279,6 +279,7 @@ _SIGNATURES = {
     "hymeta_p2p_connect_pointers": (C.c_int, [_ptr, C.POINTER(_ptr)]),
     "hymeta_p2p_set_wait_limit": (C.c_int, [_ptr, C.c_uint64]),
     "hymeta_p2p_all_reduce": (C.c_int, [_ptr, _ptr, _i64, _ptr, _i64, _f32, _ptr]),
+    "hymeta_p2p_all_reduce_partials": (C.c_int, [_ptr, C.POINTER(GemmPartials), _ptr, _ptr]),
     "hymeta_p2p_timeouts": (C.c_int, [_ptr, C.POINTER(C.c_uint32)]),
     "hymeta_p2p_destroy": (C.c_int, [_ptr]),
     "hymeta_bf16_gemm_deferred": (C.c_int, [C.POINTER(Bf16GemmArgs), C.POINTER(GemmPartials), _ptr]),

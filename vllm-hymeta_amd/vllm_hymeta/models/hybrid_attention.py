@@ -219,5 +219,8 @@ class IntraHybridAttention(torch.nn.Module):
         out_linear = self.linear_attn(hidden_states, hymeta_cache, meta_linear_cache, state_indices_tensor,
                                       attn_metadata, lower_bound, qkv=qkv_linear)
         reduce = parallel._active(self.tp_group)
-        y = self.out_proj(self.combine(out_attn, out_linear), defer=defer_out and not reduce)
+        # the K slices' sum is left to whoever reads the result next: the fused add + norm (no all-reduce), or the
+        # group's one-shot exchange
+        defer = parallel.defers_into_all_reduce(self.tp_group) if reduce else defer_out
+        y = self.out_proj(self.combine(out_attn, out_linear), defer=defer)
         return all_reduce_sum(y, self.tp_group) if reduce else y

@@ -37,9 +37,12 @@ class HymetaMLP(torch.nn.Module):
 
     def forward(self, x: torch.Tensor, defer_out: bool = False):
         """``defer_out``: the result goes straight into a fused add + norm, which may sum ``down_proj``'s K slices itself
-        (see ``HymetaLinear.forward``); ignored when an all-reduce follows."""
+        (see ``HymetaLinear.forward``); when an all-reduce follows, the group's one-shot exchange does."""
         reduce = self.reduce_results and parallel._active(self.tp_group)
-        y = self.down_proj(self.gate_up_proj.forward_silu_mul(x), defer=defer_out and not reduce)
+        # the K slices' sum is left to whoever reads the result next: the fused add + norm (no all-reduce), or the
+        # group's one-shot exchange
+        defer = parallel.defers_into_all_reduce(self.tp_group) if reduce else defer_out
+        y = self.down_proj(self.gate_up_proj.forward_silu_mul(x), defer=defer)
         return all_reduce_sum(y, self.tp_group) if reduce else y
 
 

@@ -183,6 +183,22 @@ class OneShotAllReduce:
                                                     stats.numel() if stats is not None else 0, float(stats_scale), stream),
                     "hymeta_p2p_all_reduce")
 
+    def supports_partials(self, partials) -> bool:
+        M, N = partials.shape
+        return N % 8 == 0 and 0 < M * N * 2 <= self.max_bytes
+
+    def all_reduce_partials(self, partials) -> torch.Tensor:
+        """The sum over the ranks of a K-sliced linear's result that is still in its partial sums
+        (``hip_ops.PartialSums``): the exchange adds the slices as it reads them, so the linear's own reduce launch never
+        runs.  Returns bf16 ``[M, N]``."""
+        partials.check_live()
+        M, N = partials.shape
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=partials.device)
+        stream = torch.cuda.current_stream(partials.device).cuda_stream
+        self._check(self._lib.hymeta_p2p_all_reduce_partials(self._comm, self._C.byref(partials.desc), out.data_ptr(), stream),
+                    "hymeta_p2p_all_reduce_partials")
+        return out
+
     def set_wait_limit(self, seconds: float) -> None:
         self._check(self._lib.hymeta_p2p_set_wait_limit(self._comm, max(1, int(seconds * 1e8))), "hymeta_p2p_set_wait_limit")
 
@@ -293,9 +309,22 @@ def one_shot_self_check(group: dist.ProcessGroup, device: torch.device, rows=(1,
     return good, ("" if good else (why or "another rank failed the check"))
 
 
-def all_reduce_sum(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+def defers_into_all_reduce(group) -> bool:
+    """Whether a row-parallel linear in front of ``all_reduce_sum(…, group)`` may hand over its K slices' partial sums
+    (``defer=True``): the group's one-shot exchange adds them while it reads its message."""
+    return _active(group) and _exchange_of(group) is not None
+
+
+def all_reduce_sum(x, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """Sum over the tensor-parallel group, in place (the reduction behind ``RowParallelLinear``:
-    ``out_proj`` / ``o_proj`` / ``down_proj``).  No-op for a single rank or without a group."""
+    ``out_proj`` / ``o_proj`` / ``down_proj``).  No-op for a single rank or without a group.
+    ``x`` may be the ``hip_ops.PartialSums`` of a K-sliced linear (see ``defers_into_all_reduce``): the exchange takes
+    them as they are; any other path first runs the linear's reduce launch."""
+    if not isinstance(x, torch.Tensor):        # hip_ops.PartialSums
+        comm = _exchange_of(group) if _active(group) else None
+        if comm is not None and comm.supports_partials(x):
+            return comm.all_reduce_partials(x)
+        x = x.tensor()
     if _active(group):
         comm = _exchange_of(group)
         if comm is not None and (comm.supports(x) or isinstance(group, InProcessGroup)):
