@@ -3,7 +3,14 @@ one GPU: every rank's result equals the rank-ordered fp32 sum of the ranks' mess
 message shapes (bf16 rows, fp32 [T, 2] statistics, both in one exchange), over many calls in a row (the two parities of
 the slots, changing sizes and block counts), from HIP graphs, and a wait for a peer that never comes ends at its limit.
 Stands in for the tensor_model_parallel_all_reduce calls of the reference
-(``vllm_hymeta/models/modeling_hymeta.py:158-160,858-861``)."""
+(``vllm_hymeta/models/modeling_hymeta.py:158-160,858-861``).
+
+This file is named to run FIRST among the GPU tests.  Its ranks share one process, each on its own stream, and wait for
+each other inside kernels; a process has 4 hardware queues, a stream gets one at its first use and keeps it, and kernels
+of streams that share a queue run in order.  In a young process consecutive streams get different queues
+(``tools/hwqueue_probe.py`` shows the pairs that serialise); after a few hundred tests have used the stream pool, two
+ranks can land on one queue, and the rank behind never gets to send what the one in front waits for (every wait is
+bounded: such a case fails at its limit, it does not hang)."""
 import pytest
 import torch
 
@@ -177,6 +184,109 @@ def test_exchange_takes_a_k_sliced_linear_straight_from_its_partial_sums(kind):
             assert isinstance(p, hip_ops.PartialSums), "the case is meant to be K-sliced"
             outs.append(c.all_reduce_partials(p))
     torch.cuda.synchronize()
-    assert all(torch.equal(o, ref) for o in outs) and all(c.timeouts() == 0 for c in comms)
+    assert [c.timeouts() for c in comms] == [0] * world
+    for r, o in enumerate(outs):
+        assert torch.equal(o, ref), f"rank {r}: {int((o != ref).sum())} of {o.numel()} values differ from reduce + exchange"
     _close(comms)
+
+
+D = 128
+
+
+def test_two_tensor_parallel_ranks_on_one_gpu_equal_the_unsharded_model():
+    """Configs with tensor parallelism, collectives included, on one GPU: two ranks of HymetaForCausalLM live in one
+    process, each in its own thread on its own stream, with the layers' all-reduces (branch variances, out_proj, dense
+    MLP, expert mixture + shared expert) running through the one-shot exchange between them.  Both ranks cut their
+    shards from the same checkpoint, prefill two prompts and decode one token.  The ranks' hidden states are bit-identical
+    (the exchange adds in rank order on every rank) and equal the unsharded model's and the CPU restatement's within
+    the model tolerance; the vocabulary-parallel greedy pick over the ranks' logits equals the unsharded argmax."""
+    import threading
+
+    from test_gpu_layers import _md
+    from test_gpu_model_70b import _checkpoint
+    from _util import assert_bf16_close
+
+    from oracle.model import hymeta_model_ref
+    from vllm_hymeta.models.configuration_hymeta import HymetaConfig
+    from vllm_hymeta.models.modeling_hymeta import HymetaForCausalLM
+    from vllm_hymeta.parallel import InProcessGroup
+
+    dev = torch.device("cuda")
+    g_ = gen(31)
+    cfg = HymetaConfig(vocab_size=512, hidden_size=512, num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=2,
+                       intermediate_size=512, shared_intermediate_size=256, num_local_experts=4, num_meta_tokens=32,
+                       sliding_window=48, max_position_embeddings=1024)
+    ckpt = _checkpoint(g_, cfg)
+    lens = [75, 40]
+    ids = [torch.randint(0, cfg.vocab_size, (L + 1,), generator=g_) for L in lens]
+    refs = [hymeta_model_ref(x, ckpt, cfg) for x in ids]
+    bs = 16
+    per_seq = (max(lens) + 1 + bs - 1) // bs
+    bt_cpu = torch.randperm(2 * per_seq + 1, generator=g_)[: 2 * per_seq].to(torch.int32).view(2, per_seq)
+    slot = lambda s, t: int(bt_cpu[s, t // bs]) * bs + t % bs
+    pre_slots = [slot(s, t) for s, L in enumerate(lens) for t in range(L)]
+    dec_slots = [slot(s, L) for s, L in enumerate(lens)]
+
+    def run_rank(group, out):
+        """One rank: build, load, prefill, decode.  ``group`` None = the unsharded model."""
+        kvh = cfg.num_key_value_heads // (group.size if group is not None else 1)
+        model = HymetaForCausalLM(cfg, max_num_seqs=4, tp_group=group, device=dev)
+        model.load_weights(ckpt.items())
+        kv_caches = [torch.zeros(2, 2 * per_seq + 1, bs, kvh, D, dtype=torch.bfloat16, device=dev)
+                     for _ in range(cfg.num_hidden_layers)]
+        run = dict(request_ids_to_seq_ids={"a": [0], "b": [1]}, finished_requests_ids=[])
+        bt = bt_cpu.to(dev)
+        md = _md(dev, prefill_lens=lens, context_lens=[0, 0], slot_mapping=torch.tensor(pre_slots, device=dev))
+        pre_ids = torch.cat([x[:L] for x, L in zip(ids, lens)]).to(dev)
+        pre_pos = torch.cat([torch.arange(L) for L in lens]).to(dev)
+        h_pre = model(pre_ids, pre_pos, attn_metadata=md, kv_caches=kv_caches, **run)
+        md = _md(dev, decode_seq_lens=[L + 1 for L in lens], block_tables=bt, slot_mapping=torch.tensor(dec_slots, device=dev))
+        dec_ids = torch.stack([x[L] for x, L in zip(ids, lens)]).to(dev)
+        h_dec = model(dec_ids, torch.tensor(lens, device=dev), attn_metadata=md, kv_caches=kv_caches, **run)
+        # the rank's share of the vocabulary (the unsharded model: all of it)
+        rank, size = (group.rank, group.size) if group is not None else (0, 1)
+        rows = cfg.vocab_size // size
+        logits = torch.nn.functional.linear(h_dec.float(), model.lm_head[rank * rows:(rank + 1) * rows].float())
+        torch.cuda.current_stream().synchronize()
+        out.update(h_pre=h_pre.cpu(), h_dec=h_dec.cpu(), logits=logits.cpu())
+
+    full = {}
+    run_rank(None, full)
+    torch.cuda.synchronize()
+
+    groups = InProcessGroup.make(2, dev, max_bytes=4 * 1024 * 1024, wait_seconds=30.0)
+    outs, errors = [{}, {}], []
+
+    def thread_main(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                run_rank(groups[r], outs[r])
+        except Exception as exc:       # surfaces below: a rank that dies leaves the other to its wait limit
+            errors.append((r, exc))
+
+    threads = [threading.Thread(target=thread_main, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=100)
+    torch.cuda.synchronize()
+    assert not errors, errors
+    assert all(g.comm.timeouts() == 0 for g in groups)
+    for g in groups:
+        g.comm.close()
+
+    for key in ("h_pre", "h_dec"):
+        assert torch.equal(outs[0][key], outs[1][key]), f"{key}: the two ranks differ"
+    ref_pre = torch.cat([r[0][:L] for r, L in zip(refs, lens)])
+    ref_dec = torch.stack([r[0][L] for r, L in zip(refs, lens)])
+    assert_bf16_close(outs[0]["h_pre"], ref_pre, "TP=2 model, prefill hidden states", rel=2e-2, frac=2.0 ** -4)
+    assert_bf16_close(outs[0]["h_dec"], ref_dec, "TP=2 model, decode hidden states", rel=2e-2, frac=2.0 ** -4)
+    assert_bf16_close(outs[0]["h_dec"], full["h_dec"].float(), "TP=2 against the unsharded model", rel=2e-2, frac=2.0 ** -4)
+    # vocabulary-parallel greedy pick: best (value, index) pair over the ranks
+    both = torch.cat([outs[0]["logits"], outs[1]["logits"]], dim=1)
+    assert_bf16_close(both, full["logits"], "TP=2 logits against the unsharded model", rel=2e-2, frac=2.0 ** -4)
+    ref_logits = torch.stack([r[1][L] for r, L in zip(refs, lens)])
+    top2 = ref_logits.float().topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.05 * top2[:, 0].abs()      # rows whose winner is not a near tie
+    assert torch.equal(both.argmax(-1)[clear], ref_logits.argmax(-1)[clear])
 

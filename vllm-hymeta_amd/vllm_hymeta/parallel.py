@@ -231,6 +231,12 @@ class InProcessGroup:
 
     @classmethod
     def make(cls, size: int, device: torch.device, max_bytes: int = ONE_SHOT_MAX_BYTES, wait_seconds: float = 2.0) -> list:
+        """``size`` <= 4 ranks.  A process has few hardware queues (4), a stream gets one when it is first used and keeps
+        it, and kernels of streams that share a queue run in order -- fatal for ranks that wait for each other inside a
+        kernel.  Give every rank a stream that shares its queue with no other rank's: streams first used one after the
+        other in a young process do (``tools/hwqueue_probe.py`` prints which pairs of streams serialise)."""
+        if size > 4:
+            raise ValueError("ranks that share a process need a hardware queue each: 4 at most")
         comms = OneShotAllReduce.in_process(size, device, max_bytes)
         for c in comms:
             c.set_wait_limit(wait_seconds)
