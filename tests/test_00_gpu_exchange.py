@@ -5,12 +5,12 @@ the slots, changing sizes and block counts), from HIP graphs, and a wait for a p
 Stands in for the tensor_model_parallel_all_reduce calls of the reference
 (``vllm_hymeta/models/modeling_hymeta.py:158-160,858-861``).
 
-This file is named to run FIRST among the GPU tests.  Its ranks share one process, each on its own stream, and wait for
-each other inside kernels; a process has 4 hardware queues, a stream gets one at its first use and keeps it, and kernels
-of streams that share a queue run in order.  In a young process consecutive streams get different queues
-(``tools/hwqueue_probe.py`` shows the pairs that serialise); after a few hundred tests have used the stream pool, two
-ranks can land on one queue, and the rank behind never gets to send what the one in front waits for (every wait is
-bounded: such a case fails at its limit, it does not hang)."""
+The ranks share one process, each on its own stream, and wait for each other inside kernels.  A process has 4 hardware
+queues, a stream gets one at its first use and keeps it, and kernels of streams that share a queue run in order: a rank
+behind another rank's waiting exchange kernel never gets to send what that kernel waits for.  The tests therefore run on
+streams that were measured to run side by side (``parallel.concurrent_streams``; ``tools/hwqueue_probe.py`` prints the
+pairs that serialise), and every wait is bounded: a surprise fails at its limit, it does not hang.  The file is named to
+run first among the GPU tests, while few streams have a queue yet."""
 import pytest
 import torch
 
@@ -21,13 +21,14 @@ HIDDEN = 3584
 
 
 def _ranks(world, max_bytes=2 * 1024 * 1024, wait_s=1.0):
-    from vllm_hymeta.parallel import OneShotAllReduce
+    from vllm_hymeta.parallel import OneShotAllReduce, concurrent_streams
 
     dev = torch.device("cuda")
+    streams = concurrent_streams(world, dev)      # measured not to share a hardware queue (see the module docstring)
     comms = OneShotAllReduce.in_process(world, dev, max_bytes)
     for c in comms:
         c.set_wait_limit(wait_s)      # a scheduling surprise fails the test within a second instead of waiting
-    return comms, [torch.cuda.Stream() for _ in range(world)], dev
+    return comms, streams, dev
 
 
 def _close(comms):
@@ -259,7 +260,7 @@ def test_two_tensor_parallel_ranks_on_one_gpu_equal_the_unsharded_model():
 
     def thread_main(r):
         try:
-            with torch.cuda.stream(torch.cuda.Stream()):
+            with torch.cuda.stream(groups[r].stream):
                 run_rank(groups[r], outs[r])
         except Exception as exc:       # surfaces below: a rank that dies leaves the other to its wait limit
             errors.append((r, exc))

@@ -27,7 +27,9 @@
 #include "partial_sums.h"
 
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <vector>
 
 namespace hymeta {
 namespace {
@@ -183,6 +185,38 @@ struct hymeta_p2p_comm {
   uint64_t spin_ticks = hymeta::kDefaultSpinTicks;
 };
 
+namespace hymeta {
+namespace {
+// Exchange buffers are never handed back to the driver while the process lives: a communicator that goes away parks
+// its buffer here and a later one of the same size on the same device takes it over.  (Address ranges that were mapped
+// uncached and then freed were seen to come back inside ordinary allocations of the process with chunks of later
+// kernels' output missing; a process makes a handful of communicators, so nothing is lost by keeping them.)
+struct ParkedBuffer {
+  void* ptr;
+  size_t bytes;
+  int device;
+};
+std::mutex g_parked_mutex;
+std::vector<ParkedBuffer> g_parked;
+
+void* take_parked(size_t bytes, int device) {
+  std::lock_guard<std::mutex> lock(g_parked_mutex);
+  for (size_t i = 0; i < g_parked.size(); ++i)
+    if (g_parked[i].bytes == bytes && g_parked[i].device == device) {
+      void* p = g_parked[i].ptr;
+      g_parked.erase(g_parked.begin() + static_cast<std::ptrdiff_t>(i));
+      return p;
+    }
+  return nullptr;
+}
+
+void park(void* ptr, size_t bytes, int device) {
+  std::lock_guard<std::mutex> lock(g_parked_mutex);
+  g_parked.push_back({ptr, bytes, device});
+}
+}  // namespace
+}  // namespace hymeta
+
 extern "C" int hymeta_p2p_create(int rank, int world, size_t max_message_bytes, hymeta_p2p_comm** comm, void* ipc_handle) {
   using namespace hymeta;
   if (comm == nullptr || world < 1 || world > kMaxWorld || rank < 0 || rank >= world || max_message_bytes == 0)
@@ -197,8 +231,13 @@ extern "C" int hymeta_p2p_create(int rank, int world, size_t max_message_bytes, 
   c->slot_bytes = (max_message_bytes + 255) / 256 * 256;
   c->buffer_bytes = kFlagBytes + 2 * static_cast<size_t>(world) * c->slot_bytes;
   void* buf = nullptr;
-  if (hipGetDevice(&c->device) != hipSuccess ||
-      hipExtMallocWithFlags(&buf, c->buffer_bytes, hipDeviceMallocUncached) != hipSuccess) {
+  if (hipGetDevice(&c->device) != hipSuccess) {
+    delete c;
+    return HYMETA_ERR_WORKSPACE;
+  }
+  buf = take_parked(c->buffer_bytes, c->device);
+  if (buf == nullptr && hipExtMallocWithFlags(&buf, c->buffer_bytes, hipDeviceMallocUncached) != hipSuccess) {
+    (void)hipGetLastError();
     delete c;
     return HYMETA_ERR_WORKSPACE;
   }
@@ -206,7 +245,7 @@ extern "C" int hymeta_p2p_create(int rank, int world, size_t max_message_bytes, 
   if (hipMalloc(reinterpret_cast<void**>(&c->state), 4 * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(c->state, 0, 4 * sizeof(uint32_t)) != hipSuccess || hipMemset(buf, 0, kFlagBytes) != hipSuccess ||
       hipDeviceSynchronize() != hipSuccess) {
-    (void)hipFree(buf);
+    park(buf, c->buffer_bytes, c->device);
     if (c->state) (void)hipFree(c->state);
     delete c;
     return HYMETA_ERR_WORKSPACE;
@@ -215,7 +254,7 @@ extern "C" int hymeta_p2p_create(int rank, int world, size_t max_message_bytes, 
     hipIpcMemHandle_t h;
     if (hipIpcGetMemHandle(&h, buf) != hipSuccess) {
       (void)hipGetLastError();
-      (void)hipFree(buf);
+      park(buf, c->buffer_bytes, c->device);
       (void)hipFree(c->state);
       delete c;
       return HYMETA_ERR_UNSUPPORTED;
@@ -381,7 +420,7 @@ extern "C" int hymeta_p2p_destroy(hymeta_p2p_comm* comm) {
   (void)hipDeviceSynchronize();
   for (int q = 0; q < comm->world; ++q)
     if (comm->opened[q]) (void)hipIpcCloseMemHandle(comm->peers[q]);
-  if (comm->peers[comm->rank]) (void)hipFree(comm->peers[comm->rank]);
+  if (comm->peers[comm->rank]) hymeta::park(comm->peers[comm->rank], comm->buffer_bytes, comm->device);
   if (comm->state) (void)hipFree(comm->state);
   delete comm;
   return HYMETA_OK;

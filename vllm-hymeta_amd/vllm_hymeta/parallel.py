@@ -219,6 +219,48 @@ class OneShotAllReduce:
             self._comm = None
 
 
+_CONCURRENT: dict = {}
+
+
+def _streams_serialise(a: "torch.cuda.Stream", b: "torch.cuda.Stream", device: torch.device) -> bool:
+    """Whether a kernel on ``b`` has to wait for the kernel launched before it on ``a`` (the two share a hardware queue):
+    a two-rank exchange with a 20 ms limit, rank 0 on ``a``, rank 1 on ``b``; every kernel ends at its limit."""
+    comms = OneShotAllReduce.in_process(2, device, 1 << 12)
+    try:
+        for c in comms:
+            c.set_wait_limit(0.02)
+        xs = [torch.zeros(64, dtype=torch.bfloat16, device=device) for _ in range(2)]
+        torch.cuda.synchronize(device)
+        for c, st, x in zip(comms, (a, b), xs):
+            with torch.cuda.stream(st):
+                c.all_reduce(data=x)
+        torch.cuda.synchronize(device)
+        return comms[0].timeouts() > 0
+    finally:
+        for c in comms:
+            c.close()
+
+
+def concurrent_streams(count: int, device: torch.device, candidates: int = 16) -> list:
+    """``count`` streams of this process whose kernels run side by side.  A process has few hardware queues (4), a
+    stream gets one when it is first used and keeps it, and kernels of streams that share a queue run in order -- fatal
+    for ranks that wait for each other inside a kernel.  Which streams share is not documented, so this measures it:
+    candidates from torch's pool are tried pairwise (``_streams_serialise``) until ``count`` of them are mutually
+    independent.  The answer holds for the life of the process and is remembered."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    chosen = _CONCURRENT.setdefault(key, [])
+    tried = 0
+    while len(chosen) < count and tried < candidates:
+        st = torch.cuda.Stream(device)
+        tried += 1
+        if all(st.cuda_stream != c.cuda_stream and not _streams_serialise(c, st, device) for c in chosen):
+            chosen.append(st)
+    if len(chosen) < count:
+        raise RuntimeError(f"found {len(chosen)} streams that run side by side, {count} wanted (hardware queues of a process: 4)")
+    return chosen[:count]
+
+
 class InProcessGroup:
     """A tensor-parallel group whose ranks all live in ONE process, each driving its own stream (and, to keep a host
     wait of one rank from stalling the others, its own thread) of one GPU: (rank, size) plus the rank's end of a
@@ -226,21 +268,20 @@ class InProcessGroup:
     (there is no backend behind it, so a message it does not support raises).  For tests and rehearsals of the
     sharded model on one GPU."""
 
-    def __init__(self, rank: int, size: int, comm: OneShotAllReduce):
-        self.rank, self.size, self.comm = rank, size, comm
+    def __init__(self, rank: int, size: int, comm: OneShotAllReduce, stream: "torch.cuda.Stream"):
+        self.rank, self.size, self.comm, self.stream = rank, size, comm, stream
 
     @classmethod
     def make(cls, size: int, device: torch.device, max_bytes: int = ONE_SHOT_MAX_BYTES, wait_seconds: float = 2.0) -> list:
-        """``size`` <= 4 ranks.  A process has few hardware queues (4), a stream gets one when it is first used and keeps
-        it, and kernels of streams that share a queue run in order -- fatal for ranks that wait for each other inside a
-        kernel.  Give every rank a stream that shares its queue with no other rank's: streams first used one after the
-        other in a young process do (``tools/hwqueue_probe.py`` prints which pairs of streams serialise)."""
+        """``size`` <= 4 ranks (the hardware queues of a process).  Run rank ``r`` on ``groups[r].stream``: streams that
+        were measured not to share a hardware queue (``concurrent_streams``)."""
         if size > 4:
             raise ValueError("ranks that share a process need a hardware queue each: 4 at most")
+        streams = concurrent_streams(size, device)
         comms = OneShotAllReduce.in_process(size, device, max_bytes)
         for c in comms:
             c.set_wait_limit(wait_seconds)
-        return [cls(r, size, c) for r, c in enumerate(comms)]
+        return [cls(r, size, c, st) for r, (c, st) in enumerate(zip(comms, streams))]
 
 
 _ONE_SHOT: dict = {}
