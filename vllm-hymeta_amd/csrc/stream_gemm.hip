@@ -382,8 +382,11 @@ bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan
     if (groups % nf_forced != 0) return false;
     tiles = groups / nf_forced, nf = nf_forced;
   } else if (groups >= want) {
-    // wide matrix: `want` tiles (more when a wave would pass 4 fragments), the fragments dealt out in equal shares
-    tiles = want > (frags + 15) / 16 ? want : (frags + 15) / 16;
+    // wide matrix: `want` tiles, the fragments dealt out in equal shares; when a wave would pass 4 fragments, the next
+    // multiple of `want`: one workgroup runs per compute unit, so the tiles go by in rounds, and a last round that
+    // fills a third of the chip (the 152064-row lm_head as 594 tiles of 16 fragments) costs as much as a full one
+    const int min_tiles = (frags + 15) / 16;
+    tiles = want >= min_tiles ? want : (min_tiles + want - 1) / want * want;
     nf = ((frags + tiles - 1) / tiles + 3) / 4;
   } else {
     // narrow matrix: K slices make up the count.  Tiles of 128 columns for the large ones (x is re-read once per
