@@ -145,6 +145,16 @@ def test_limits_and_unsupported_messages():
     lib = _C.load()
     assert lib.hymeta_p2p_all_reduce(c._comm, big.data_ptr(), big.numel(), None, 0, 1.0, None) == _C.ERR_SCRATCH_LIMIT
     assert lib.hymeta_p2p_all_reduce(c._comm, big.data_ptr(), 12, None, 0, 1.0, None) == -2
+    # group sizes other than 1, 2, 4, 8 and a rank outside its group are refused; so is an exchange before the
+    # peers are connected
+    import ctypes as C
+    comm = C.c_void_p()
+    assert lib.hymeta_p2p_create(0, 3, 4096, C.byref(comm), None) == -2
+    assert lib.hymeta_p2p_create(2, 2, 4096, C.byref(comm), None) == -1
+    assert lib.hymeta_p2p_create(0, 2, 4096, C.byref(comm), None) == 0
+    assert lib.hymeta_p2p_all_reduce(comm, big.data_ptr(), 64, None, 0, 1.0, None) == -1
+    assert lib.hymeta_p2p_verify(comm) == -1
+    assert lib.hymeta_p2p_destroy(comm) == 0
     x = torch.ones(2048, dtype=torch.bfloat16, device=dev)
     c.all_reduce(data=x)                 # a world of one: the sum is the message
     torch.cuda.synchronize()
