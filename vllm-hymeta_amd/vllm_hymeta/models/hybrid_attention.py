@@ -123,7 +123,7 @@ class MetaFlashAttention(torch.nn.Module):
             raise ValueError("attention layer and head shard disagree on the head geometry")
         self.attn = attn
 
-    def _qkv(self, hidden_states, positions, offset, qkv=None):
+    def _qkv(self, hidden_states, positions, offset, qkv=None, roped=False):
         H, Hkv, D = self.shard.num_heads, self.shard.num_kv_heads, self.head_dim
         T = hidden_states.shape[0]
         if qkv is None:
@@ -131,7 +131,8 @@ class MetaFlashAttention(torch.nn.Module):
         q = qkv[:, : H * D].view(T, H, D)
         k = qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
         v = qkv[:, (H + Hkv) * D:].view(T, Hkv, D)
-        hip_ops.rope_neox_(positions, q, k, self.cos_sin_cache, position_offset=offset)
+        if not roped:
+            hip_ops.rope_neox_(positions, q, k, self.cos_sin_cache, position_offset=offset)
         return q, k, v
 
     def prepare_meta_state(self, meta_hidden: torch.Tensor, meta_fattn_cache: torch.Tensor) -> torch.Tensor:
@@ -148,7 +149,8 @@ class MetaFlashAttention(torch.nn.Module):
         return out.view(M, -1)
 
     def forward(self, hidden_states: torch.Tensor, positions: torch.Tensor, kv_cache: Optional[torch.Tensor],
-                meta_fattn_cache: torch.Tensor, attn_metadata=None, qkv: Optional[torch.Tensor] = None) -> torch.Tensor:
+                meta_fattn_cache: torch.Tensor, attn_metadata=None, qkv: Optional[torch.Tensor] = None,
+                qkv_roped: bool = False) -> torch.Tensor:
         """positions are the sequence positions of the real tokens; the meta tokens occupy 0..M-1, so
         real token p is roped at p + M (reference ``modeling_hymeta.py:1314-1323``).
 
@@ -156,8 +158,8 @@ class MetaFlashAttention(torch.nn.Module):
         (reference ``:795``), which reads the paged cache bound to that layer and the step's metadata from
         the forward context.  ``kv_cache`` / ``attn_metadata`` given explicitly (callers without an engine)
         are bound / set for the call.  ``qkv``: this branch's projection of ``hidden_states`` when the caller has
-        computed it already (roped in place here)."""
-        q, k, v = self._qkv(hidden_states, positions, self.num_meta_tokens, qkv)
+        computed it already (roped in place here, unless ``qkv_roped`` says its q and k heads are rotated already)."""
+        q, k, v = self._qkv(hidden_states, positions, self.num_meta_tokens, qkv, qkv_roped)
         T, H, D = q.shape
         if kv_cache is not None:
             bind_kv_cache(self.attn, kv_cache)
@@ -211,11 +213,20 @@ class IntraHybridAttention(torch.nn.Module):
         if attn_metadata is None:
             attn_metadata = current_attn_metadata()
         qkv_attn = qkv_linear = None
+        roped = False
         if self.merged_qkv is not None:
-            both = self.merged_qkv(hidden_states)
+            both = self.merged_qkv(hidden_states, defer=True)
+            if isinstance(both, hip_ops.PartialSums):
+                # a K-sliced projection: the launch that adds its slices also rotates the softmax branch's q and k heads
+                # (the first columns; everything behind them is written as it is)
+                va = self.vanilla_attn
+                both = hip_ops.rope_from_partials(both, positions, va.cos_sin_cache, va.shard.num_heads, va.shard.num_kv_heads,
+                                                  position_offset=va.num_meta_tokens)
+                roped = True
             half = both.shape[1] // 2
             qkv_attn, qkv_linear = both[:, :half], both[:, half:]
-        out_attn = self.vanilla_attn(hidden_states, positions, kv_cache, meta_fattn_cache, attn_metadata, qkv=qkv_attn)
+        out_attn = self.vanilla_attn(hidden_states, positions, kv_cache, meta_fattn_cache, attn_metadata, qkv=qkv_attn,
+                                     qkv_roped=roped)
         out_linear = self.linear_attn(hidden_states, hymeta_cache, meta_linear_cache, state_indices_tensor,
                                       attn_metadata, lower_bound, qkv=qkv_linear)
         reduce = parallel._active(self.tp_group)
