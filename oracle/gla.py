@@ -1,7 +1,9 @@
 """Gated-linear-attention (GLA) recurrence: CPU restatement (test infrastructure).
 
-Parity unpinned: the reference holds no vectors for these functions; the math
-is restated from
+The single-token step (``gla_decode_step_ref``) is pinned to outputs of the reference's own
+Triton kernel run under the CPU interpreter (``tests/golden/ref_gla_decode.npz``, script
+``tests/golden/make_ref_fixtures.py``).  The prefill functions are parity unpinned: their kernel
+is third party and the reference holds no vectors for it.  The math is restated from
 
 * the single-token Triton step, ``vllm_hymeta/models/my_fused_recurrent.py:58-80``
   (7B variant with explicit casts: ``vllm_hymeta/model_for_7B/my_fused_recurrent.py:60-80``);
@@ -22,6 +24,7 @@ from __future__ import annotations
 
 from typing import Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 
@@ -78,13 +81,26 @@ def gla_decode_step_ref(
     """One decode token per sequence, state updated IN PLACE at ``state[slot_idx[b]]``.
 
     Follows the arithmetic types of ``my_fused_recurrent_fwd_kernel``
-    (``my_fused_recurrent.py:58-80``): the outer product ``k v^T`` is formed
-    in the activation dtype (bf16) before it is added in fp32 (``:65,72``);
-    the decay ``exp(g)`` and the state update are fp32 (``:69-72``); the output
-    contracts ``(q*scale)`` (fp32) with the *updated fp32* state (``:75-76``);
-    state and output are rounded to their storage dtype on store (``:79-80``).
-    ``slot_idx[b] == -1`` skips the sequence: state untouched, output row left
-    as it was (here: zeros) (``:33-35``).
+    (``my_fused_recurrent.py:58-80``) operation by operation; pinned bit for bit (fp16 and fp32
+    activations, both variants of the kernel) by ``tests/golden/ref_gla_decode.npz``, which holds
+    outputs of that kernel run under Triton's CPU interpreter:
+
+    * ``q * scale`` (``:59``) is a tensor-times-scalar product: Triton casts the fp32 scalar to the
+      tensor's dtype and multiplies in that dtype, so the product AND the scale itself are rounded to
+      the activation dtype (bf16: ``128 ** -0.5`` becomes 0.08837890625) before ``.to(float32)`` at
+      ``:75``;
+    * the outer product ``k v^T`` is formed in the activation dtype (``:65``) and added in fp32
+      (``:72``);
+    * the decay ``exp(g)`` (g widened to fp32; the 7B variant hands g over in the activation dtype,
+      ``model_for_7B/my_fused_recurrent.py:63``) and the state update are fp32 (``:69-72``);
+    * the output contracts the rounded ``q * scale`` with the *updated, unrounded fp32* state
+      (``:75-76``), summed here in key-channel order, the order of the interpreter's ``tl.sum``
+      (on a GPU the order is the compiler's tree);
+    * state and output are rounded to their storage dtypes on store (``:79-80``).
+
+    ``exp`` is numpy's float32 routine, the one the interpreter run used (a GPU's differs from it in
+    the last bit now and then, like any two ``expf``).  ``slot_idx[b] == -1`` skips the sequence:
+    state untouched, output row left as it was (here: zeros) (``:33-35``).
 
     q ``[B,H,D]``; k, v, g ``[B,Hkv,D]``; state ``[slots,H,D,D]`` (any float
     dtype; bf16 in the reference, ``modeling_hymeta.py:1166``).  Returns
@@ -94,21 +110,23 @@ def gla_decode_step_ref(
     if scale is None:
         scale = D ** -0.5
     act = q.dtype
-    kx = _expand_kv(k, H)
-    vx = _expand_kv(v, H)
+    kx = _expand_kv(k, H).to(act)
+    vx = _expand_kv(v, H).to(act)
     gx = _expand_kv(g, H).float()
     out = torch.zeros(B, H, D, dtype=act)
-    scale32 = torch.tensor(scale, dtype=torch.float32)
+    scale_act = torch.tensor(scale, dtype=torch.float32).to(act)
     for b in range(B):
         slot = int(slot_idx[b])
         if slot == -1:
             continue
-        kv_outer = (kx[b].to(act)[:, :, None] * vx[b].to(act)[:, None, :]).float()
-        ratio = torch.exp(gx[b])[:, :, None]
-        s_old = state[slot].float()
-        s_new = kv_outer + ratio * s_old
-        qs = q[b].float() * scale32
-        o = (qs[:, :, None] * s_new).sum(dim=1)
+        kv_outer = (kx[b][:, :, None] * vx[b][:, None, :]).float()
+        ratio = torch.from_numpy(np.exp(gx[b].numpy()))[:, :, None]
+        s_new = kv_outer + ratio * state[slot].float()
+        qs = (q[b] * scale_act).float()
+        prod = qs[:, :, None] * s_new
+        o = torch.zeros(H, D, dtype=torch.float32)
+        for d in range(D):
+            o = o + prod[:, d, :]
         state[slot] = s_new.to(state.dtype)
         out[b] = o.to(act)
     return out

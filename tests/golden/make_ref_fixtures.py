@@ -8,12 +8,20 @@ and outputs, no source).  What loads by file path without the GPU-only third-par
                                 forward needs flash_attn and is not called)  -> ref_rope.npz
 * hf_7B_model/cache.py, hf_model/cache.py   Cache.update (rolling window, recurrent / meta state slots)
                                                                            -> ref_cache.npz
+* vllm_hymeta/models/my_fused_recurrent.py and vllm_hymeta/model_for_7B/my_fused_recurrent.py: the reference's one
+  kernel, the single-token GLA step, run under Triton's CPU interpreter (TRITON_INTERPRET=1, set by this script
+  before triton is imported; numpy arithmetic, so fp16 and fp32 tensors: the interpreter has no bf16).  Both files
+  import two decorators from ``fla.utils`` (``contiguous``: make tensor arguments contiguous; ``autocast_custom_fwd``:
+  autocast bookkeeping); fla is not installed, and the script registers a module of that name holding those two
+  decorators (no arithmetic in either) before loading the files           -> ref_gla_decode.npz
 
 bf16 tensors are stored as their uint16 bit patterns (key suffix ``_bf16``)."""
 import importlib.util
 import os
 import sys
 import types
+
+os.environ.setdefault("TRITON_INTERPRET", "1")   # before triton is imported anywhere
 
 import numpy as np
 import torch
@@ -133,7 +141,71 @@ def cache():
     return len(out)
 
 
+def _fla_utils_decorators():
+    """``fla.utils.contiguous`` / ``autocast_custom_fwd`` as far as the kernel launchers use them."""
+    if "fla.utils" in sys.modules:
+        return
+    import functools
+
+    def contiguous(fn):
+        @functools.wraps(fn)
+        def wrapper(ctx, *args, **kwargs):
+            return fn(ctx, *(a.contiguous() if isinstance(a, torch.Tensor) else a for a in args),
+                      **{k: (v.contiguous() if isinstance(v, torch.Tensor) else v) for k, v in kwargs.items()})
+        return wrapper
+
+    fla, utils = types.ModuleType("fla"), types.ModuleType("fla.utils")
+    utils.contiguous, utils.autocast_custom_fwd = contiguous, (lambda fn: fn)
+    fla.utils = utils
+    sys.modules["fla"], sys.modules["fla.utils"] = fla, utils
+
+
+def _load_file(path: str, name: str):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gla_decode():
+    """Two successive steps of ``my_fused_recurrent`` (70B file) and of its 7B twin on the same inputs: B = 4 with one
+    padded sequence (slot -1), H = 2, D = 128, a state of 3 slots that is not zero; fp16 and fp32."""
+    assert os.environ.get("TRITON_INTERPRET") == "1"
+    _fla_utils_decorators()
+    k70 = _load_file(os.path.join(REF, "vllm_hymeta/models/my_fused_recurrent.py"), "ref_my_fused_recurrent_70b")
+    k7 = _load_file(os.path.join(REF, "vllm_hymeta/model_for_7B/my_fused_recurrent.py"), "ref_my_fused_recurrent_7b")
+    gen = torch.Generator().manual_seed(103)
+    B, H, D, slots, steps = 4, 2, 128, 3, 2
+    slot = torch.tensor([2, -1, 0, 1], dtype=torch.int32)
+    live = slot != -1
+    out = {"slot_idx": slot.numpy(), "scale": np.float64(D ** -0.5), "steps": np.int64(steps)}
+    for tag, dt in (("f16", torch.float16), ("f32", torch.float32)):
+        state = (torch.randn(slots, H, D, D, generator=gen) * 0.5).to(dt)
+        put(out, f"{tag}_state_in", state)
+        st70, st7 = state.clone(), state.clone()
+        for s in range(steps):
+            q = torch.randn(B, H, 1, D, generator=gen).to(dt)
+            k = torch.randn(B, H, 1, D, generator=gen).to(dt)
+            v = torch.randn(B, H, 1, D, generator=gen).to(dt)
+            # log-decays of both gates' ranges: logsigmoid / 16 (7B) up to log(0.05) (70B clamp)
+            g = torch.nn.functional.logsigmoid(torch.randn(B, H, 1, D, generator=gen) * 2) * (0.2 if s == 0 else 1.5)
+            g = g.to(dt).float()          # representable in the activation dtype: both variants see the same values
+            o70 = k70.my_fused_recurrent(q, k, v, g, st70, slot, D ** -0.5)            # fp32 g, [B, H * D]
+            o7 = k7.my_fused_recurrent_gla(q, k, v, g.to(dt), st7, slot)                # g in dt, [B, H, D]
+            assert o70.shape == (B, H * D) and o7.shape == (B, H, D)
+            assert torch.equal(o70.view(B, H, D)[live], o7[live]) and torch.equal(st70, st7), "the two variants differ"
+            for name, t in (("q", q[:, :, 0]), ("k", k[:, :, 0]), ("v", v[:, :, 0]), ("g", g[:, :, 0])):
+                put(out, f"{tag}_{name}{s}", t)
+            o = o7.clone()
+            o[~live] = 0            # rows of padded sequences are never written by the kernel (torch.empty)
+            put(out, f"{tag}_out{s}", o)
+        put(out, f"{tag}_state_out", st70)
+    np.savez_compressed(os.path.join(HERE, "ref_gla_decode.npz"), variants_agree=np.bool_(True), **out)
+    return {k: getattr(v, "shape", ()) for k, v in out.items()}
+
+
 if __name__ == "__main__":
     print("rmsnorm", rmsnorm())
     print("rope", rope())
     print("cache", cache())
+    print("gla_decode", gla_decode())

@@ -1,6 +1,7 @@
 """The oracle against outputs of the reference's OWN code (tests/golden/ref_*.npz, made by
 tests/golden/make_ref_fixtures.py in the build container from the reference files that import without the
-GPU-only wheels): RMSNorm, RoPE, repeat_kv and the eager rolling-window cache."""
+GPU-only wheels): RMSNorm, RoPE, repeat_kv, the eager rolling-window cache, and the single-token GLA kernel
+(the reference's Triton source run under Triton's CPU interpreter)."""
 import os
 
 import numpy as np
@@ -101,3 +102,43 @@ def test_rolling_window_is_the_paged_window():
     for step, h in enumerate(held):
         L = W + step
         assert h == list(range(L - W, L))
+
+
+@pytest.mark.parametrize("tag,dtype", [("f16", torch.float16), ("f32", torch.float32)])
+def test_gla_decode_step_ref_equals_reference_triton_kernel(tag, dtype):
+    """vllm_hymeta/models/my_fused_recurrent.py:8-119 and model_for_7B/my_fused_recurrent.py:9-119 (the two files gave
+    identical bits on these inputs): two successive steps, one padded sequence, outputs and state bit for bit."""
+    from oracle import gla_decode_step_ref
+
+    f = load("ref_gla_decode.npz")
+    assert bool(f["variants_agree"])
+    slot = f["slot_idx"]
+    state = f[f"{tag}_state_in"].clone()
+    assert state.dtype == dtype
+    for s in range(int(f["steps"])):
+        o = gla_decode_step_ref(f[f"{tag}_q{s}"], f[f"{tag}_k{s}"], f[f"{tag}_v{s}"], f[f"{tag}_g{s}"], state, slot,
+                                scale=float(f["scale"]))
+        assert o.dtype == dtype and torch.equal(o, f[f"{tag}_out{s}"]), (tag, s)
+    assert torch.equal(state, f[f"{tag}_state_out"])
+
+
+def test_gla_decode_scale_is_rounded_to_the_activation_dtype():
+    """my_fused_recurrent.py:59: `load(q) * scale` is tensor x scalar, computed in the tensor's dtype.  With bf16
+    activations the scale 128 ** -0.5 therefore enters as 0.08837890625 and the product is rounded to bf16."""
+    from oracle import gla_decode_step_ref
+
+    D = 128
+    q = torch.zeros(1, 1, D, dtype=torch.bfloat16)
+    q[0, 0, 0] = 1.0
+    q[0, 0, 1] = 1.0078125                     # 1 + 2^-7: the product with the rounded scale needs a rounding
+    k = torch.zeros(1, 1, D, dtype=torch.bfloat16)
+    v = torch.zeros(1, 1, D, dtype=torch.bfloat16)
+    g = torch.zeros(1, 1, D)
+    state = torch.zeros(1, 1, D, D, dtype=torch.float32)
+    state[0, 0, 0, 0] = 1.0
+    state[0, 0, 1, 1] = 1.0
+    o = gla_decode_step_ref(q, k, v, g, state, torch.tensor([0], dtype=torch.int32))
+    sc = torch.tensor(D ** -0.5).to(torch.bfloat16)
+    assert float(sc) == 0.08837890625
+    assert float(o[0, 0, 0]) == float(sc)
+    assert float(o[0, 0, 1]) == float((q[0, 0, 1] * sc))

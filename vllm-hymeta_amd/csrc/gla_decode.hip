@@ -1,4 +1,5 @@
-// GLA single-token decode: S' = bf16(k v^T) + exp(g) * S ; o = (scale q) S'.
+// GLA single-token decode: S' = bf16(k v^T) + exp(g) * S ; o = bf16(bf16(scale) q) S'  (the rounding points of
+// vllm_hymeta/models/my_fused_recurrent.py:59-76).
 //
 // HBM-bound: per (sequence, head) the kernel streams the 128x128 state once in
 // and once out (64 KiB at bf16) and touches 5 vectors of 128 elements.  One
@@ -8,6 +9,8 @@
 // the q-contraction in registers.  Rows of the state are 256 B, so a wave's
 // 16-byte-per-lane access covers whole rows (NSPLIT 1) or 128-B half rows
 // (NSPLIT 2): fully coalesced either way.
+#include <string.h>
+
 #include "lowrank_gate.h"
 #include "common.h"
 #include "gla_gate.h"
@@ -553,7 +556,12 @@ extern "C" int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stre
 
   GateParams gp;
   gp.mode = a.gate_mode;
-  gp.scale = a.scale > 0.f ? a.scale : 1.f / sqrtf(static_cast<float>(a.head_dim));
+  // the reference multiplies q by the scale in bf16: the scale enters rounded to bf16 (round to nearest even)
+  const float scale = a.scale > 0.f ? a.scale : 1.f / sqrtf(static_cast<float>(a.head_dim));
+  uint32_t scale_bits;
+  memcpy(&scale_bits, &scale, sizeof(scale_bits));
+  scale_bits = (scale_bits + 0x7fffu + ((scale_bits >> 16) & 1u)) & 0xffff0000u;
+  memcpy(&gp.scale, &scale_bits, sizeof(scale_bits));
   gp.normalizer = a.gate_normalizer > 0.f ? a.gate_normalizer : 16.f;
   gp.clamp = a.gate_clamp > 0.f ? a.gate_clamp : 0.95f;
 

@@ -14,30 +14,36 @@ struct GateParams {
   float clamp;       // HYMETA_GATE_70B_CLAMP
 };
 
-// q_raw, k_raw: the bf16 projections widened to fp32; g_raw: the gate input
-// widened to fp32 (ignored by the 70B modes); lb: lower bound of this channel.
-// Outputs: qs = feature-mapped q times scale (fp32); kb = k rounded to bf16
-// (as fp32); g = log-decay (fp32, <= 0).
+// bf16 * bf16 scale as the single-token kernel of the reference forms it
+// (vllm_hymeta/models/my_fused_recurrent.py:59: a tensor-times-scalar product is computed in the
+// tensor's dtype, so the scalar is cast to bf16 first and the product is rounded to bf16; the
+// widening to fp32 at :75 comes after).  ``scale_bf16`` is the scale already rounded.
+__device__ __forceinline__ float scaled_query_bf16(float q, float scale_bf16) { return bf16_round(q * scale_bf16); }
+
+// Decode-step form.  q_raw, k_raw: the bf16 projections widened to fp32; g_raw: the gate input
+// widened to fp32 (ignored by the 70B modes); lb: lower bound of this channel; gp.scale: the
+// scale rounded to bf16.  Outputs: qs = feature-mapped q times scale, rounded to bf16 (as fp32);
+// kb = k rounded to bf16 (as fp32); g = log-decay (fp32, <= 0).
 __device__ __forceinline__ void apply_gate(const GateParams& gp, float q_raw, float k_raw,
                                            float g_raw, float lb, float& qs, float& kb,
                                            float& g) {
   switch (gp.mode) {
     case HYMETA_GATE_7B: {
-      qs = fmaxf(q_raw, 0.f) * gp.scale;
+      qs = scaled_query_bf16(fmaxf(q_raw, 0.f), gp.scale);
       kb = fmaxf(k_raw, 0.f);
       // logsigmoid is evaluated on a bf16 tensor and divided in bf16.
       g = bf16_round(bf16_round(logsigmoidf(g_raw)) / gp.normalizer);
       break;
     }
     case HYMETA_GATE_70B_CLAMP: {
-      qs = fmaxf(q_raw, 0.f) * gp.scale;
+      qs = scaled_query_bf16(fmaxf(q_raw, 0.f), gp.scale);
       float kt = fminf(sigmoidf(k_raw), gp.clamp);
       g = __logf(1.f - kt);
       kb = bf16_round(kt);
       break;
     }
     case HYMETA_GATE_70B_LOWER_BOUND: {
-      qs = fmaxf(q_raw, 0.f) * gp.scale;
+      qs = scaled_query_bf16(fmaxf(q_raw, 0.f), gp.scale);
       float kt = sigmoidf(k_raw);
       float gl = 1.f - (1.f - lb) * kt;
       g = __logf(gl);
@@ -45,7 +51,7 @@ __device__ __forceinline__ void apply_gate(const GateParams& gp, float q_raw, fl
       break;
     }
     default: {
-      qs = q_raw * gp.scale;
+      qs = scaled_query_bf16(q_raw, gp.scale);
       kb = k_raw;
       g = g_raw;
       break;
@@ -67,7 +73,9 @@ __device__ __forceinline__ float log1p_unit(float e) {
 }
 
 // Branch-free, compile-time-mode form of apply_gate for the prefill producers, where the gate
-// math is the VALU budget: same formulas; the sigmoid uses the hardware reciprocal (1 ulp) and
+// math is the VALU budget: same formulas, except that q * scale stays in fp32 (the chunked kernel
+// of flash-linear-attention that the reference calls for prefill is third party: its rounding
+// points are not known here); the sigmoid uses the hardware reciprocal (1 ulp) and
 // the 7B normaliser is applied as a multiplication by 1/normalizer (exact for powers of two,
 // 16 in every published configuration).
 template <int GATE>
