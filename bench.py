@@ -523,6 +523,7 @@ def cpu_baseline(args):
                 gate_up=rb(2 * INTER, HIDDEN, sc=HIDDEN ** -0.5), down=rb(HIDDEN, INTER, sc=INTER ** -0.5)) for _ in range(2)]
     gk0, gk1, gk1_b = rb(16, HIDDEN, sc=HIDDEN ** -0.5), rb(HKV * D, 16, sc=0.25), rb(HKV * D, sc=0.02)
     ones_h, ones_d = torch.ones(HIDDEN, dtype=torch.bfloat16), torch.ones(D, dtype=torch.bfloat16)
+    lm_head = rb(VOCAB, HIDDEN, sc=HIDDEN ** -0.5).float()      # the reference widens lm_head to fp32 (modeling_gla_swa.py:548)
     table = rope_cos_sin_cache_ref(D, ctx + 64, 1e6)
     x0 = rb(Bc, HIDDEN, sc=0.5)
 
@@ -552,20 +553,28 @@ def cpu_baseline(args):
         n, r = add_rms_norm_ref(_linear(att.reshape(Bc, H * D).to(torch.bfloat16), lay[1]["o"]), x, ones_h)
         return (r.float() + mlp(lay[1], n).float()).to(torch.bfloat16)
 
-    step(0)  # warm-up
-    n, t0 = 0, time.perf_counter()
+    def head(x):
+        """final norm, fp32 logits, greedy token: once per step whatever the layer count"""
+        h, _ = add_rms_norm_ref(x, None, ones_h)
+        return (h.float() @ lm_head.t()).argmax(dim=-1)
+
+    head(step(0))  # warm-up
+    n, t_layers, t_head = 0, 0.0, 0.0
     while True:
-        step(1 + n)
+        t0 = time.perf_counter()
+        x = step(1 + n)
+        t1 = time.perf_counter()
+        head(x)
+        t_layers, t_head = t_layers + (t1 - t0), t_head + (time.perf_counter() - t1)
         n += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or n >= 8:
+        if t_layers + t_head > 10.0 or n >= 8:
             break
-    per_step_28 = el / n * (N_LAYERS / 2)
+    per_step_28 = t_layers / n * (N_LAYERS / 2) + t_head / n
     return {"value": round(Bc / per_step_28, 3), "unit": "tokens/s", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"oracle/ (torch CPU, {torch.get_num_threads()} threads): {Bc} sequences x {n} decode steps at ctx {ctx} through "
                       "one GLA layer + one sliding-window layer of the published geometry (norms, projections, attention, MLP), "
-                      "time scaled from 2 to 28 layers"}
+                      "layer time scaled from 2 to 28 layers, plus the final norm, the fp32 lm_head logits and the argmax once per step"}
 
 
 # --------------------------------------------------------------------------- main (N = 1)
@@ -637,6 +646,9 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": read_traffic(B, args.ctx),
+            "traffic_source": "profiles/traffic_model_decode.json: FETCH_SIZE / WRITE_SIZE counter passes (rocprofv3 --pmc, separate runs, "
+                              "tools/profile_model_step.sh) over this command on an earlier run of this tree; NOT collected by this run "
+                              "(null when no recorded pass matches this batch and context)",
             "algorithmic_bytes_per_launch": int(step_bytes),
             "linear_weight_bytes": linear_weight_bytes(args.quant),
             "attention_bytes": int(attention_bytes(B, args.ctx, state_heads=state_heads)),

@@ -21,6 +21,17 @@
  *    crosses the boundary.  hymeta_strerror() names a code.
  *  - Activations, KV cache and (by default) the recurrent state are bf16;
  *    accumulation is fp32.
+ *
+ * Versioning
+ *  - hymeta_abi_version() returns the HYMETA_ABI_VERSION the library was built
+ *    with; a binding compares it with the header it was written against before
+ *    the first call (version 2: every argument struct starts with struct_size).
+ *  - Every argument struct starts with `uint32_t struct_size`, which the caller
+ *    sets to sizeof(the struct) of ITS declaration.  An entry point returns
+ *    HYMETA_ERR_INVALID_ARG, before it reads any other field, when the value
+ *    is not the size the library was built with: a binding that is a field
+ *    short (or long) gets an error code, never a kernel that reads past the
+ *    end of its struct.
  */
 #ifndef HYMETA_HIP_H
 #define HYMETA_HIP_H
@@ -32,7 +43,7 @@
 extern "C" {
 #endif
 
-#define HYMETA_ABI_VERSION 1
+#define HYMETA_ABI_VERSION 2
 
 typedef void* hymeta_stream_t;
 
@@ -81,8 +92,11 @@ int hymeta_stream_capture_id(hymeta_stream_t stream, uint64_t* id);
  * Per (sequence b, q-head h), kv-head j = h / (num_heads / num_kv_heads):
  *   S  = state[slot_idx[b], h]                       (Dk x Dv, row-major)
  *   S' = bf16(k_j * v_j^T) + exp(g_j)[:,None] * S    (fp32)
- *   out[b,h,:] = sum_dk (scale * q[b,h,dk]) * S'[dk,:]
+ *   out[b,h,:] = sum_dk bf16(bf16(scale) * q[b,h,dk]) * S'[dk,:]   (fp32 sum)
  *   state[slot_idx[b], h] = S'  (rounded to state_dtype)
+ * The two bf16 roundings of the query side are the reference kernel's: its
+ * `load(q) * scale` (my_fused_recurrent.py:59) is a tensor-times-scalar product,
+ * which Triton computes in the tensor's dtype with the scalar cast to it.
  * slot_idx[b] == -1 skips sequence b (state and out untouched).
  * Optional fused prologue (gate_mode) and epilogue (per-head RMS norm over Dv
  * with weight out_norm_weight[Dv] and out_norm_eps, the g_norm of
@@ -99,6 +113,7 @@ int hymeta_stream_capture_id(hymeta_stream_t stream, uint64_t* id);
  * query of the group; out is bit-identical to the per-query-head layout.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_gla_decode_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* q;            /* bf16 [batch, num_heads,    head_dim] */
   const void* k;            /* bf16 [batch, num_kv_heads, head_dim] */
   const void* v;            /* bf16 [batch, num_kv_heads, head_dim] */
@@ -187,6 +202,7 @@ int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stream_t stream
  * Segment counts and the workspace are then sized over state_heads.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_gla_prefill_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* q;            /* bf16 [total_tokens, num_heads,    head_dim] */
   const void* k;            /* bf16 [total_tokens, num_kv_heads, head_dim] */
   const void* v;            /* bf16 [total_tokens, num_kv_heads, head_dim] */
@@ -241,6 +257,7 @@ int hymeta_gla_prefill_varlen(const hymeta_gla_prefill_args* args, hymeta_stream
  * a negative slot (PAD_SLOT_ID) writes nothing.  Bit-exact.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_reshape_and_cache_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* key;          /* [num_tokens, num_kv_heads, head_dim] */
   const void* value;
   void* key_cache;          /* [num_blocks, block_size, num_kv_heads, head_dim] */
@@ -291,6 +308,7 @@ int hymeta_reshape_and_cache(const hymeta_reshape_and_cache_args* args, hymeta_s
  * two per layer and step.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_paged_decode_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* q;            /* bf16 [batch, num_heads, head_dim] */
   void* out;                /* bf16 [batch, num_heads, head_dim] */
   const void* key_cache;    /* bf16 [num_blocks, block_size, num_kv_heads, head_dim] */
@@ -370,6 +388,7 @@ int hymeta_meta_swa_paged_decode_static(const hymeta_paged_decode_args* args, hy
  * queries (they see the meta keys only), followed by the real rows.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_swa_prefill_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* q;            /* bf16 [total_q, num_heads, head_dim] */
   const void* key;          /* bf16 [total_k, num_kv_heads, head_dim] (un-paged) or NULL */
   const void* value;
@@ -436,6 +455,7 @@ int hymeta_meta_swa_prefill(const hymeta_swa_prefill_args* args, hymeta_stream_t
  * (vllm_hymeta/models/modeling_hymeta.py:1314-1323).
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_rope_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   void* q;                   /* bf16 [num_tokens, num_heads,    head_dim] */
   void* k;                   /* bf16 [num_tokens, num_kv_heads, head_dim] or NULL */
   const int64_t* positions;  /* [num_tokens] */
@@ -471,6 +491,7 @@ int hymeta_rope_neox(const hymeta_rope_args* args, hymeta_stream_t stream);
  *                           xn = bf16(x * rsqrt(var + eps)); y = bf16((xn1*w1 + xn2*w2) / 2).
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_combine_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* o_attn;    /* bf16 [num_tokens, hidden_local] */
   const void* o_lin;     /* bf16 [num_tokens, hidden_local] */
   const float* weight1;  /* fp32 [hidden_local] (norm1, softmax branch) */
@@ -501,6 +522,7 @@ int hymeta_hybrid_combine(const hymeta_combine_args* args, hymeta_stream_t strea
  * out may alias x.  hidden is a multiple of 8.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_add_rmsnorm_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* x;         /* bf16 [num_tokens, hidden] */
   void* residual;        /* bf16 [num_tokens, hidden], updated in place, or NULL */
   const void* weight;    /* bf16 [hidden] */
@@ -524,6 +546,7 @@ int hymeta_add_rmsnorm(const hymeta_add_rmsnorm_args* args, hymeta_stream_t stre
  * rank must be 16, hidden a multiple of 8.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_lowrank_gate_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* x;         /* bf16 [num_tokens, hidden] */
   const void* w0;        /* bf16 [rank, hidden], contiguous */
   const void* w1;        /* bf16 [out_features, rank], contiguous */
@@ -575,6 +598,7 @@ int hymeta_lowrank_gate(const hymeta_lowrank_gate_args* args, hymeta_stream_t st
  * ---------------------------------------------------------------------- */
 #define HYMETA_GEMM_TICKET_BYTES 16384
 typedef struct hymeta_gptq_gemm_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* x;          /* bf16 [M, K] */
   const int32_t* qweight;
   const int32_t* qzeros;
@@ -618,6 +642,7 @@ int hymeta_gptq_dequant(const int32_t* qweight, const int32_t* qzeros, const voi
  * a bound that does not depend on K) and means 1 without one.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_bf16_gemm_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* x;          /* bf16 [M, K] */
   const void* weight;     /* bf16 [N, K] */
   const void* bias;       /* bf16 [N] or NULL */
@@ -686,6 +711,7 @@ int hymeta_bf16_gemm_silu_mul(const hymeta_bf16_gemm_args* args, hymeta_stream_t
  * library choose when a workspace is given, and means 1 without one.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_w8a8_gemm_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* x;           /* bf16 [M, K]; NULL: xq / x_scale below already hold the quantised rows (inputs) */
   const int8_t* qweight;   /* int8 [N, K] */
   const float* w_scale;    /* fp32 [N] */
@@ -721,6 +747,7 @@ int hymeta_w8a8_gemm_silu_mul(const hymeta_w8a8_gemm_args* args, hymeta_stream_t
  * The partial sums live in the GEMM call's workspace: consume them before the next call that uses it.
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_gemm_partials {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* slabs;     /* [splits][M][N] fp32 (bf16 linear) or int32 (W8A8) */
   int32_t splits;        /* 0: the call wrote `out` itself (no K slices): nothing is deferred */
   int32_t is_int32;
@@ -783,6 +810,7 @@ int hymeta_w8a8_scale_out(const int32_t* acc, const float* x_scale, const float*
  * Weight stacks are K-contiguous: W13 [E, 2 I, H], W2 [E, H, I] (vLLM's w13 / w2).
  * ---------------------------------------------------------------------- */
 typedef struct hymeta_moe_route_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* router_logits;   /* logits_dtype [num_tokens, num_experts] */
   int32_t* topk_ids;           /* out [num_tokens, top_k] */
   float* topk_weights;         /* out [num_tokens, top_k] */
@@ -811,6 +839,7 @@ int hymeta_moe_route(const hymeta_moe_route_args* args, hymeta_stream_t stream);
  * hymeta_moe_route). */
 #define HYMETA_MOE_ROUTER_MAX_TOKENS 256
 typedef struct hymeta_moe_router_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* x;               /* bf16 [num_tokens, hidden] */
   const void* gate_weight;     /* bf16 [num_experts, hidden] contiguous */
   void* logits_out;            /* bf16 [num_tokens, num_experts] or NULL */
@@ -828,6 +857,7 @@ typedef struct hymeta_moe_router_args {
 int hymeta_moe_router(const hymeta_moe_router_args* args, hymeta_stream_t stream);
 
 typedef struct hymeta_moe_gemm_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* x;               /* bf16 rows of K */
   const void* weights;         /* bf16 [experts, N, K] */
   void* out;                   /* bf16 [slots, N] */
@@ -862,6 +892,7 @@ int hymeta_silu_and_mul(const void* in, void* out, const int32_t* num_rows_dev, 
                         int32_t inter, int64_t in_stride, int64_t out_stride, hymeta_stream_t stream);
 
 typedef struct hymeta_moe_combine_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
   const void* y;               /* bf16 [slots, hidden] */
   const void* shared;          /* bf16 [num_tokens, hidden] or NULL */
   void* out;                   /* bf16 [num_tokens, hidden] */

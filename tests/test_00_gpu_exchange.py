@@ -121,11 +121,20 @@ def test_replays_from_graphs_with_eager_calls_between():
 
 
 def test_a_wait_for_a_missing_peer_ends_at_its_limit():
+    """... and what it could not sum comes out as NaN, never as a sum of whatever the slots held; the serving path's check
+    turns the sticky count into an error."""
+    from vllm_hymeta.parallel import InProcessGroup, OneShotTimeout, raise_on_exchange_timeout
+
     comms, streams, dev = _ranks(2, wait_s=0.002)
     x = randn_bf16(gen(60), 64, HIDDEN).to(dev)
-    comms[0].all_reduce(data=x)          # rank 1 never calls: rank 0's blocks give up after 2 ms and the launch ends
+    s = torch.rand(64, 2, generator=gen(61)).to(dev)
+    comms[0].all_reduce(data=x, stats=s)          # rank 1 never calls: rank 0's blocks give up after 2 ms and the launch ends
     torch.cuda.synchronize()
     assert comms[0].timeouts() > 0 and comms[1].timeouts() == 0
+    assert bool(torch.isnan(x).all()) and bool(torch.isnan(s).all())
+    raise_on_exchange_timeout(InProcessGroup(1, 2, comms[1], streams[1]))      # the rank that never waited: nothing to report
+    with pytest.raises(OneShotTimeout):
+        raise_on_exchange_timeout(InProcessGroup(0, 2, comms[0], streams[0]))
     _close(comms)
 
 

@@ -54,6 +54,67 @@ def test_ctypes_structs_match_header_layout():
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
 
 
+def test_every_header_struct_has_a_ctypes_mirror_that_starts_with_its_size():
+    from vllm_hymeta import _C
+
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"typedef struct (hymeta_\w+) \{", text)))
+    assert declared == sorted(_C.STRUCTS), "a struct of the header has no mirror in _C.STRUCTS (or the reverse)"
+    for cname, cls in _C.STRUCTS.items():
+        assert cls._fields_[0][0] == "struct_size" and cls.struct_size.offset == 0, cname
+        assert cls().struct_size == C.sizeof(cls), cname                # filled in on construction
+        assert cls(struct_size=7).struct_size == 7, cname               # unless the caller says otherwise
+
+
+def test_integration_document_struct_equals_the_binding():
+    """The ctypes struct INTEGRATION.md tells a maintainer to declare is the one the library reads: same fields,
+    same types, same size (a stale document would hand the kernels a short struct)."""
+    from vllm_hymeta import _C
+
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"^(P, I32, I64, F32, U32 = [^\n]*\n)class GlaDecodeArgs\(C\.Structure\):[^\n]*\n(    _fields_ = \[.*?\)\])\n",
+                  doc, flags=re.S | re.M)
+    assert m, "INTEGRATION.md no longer holds the GlaDecodeArgs snippet"
+    ns = {"C": C}
+    exec(m.group(1) + "class GlaDecodeArgs(C.Structure):\n" + m.group(2) + "\n", ns)
+    doc_cls = ns["GlaDecodeArgs"]
+    assert [(n, t) for n, t in doc_cls._fields_] == [(n, t) for n, t in _C.GlaDecodeArgs._fields_]
+    assert C.sizeof(doc_cls) == C.sizeof(_C.GlaDecodeArgs)
+    ver = re.search(r"hymeta_abi_version\(\) == (\d+)", doc)
+    assert ver and int(ver.group(1)) == _C.ABI_VERSION
+    assert f"#define HYMETA_ABI_VERSION {_C.ABI_VERSION}\n" in open(HEADER).read()
+
+
+def test_wrong_struct_size_is_refused_by_every_entry_point():
+    """Each struct-taking entry point compares struct_size with its own sizeof first and returns
+    HYMETA_ERR_INVALID_ARG (-1); nothing is launched, so this runs without a GPU."""
+    from vllm_hymeta import _C
+
+    lib = _C.load()
+
+    def struct_of(argtype):
+        t = getattr(argtype, "_type_", None)
+        return t if isinstance(t, type) and issubclass(t, _C._Args) else None
+
+    seen = set()
+    for name, (_, argtypes) in _C._SIGNATURES.items():
+        if not any(struct_of(a) for a in argtypes):
+            continue
+        for delta in (-4, 8):
+            args = []
+            for a in argtypes:
+                st = struct_of(a)
+                if st is not None:
+                    args.append(C.byref(st(struct_size=C.sizeof(st) + delta)))
+                    seen.add(st)
+                elif a is C.c_void_p:
+                    args.append(None)
+                else:
+                    args.append(a())
+            assert getattr(lib, name)(*args) == -1, (name, delta)
+    assert seen == set(_C.STRUCTS.values())      # every struct is taken by some entry point and was exercised
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     """The ops have no fallback: a missing .so is an error, not a silent CPU path."""
     code = ("import os, sys; sys.path.insert(0, %r); os.environ['HYMETA_HIP_LIB'] = %r\n"

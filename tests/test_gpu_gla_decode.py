@@ -252,3 +252,31 @@ def test_gla_decode_follows_the_reference_kernels_rounding_points():
     o_old = (qs_old[:, :, :, None] * s_new).sum(dim=2).to(torch.bfloat16)
     old_differ = (o_old.view(torch.int16) != o_ref.view(torch.int16)).float().mean().item()
     assert old_differ > 3 * max(differ, 0.02), (old_differ, differ)
+
+
+def test_stale_struct_is_refused_before_any_field_is_read():
+    """A binding compiled against an older header passes a shorter struct: every entry point compares the leading
+    struct_size with its own sizeof and returns HYMETA_ERR_INVALID_ARG (-1) without touching the rest."""
+    import ctypes as C
+
+    from vllm_hymeta import _C
+
+    lib = _C.load()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    class OldGlaDecodeArgs(C.Structure):      # the struct as a first-cut binding declared it: no size, eleven fields short
+        _fields_ = [f for f in _C.GlaDecodeArgs._fields_[1:] if f[0] not in (
+            "state_heads", "g_w1", "g_bias", "qkv_slabs", "qkv_bias", "qkv_splits", "qkv_n", "q_col", "k_col", "v_col", "g_col",
+            "g_w0", "g_hidden")]
+
+    q = torch.zeros(1, 1, D, dtype=torch.bfloat16, device="cuda")
+    old = OldGlaDecodeArgs(q=q.data_ptr(), k=q.data_ptr(), v=q.data_ptr(), g=q.data_ptr(), out=q.data_ptr(), batch=1, num_heads=1,
+                           num_kv_heads=1, head_dim=D)
+    fn = lib.hymeta_gla_decode
+    saved = fn.argtypes
+    fn.argtypes = [C.c_void_p, C.c_void_p]
+    try:
+        assert fn(C.addressof(old), stream) == -1
+    finally:
+        fn.argtypes = saved
+    torch.cuda.synchronize()

@@ -8,6 +8,19 @@
 
 namespace hymeta {
 
+// Guard of every entry point: the caller's struct is there and was compiled to the size this library
+// was built with (its first field says so), checked before any other field is read.
+template <typename T>
+inline bool args_ok(const T* a) { return a != nullptr && a->struct_size == sizeof(T); }
+
+// An argument struct the library builds for its own calls.
+template <typename T>
+__host__ __device__ inline T make_args() {
+  T t = {};
+  t.struct_size = static_cast<uint32_t>(sizeof(T));
+  return t;
+}
+
 constexpr int kWave = 64;        // CDNA wavefront width
 constexpr int kHeadDim = 128;    // the only head size the Hymeta models use
 

@@ -164,8 +164,8 @@ extern "C" size_t hymeta_bf16_gemm_workspace_bytes(int32_t M, int32_t N, int32_t
 }
 
 static int bf16_gemm_impl(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream, hymeta_gemm_partials* deferred) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
-  if (deferred != nullptr) *deferred = hymeta_gemm_partials{};
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
+  if (deferred != nullptr) *deferred = hymeta::make_args<hymeta_gemm_partials>();
   const hymeta_bf16_gemm_args& a = *args;
   if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;
@@ -224,14 +224,14 @@ extern "C" int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream
 
 extern "C" int hymeta_bf16_gemm_deferred(const hymeta_bf16_gemm_args* args, hymeta_gemm_partials* partials,
                                          hymeta_stream_t stream) {
-  if (partials == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(partials)) return HYMETA_ERR_INVALID_ARG;
   return bf16_gemm_impl(args, stream, partials);
 }
 
 // fp32 result of bf16 operands, unrounded: the logits of a bf16 lm_head.  The streaming kernel without K slices only.
 extern "C" int hymeta_bf16_gemm_f32out(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream) {
   using namespace hymeta;
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_bf16_gemm_args& a = *args;
   if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;
@@ -255,7 +255,7 @@ extern "C" int hymeta_bf16_gemm_f32out(const hymeta_bf16_gemm_args* args, hymeta
 // caller runs hymeta_bf16_gemm + hymeta_silu_and_mul, which give the same bits.
 extern "C" int hymeta_bf16_gemm_silu_mul(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream) {
   using namespace hymeta;
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_bf16_gemm_args& a = *args;
   if (a.M < 0 || a.K <= 0 || a.N <= 0 || a.bias != nullptr) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;

@@ -22,7 +22,7 @@ namespace hymeta {
 // token (bf16, the first linear's rounded output) and the second linear is applied here, one output feature per thread, in
 // the arithmetic of hymeta_lowrank_gate's second stage (fma chain in rank order, bias added, rounded to bf16).
 __device__ __forceinline__ hymeta_gemm_partials qkv_partials(const hymeta_gla_decode_args& a) {
-  hymeta_gemm_partials p = {};
+  hymeta_gemm_partials p = hymeta::make_args<hymeta_gemm_partials>();
   p.slabs = a.qkv_slabs, p.splits = a.qkv_splits, p.bias = a.qkv_bias, p.M = a.batch, p.N = a.qkv_n;
   return p;
 }
@@ -516,7 +516,7 @@ void launch_group(const hymeta_gla_decode_args& a, const GateParams& gp, bool sp
 }  // namespace
 
 extern "C" int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_gla_decode_args& a = *args;
   if (a.batch < 0 || a.num_heads <= 0 || a.num_kv_heads <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.batch == 0) return HYMETA_OK;

@@ -1241,7 +1241,7 @@ void launch_main(const hymeta_gla_prefill_args& a, const GateParams& gp, float* 
 }  // namespace
 
 extern "C" int hymeta_gla_prefill_varlen(const hymeta_gla_prefill_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   hymeta_gla_prefill_args a = *args;
   if (a.num_seqs < 0 || a.total_tokens < 0 || a.num_heads <= 0 || a.num_kv_heads <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.num_seqs == 0 || a.total_tokens == 0) return HYMETA_OK;

@@ -294,7 +294,7 @@ using namespace hymeta;
 
 static int add_rmsnorm_partials_impl(const hymeta_add_rmsnorm_args* args, const hymeta_gemm_partials* partials, int8_t* xq,
                                      float* x_scale, hymeta_stream_t stream) {
-  if (args == nullptr || partials == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args) || !hymeta::args_ok(partials)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_add_rmsnorm_args& a = *args;
   const hymeta_gemm_partials& p = *partials;
   if (a.num_tokens < 0 || a.hidden <= 0 || p.splits < 1 || !p.slabs) return HYMETA_ERR_INVALID_ARG;
@@ -324,7 +324,7 @@ extern "C" int hymeta_add_rmsnorm_partials(const hymeta_add_rmsnorm_args* args, 
 }
 
 extern "C" int hymeta_rope_neox(const hymeta_rope_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_rope_args& a = *args;
   if (a.num_tokens < 0 || a.num_heads <= 0 || a.num_kv_heads < 0) return HYMETA_ERR_INVALID_ARG;
   if (a.num_tokens == 0) return HYMETA_OK;
@@ -339,7 +339,7 @@ extern "C" int hymeta_rope_neox(const hymeta_rope_args* args, hymeta_stream_t st
 
 extern "C" int hymeta_rope_neox_partials(const hymeta_rope_args* args, const hymeta_gemm_partials* partials,
                                          hymeta_stream_t stream) {
-  if (args == nullptr || partials == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args) || !hymeta::args_ok(partials)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_rope_args& a = *args;
   const hymeta_gemm_partials& p = *partials;
   if (a.num_tokens < 0 || a.num_heads <= 0 || a.num_kv_heads < 0 || p.splits < 1 || !p.slabs) return HYMETA_ERR_INVALID_ARG;
@@ -374,7 +374,7 @@ static int check_combine(const hymeta_combine_args& a, bool need_out) {
 }
 
 extern "C" int hymeta_rms_sumsq2(const hymeta_combine_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const int rc = check_combine(*args, false);
   if (rc != HYMETA_OK || args->num_tokens == 0) return rc;
   hipLaunchKernelGGL((hybrid_combine_kernel<0>), dim3(args->num_tokens), dim3(256), 0, begin_launches(stream), *args);
@@ -382,7 +382,7 @@ extern "C" int hymeta_rms_sumsq2(const hymeta_combine_args* args, hymeta_stream_
 }
 
 extern "C" int hymeta_hybrid_combine(const hymeta_combine_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const int rc = check_combine(*args, true);
   if (rc != HYMETA_OK || args->num_tokens == 0) return rc;
   hipLaunchKernelGGL((hybrid_combine_kernel<1>), dim3(args->num_tokens), dim3(256), 0, begin_launches(stream), *args);
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void lowrank_gate_kernel(hymeta_lowrank_gate_a
 }  // namespace hymeta
 
 extern "C" int hymeta_lowrank_gate(const hymeta_lowrank_gate_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_lowrank_gate_args& a = *args;
   if (a.num_tokens < 0 || a.hidden <= 0 || a.out_features <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.num_tokens == 0) return HYMETA_OK;
@@ -451,7 +451,7 @@ extern "C" int hymeta_lowrank_gate(const hymeta_lowrank_gate_args* args, hymeta_
 }
 
 static int add_rmsnorm_impl(const hymeta_add_rmsnorm_args* args, int8_t* xq, float* x_scale, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_add_rmsnorm_args& a = *args;
   if (a.num_tokens < 0 || a.hidden <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.num_tokens == 0) return HYMETA_OK;
@@ -478,6 +478,7 @@ extern "C" int hymeta_add_rmsnorm(const hymeta_add_rmsnorm_args* args, hymeta_st
 extern "C" int hymeta_add_rmsnorm_int8(const hymeta_add_rmsnorm_args* args, const hymeta_gemm_partials* partials, int8_t* xq,
                                        float* x_scale, hymeta_stream_t stream) {
   if (xq == nullptr || x_scale == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (partials != nullptr && !hymeta::args_ok(partials)) return HYMETA_ERR_INVALID_ARG;
   if (partials != nullptr && partials->splits > 0) return add_rmsnorm_partials_impl(args, partials, xq, x_scale, stream);
   return add_rmsnorm_impl(args, xq, x_scale, stream);
 }

@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(hymeta_moe_combine_arg
 using namespace hymeta;
 
 extern "C" int hymeta_moe_route(const hymeta_moe_route_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_moe_route_args& a = *args;
   if (a.num_tokens < 0 || a.num_experts <= 0 || a.top_k <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.num_experts > kMaxExperts || a.top_k > 2 || a.top_k > a.num_experts) return HYMETA_ERR_UNSUPPORTED;
@@ -685,7 +685,7 @@ extern "C" int hymeta_moe_route(const hymeta_moe_route_args* args, hymeta_stream
 }
 
 extern "C" int hymeta_moe_router(const hymeta_moe_router_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_moe_router_args& a = *args;
   if (a.num_tokens < 0 || a.num_experts <= 0 || a.top_k <= 0 || a.hidden <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.num_experts > kMaxExperts || a.top_k > 2 || a.top_k > a.num_experts) return HYMETA_ERR_UNSUPPORTED;
@@ -726,7 +726,7 @@ extern "C" int hymeta_moe_gemm_fuses(int32_t max_rows, int32_t experts, int32_t 
 
 extern "C" int hymeta_moe_gemm(const hymeta_moe_gemm_args* args, hymeta_stream_t stream) {
   using namespace hymeta;
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_moe_gemm_args& a = *args;
   if (a.max_rows < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.local_expert_begin < 0 || a.local_expert_end < a.local_expert_begin) return HYMETA_ERR_INVALID_ARG;
@@ -789,7 +789,7 @@ extern "C" int hymeta_silu_and_mul(const void* in, void* out, const int32_t* num
 }
 
 extern "C" int hymeta_moe_combine(const hymeta_moe_combine_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_moe_combine_args& a = *args;
   if (a.num_tokens < 0 || a.hidden <= 0 || a.top_k <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.num_tokens == 0) return HYMETA_OK;

@@ -21,8 +21,13 @@
 // reader of the parity's slots.  That argument needs the launches of one communicator to be ordered on
 // every rank (one stream, or one graph): calls that overlap on a rank race.
 //
-// Every wait is bounded by wall-clock ticks; a block that gives up counts a timeout in the state and
-// goes on (its output is then undefined), so that every launch ends whatever the peers do.
+// Every wait is bounded by wall-clock ticks, so that every launch ends whatever the peers do.  A block
+// whose wait runs out counts a timeout in the state (a sticky count: nothing on the device ever clears
+// it) and writes NaN over its share of the output instead of a sum of whatever the slots held, so a
+// missed peer can never pass for a result; the host looks at the count where it synchronises anyway
+// (hymeta_p2p_timeouts) and must then stop using the communicator: after a timeout the argument above
+// no longer holds -- the rank that gave up can reach epoch e + 2 and overwrite slots and flags of
+// parity e that a late peer has not read yet, so the peer times out in turn.
 #include "common.h"
 #include "partial_sums.h"
 
@@ -66,8 +71,12 @@ __device__ __forceinline__ uint32_t* flag_ptr(char* buf, int parity, int rank, i
 template <int W, int MODE>
 __global__ __launch_bounds__(kThreads) void p2p_all_reduce_kernel(P2pArgs a) {
   __shared__ uint32_t s_epoch;
+  __shared__ uint32_t s_timed_out;
   const int tid = threadIdx.x, b = blockIdx.x;
-  if (tid == 0) s_epoch = __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  if (tid == 0) {
+    s_epoch = __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    s_timed_out = 0;
+  }
   __syncthreads();
   const uint32_t epoch = s_epoch;
   const int parity = epoch & 1;
@@ -108,6 +117,7 @@ __global__ __launch_bounds__(kThreads) void p2p_all_reduce_kernel(P2pArgs a) {
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
       if (wall_clock64() - t0 > a.spin_ticks) {
         atomicAdd(a.state + 2, 1u);
+        s_timed_out = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(4);
@@ -115,12 +125,24 @@ __global__ __launch_bounds__(kThreads) void p2p_all_reduce_kernel(P2pArgs a) {
   }
   __syncthreads();
 
-  // sum the W slots in rank order
+  // sum the W slots in rank order; a block that missed a peer writes NaN (fp32 and bf16 quiet NaNs) instead
+  const bool poisoned = s_timed_out != 0;
   const char* mine = a.peers[a.rank] + slots;
   for (int64_t u = u_lo + tid; u < u_hi; u += kThreads) {
     u32x4 v[W];
 #pragma unroll
     for (int q = 0; q < W; ++q) v[q] = ld16g(mine + static_cast<size_t>(q) * a.slot_bytes + 16 * u);
+    if (poisoned) {
+      if (u < a.units_stats) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * u + i < a.n_stats) a.stats[4 * u + i] = __uint_as_float(0x7FC00000u);
+      } else {
+        const u32x4 nan = {0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u};
+        *reinterpret_cast<u32x4*>((MODE != 0 ? a.out : a.data) + 8 * (u - a.units_stats)) = nan;
+      }
+      continue;
+    }
     if (u < a.units_stats) {
       float f[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -178,8 +200,10 @@ int launch_exchange(int world, P2pArgs& a, hymeta_stream_t stream) {
 struct hymeta_p2p_comm {
   int rank = 0, world = 0, device = 0;
   size_t max_bytes = 0, slot_bytes = 0, buffer_bytes = 0;
+  size_t alloc_bytes = 0;               // size of the allocation behind the own buffer (a parked one may be larger than asked)
   char* peers[hymeta::kMaxWorld] = {};
   bool opened[hymeta::kMaxWorld] = {};
+  bool by_pointer[hymeta::kMaxWorld] = {};   // peers[q] is a buffer of this process that this communicator holds
   bool connected = false;
   uint32_t* state = nullptr;
   uint64_t spin_ticks = hymeta::kDefaultSpinTicks;
@@ -188,9 +212,11 @@ struct hymeta_p2p_comm {
 namespace hymeta {
 namespace {
 // Exchange buffers are never handed back to the driver while the process lives: a communicator that goes away parks
-// its buffer here and a later one of the same size on the same device takes it over.  (Address ranges that were mapped
-// uncached and then freed were seen to come back inside ordinary allocations of the process with chunks of later
-// kernels' output missing; a process makes a handful of communicators, so nothing is lost by keeping them.)
+// its buffer here and a later one on the same device that needs no more takes it over.  (After a series of create /
+// destroy cycles that freed uncached buffers, a later ordinary allocation of the process was seen with stretches of a
+// kernel's output missing.  The cause is NOT established: a late store of a peer into a buffer that had changed hands
+// would look the same as a stale uncached mapping.  Keeping the buffers, and the holder counts below, rule out the
+// first; a process makes a handful of communicators, so nothing is lost by keeping them.)
 struct ParkedBuffer {
   void* ptr;
   size_t bytes;
@@ -199,15 +225,55 @@ struct ParkedBuffer {
 std::mutex g_parked_mutex;
 std::vector<ParkedBuffer> g_parked;
 
-void* take_parked(size_t bytes, int device) {
+// Communicators of THIS process that still hold a pointer into a buffer (its owner, and every in-process peer that was
+// connected to it by pointer): a buffer is handed to a new communicator only once nobody holds it any more, so a kernel
+// of a communicator that is still alive can never write into a buffer that has changed hands.  (Peers in other
+// processes hold IPC mappings, which this count cannot see: their communicators are closed behind a barrier of the
+// group, vllm_hymeta/parallel.py.)
+struct Held {
+  void* ptr;
+  int holders;
+};
+std::vector<Held> g_held;
+
+void hold(void* ptr) {
   std::lock_guard<std::mutex> lock(g_parked_mutex);
-  for (size_t i = 0; i < g_parked.size(); ++i)
-    if (g_parked[i].bytes == bytes && g_parked[i].device == device) {
-      void* p = g_parked[i].ptr;
-      g_parked.erase(g_parked.begin() + static_cast<std::ptrdiff_t>(i));
-      return p;
+  for (Held& h : g_held)
+    if (h.ptr == ptr) {
+      ++h.holders;
+      return;
     }
-  return nullptr;
+  g_held.push_back({ptr, 1});
+}
+
+void release(void* ptr) {
+  std::lock_guard<std::mutex> lock(g_parked_mutex);
+  for (size_t i = 0; i < g_held.size(); ++i)
+    if (g_held[i].ptr == ptr) {
+      if (--g_held[i].holders <= 0) g_held.erase(g_held.begin() + static_cast<std::ptrdiff_t>(i));
+      return;
+    }
+}
+
+bool held_locked(const void* ptr) {
+  for (const Held& h : g_held)
+    if (h.ptr == ptr) return true;
+  return false;
+}
+
+// The smallest parked buffer of the device that is large enough and that no communicator of the process still holds.
+void* take_parked(size_t bytes, int device, size_t* got_bytes) {
+  std::lock_guard<std::mutex> lock(g_parked_mutex);
+  size_t best = g_parked.size();
+  for (size_t i = 0; i < g_parked.size(); ++i)
+    if (g_parked[i].bytes >= bytes && g_parked[i].device == device && !held_locked(g_parked[i].ptr) &&
+        (best == g_parked.size() || g_parked[i].bytes < g_parked[best].bytes))
+      best = i;
+  if (best == g_parked.size()) return nullptr;
+  void* p = g_parked[best].ptr;
+  *got_bytes = g_parked[best].bytes;
+  g_parked.erase(g_parked.begin() + static_cast<std::ptrdiff_t>(best));
+  return p;
 }
 
 void park(void* ptr, size_t bytes, int device) {
@@ -235,7 +301,8 @@ extern "C" int hymeta_p2p_create(int rank, int world, size_t max_message_bytes, 
     delete c;
     return HYMETA_ERR_WORKSPACE;
   }
-  buf = take_parked(c->buffer_bytes, c->device);
+  c->alloc_bytes = c->buffer_bytes;
+  buf = take_parked(c->buffer_bytes, c->device, &c->alloc_bytes);
   if (buf == nullptr && hipExtMallocWithFlags(&buf, c->buffer_bytes, hipDeviceMallocUncached) != hipSuccess) {
     (void)hipGetLastError();
     delete c;
@@ -245,7 +312,7 @@ extern "C" int hymeta_p2p_create(int rank, int world, size_t max_message_bytes, 
   if (hipMalloc(reinterpret_cast<void**>(&c->state), 4 * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(c->state, 0, 4 * sizeof(uint32_t)) != hipSuccess || hipMemset(buf, 0, kFlagBytes) != hipSuccess ||
       hipDeviceSynchronize() != hipSuccess) {
-    park(buf, c->buffer_bytes, c->device);
+    park(buf, c->alloc_bytes, c->device);
     if (c->state) (void)hipFree(c->state);
     delete c;
     return HYMETA_ERR_WORKSPACE;
@@ -254,13 +321,14 @@ extern "C" int hymeta_p2p_create(int rank, int world, size_t max_message_bytes, 
     hipIpcMemHandle_t h;
     if (hipIpcGetMemHandle(&h, buf) != hipSuccess) {
       (void)hipGetLastError();
-      park(buf, c->buffer_bytes, c->device);
+      park(buf, c->alloc_bytes, c->device);
       (void)hipFree(c->state);
       delete c;
       return HYMETA_ERR_UNSUPPORTED;
     }
     memcpy(ipc_handle, &h, sizeof(h));
   }
+  hold(buf);
   *comm = c;
   return HYMETA_OK;
 }
@@ -344,6 +412,8 @@ extern "C" int hymeta_p2p_connect_pointers(hymeta_p2p_comm* comm, void* const* b
       continue;
     }
     comm->peers[q] = static_cast<char*>(buffers[q]);
+    comm->by_pointer[q] = true;
+    hymeta::hold(buffers[q]);
   }
   comm->connected = true;
   return HYMETA_OK;
@@ -377,7 +447,7 @@ extern "C" int hymeta_p2p_all_reduce(hymeta_p2p_comm* comm, void* data_bf16, int
   a.spin_ticks = comm->spin_ticks;
   a.rank = comm->rank;
   a.stats_scale = stats_scale;
-  a.partials = hymeta_gemm_partials{};
+  a.partials = hymeta::make_args<hymeta_gemm_partials>();
   a.out = nullptr;
   return launch_exchange<0>(comm->world, a, stream);
 }
@@ -385,7 +455,7 @@ extern "C" int hymeta_p2p_all_reduce(hymeta_p2p_comm* comm, void* data_bf16, int
 extern "C" int hymeta_p2p_all_reduce_partials(hymeta_p2p_comm* comm, const hymeta_gemm_partials* partials, void* out_bf16,
                                               hymeta_stream_t stream) {
   using namespace hymeta;
-  if (comm == nullptr || partials == nullptr || out_bf16 == nullptr || !comm->connected) return HYMETA_ERR_INVALID_ARG;
+  if (comm == nullptr || !hymeta::args_ok(partials) || out_bf16 == nullptr || !comm->connected) return HYMETA_ERR_INVALID_ARG;
   const hymeta_gemm_partials& p = *partials;
   if (p.splits <= 0 || p.slabs == nullptr || p.M <= 0 || p.N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (p.is_int32 && (p.x_scale == nullptr || p.w_scale == nullptr)) return HYMETA_ERR_INVALID_ARG;
@@ -418,9 +488,15 @@ extern "C" int hymeta_p2p_timeouts(hymeta_p2p_comm* comm, uint32_t* count) {
 extern "C" int hymeta_p2p_destroy(hymeta_p2p_comm* comm) {
   if (comm == nullptr) return HYMETA_OK;
   (void)hipDeviceSynchronize();
-  for (int q = 0; q < comm->world; ++q)
+  for (int q = 0; q < comm->world; ++q) {
     if (comm->opened[q]) (void)hipIpcCloseMemHandle(comm->peers[q]);
-  if (comm->peers[comm->rank]) hymeta::park(comm->peers[comm->rank], comm->buffer_bytes, comm->device);
+    if (comm->by_pointer[q]) hymeta::release(comm->peers[q]);
+  }
+  if (comm->peers[comm->rank]) {
+    // parked at once, handed out again only when the in-process peers that point into it are gone too
+    hymeta::release(comm->peers[comm->rank]);
+    hymeta::park(comm->peers[comm->rank], comm->alloc_bytes, comm->device);
+  }
   if (comm->state) (void)hipFree(comm->state);
   delete comm;
   return HYMETA_OK;

@@ -503,12 +503,12 @@ int paged_decode_impl(hymeta_paged_decode_args a, hymeta_stream_t stream, bool u
 }  // namespace
 
 extern "C" int hymeta_meta_swa_paged_decode(const hymeta_paged_decode_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   return paged_decode_impl(*args, stream, false);
 }
 
 extern "C" int hymeta_meta_swa_paged_decode_static(const hymeta_paged_decode_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   return paged_decode_impl(*args, stream, true);
 }
 
@@ -564,7 +564,7 @@ int paged_decode_impl(hymeta_paged_decode_args a, hymeta_stream_t stream, bool u
       return HYMETA_ERR_UNSUPPORTED;
     if (head_groups > 1) {
       // several workgroups read the new row: write it with the stand-alone kernel first
-      hymeta_reshape_and_cache_args w = {};
+      hymeta_reshape_and_cache_args w = hymeta::make_args<hymeta_reshape_and_cache_args>();
       w.key = a.new_key; w.value = a.new_value;
       w.key_cache = const_cast<void*>(a.key_cache); w.value_cache = const_cast<void*>(a.value_cache);
       w.slot_mapping = a.slot_mapping;

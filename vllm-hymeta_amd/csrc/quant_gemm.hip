@@ -913,8 +913,8 @@ static int compute_units(void) {
 }
 
 static int gptq_gemm_impl(const hymeta_gptq_gemm_args* args, hymeta_stream_t stream, hymeta_gemm_partials* deferred) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
-  if (deferred != nullptr) *deferred = hymeta_gemm_partials{};
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
+  if (deferred != nullptr) *deferred = hymeta::make_args<hymeta_gemm_partials>();
   hymeta_gptq_gemm_args a = *args;
   if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;
@@ -1026,7 +1026,7 @@ extern "C" int hymeta_gptq_gemm(const hymeta_gptq_gemm_args* args, hymeta_stream
 
 extern "C" int hymeta_gptq_gemm_deferred(const hymeta_gptq_gemm_args* args, hymeta_gemm_partials* partials,
                                          hymeta_stream_t stream) {
-  if (partials == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(partials)) return HYMETA_ERR_INVALID_ARG;
   return gptq_gemm_impl(args, stream, partials);
 }
 
@@ -1072,8 +1072,8 @@ extern "C" size_t hymeta_w8a8_gemm_workspace_bytes(int32_t M, int32_t N, int32_t
 }
 
 static int w8a8_gemm_impl(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream, hymeta_gemm_partials* deferred) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
-  if (deferred != nullptr) *deferred = hymeta_gemm_partials{};
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
+  if (deferred != nullptr) *deferred = hymeta::make_args<hymeta_gemm_partials>();
   const hymeta_w8a8_gemm_args& a = *args;
   if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;
@@ -1146,7 +1146,7 @@ extern "C" int hymeta_w8a8_quantize(const void* x, int8_t* xq, float* x_scale, i
   if (!x || !xq || !x_scale) return HYMETA_ERR_INVALID_ARG;
   if (K % 8 != 0 || x_stride_m % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xq)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
-  hymeta_w8a8_gemm_args a = {};
+  hymeta_w8a8_gemm_args a = hymeta::make_args<hymeta_w8a8_gemm_args>();
   a.x = x, a.xq = xq, a.x_scale = x_scale, a.M = M, a.K = K, a.x_stride_m = x_stride_m;
   hipLaunchKernelGGL(w8a8_quant_kernel, dim3(M), dim3(256), 0, begin_launches(stream), a);
   return launch_status();
@@ -1174,7 +1174,7 @@ extern "C" int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream
 
 extern "C" int hymeta_w8a8_gemm_deferred(const hymeta_w8a8_gemm_args* args, hymeta_gemm_partials* partials,
                                          hymeta_stream_t stream) {
-  if (partials == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(partials)) return HYMETA_ERR_INVALID_ARG;
   return w8a8_gemm_impl(args, stream, partials);
 }
 
@@ -1183,7 +1183,7 @@ extern "C" int hymeta_w8a8_gemm_deferred(const hymeta_w8a8_gemm_args* args, hyme
 // HYMETA_ERR_UNSUPPORTED (the caller runs hymeta_w8a8_gemm + hymeta_silu_and_mul: same bits).
 extern "C" int hymeta_w8a8_gemm_silu_mul(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream) {
   using namespace hymeta;
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_w8a8_gemm_args& a = *args;
   if (a.M < 0 || a.K <= 0 || a.N <= 0 || a.bias != nullptr) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void reshape_and_cache_kernel(hymeta_reshape_a
 using namespace hymeta;
 
 extern "C" int hymeta_reshape_and_cache(const hymeta_reshape_and_cache_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   const hymeta_reshape_and_cache_args& a = *args;
   if (a.num_tokens < 0 || a.num_kv_heads <= 0 || a.head_dim <= 0 || a.block_size <= 0 || a.num_blocks < 0)
     return HYMETA_ERR_INVALID_ARG;

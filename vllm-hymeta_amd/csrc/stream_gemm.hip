@@ -450,7 +450,7 @@ template int stream_gemm_launch<true>(StreamArgs, const StreamPlan&, hipStream_t
 extern "C" int hymeta_gemm_partials_reduce(const hymeta_gemm_partials* partials, void* out, int64_t out_stride_m,
                                            hymeta_stream_t stream) {
   using namespace hymeta;
-  if (partials == nullptr || out == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(partials) || out == nullptr) return HYMETA_ERR_INVALID_ARG;
   const hymeta_gemm_partials& p = *partials;
   if (p.splits < 1 || p.M <= 0 || p.N <= 0 || p.N % 4 != 0 || !p.slabs) return HYMETA_ERR_INVALID_ARG;
   if (p.is_int32 && (!p.x_scale || !p.w_scale)) return HYMETA_ERR_INVALID_ARG;

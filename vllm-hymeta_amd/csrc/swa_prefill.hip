@@ -547,7 +547,7 @@ extern "C" size_t hymeta_meta_swa_prefill_workspace_bytes(int32_t out_rows, int3
 }
 
 extern "C" int hymeta_meta_swa_prefill(const hymeta_swa_prefill_args* args, hymeta_stream_t stream) {
-  if (args == nullptr) return HYMETA_ERR_INVALID_ARG;
+  if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   hymeta_swa_prefill_args a = *args;
   if (a.num_seqs < 0 || a.total_q < 0 || a.num_heads <= 0 || a.num_kv_heads <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.head_dim != kHeadDim) return HYMETA_ERR_UNSUPPORTED;

@@ -23,16 +23,28 @@ GATE_7B = 1
 GATE_70B_CLAMP = 2
 GATE_70B_LOWER_BOUND = 3
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ERR_SCRATCH_LIMIT = -5
 GEMM_TICKET_BYTES = 16384
 STATIC_SCRATCH_BYTES = 16 << 20
 
 _i32, _i64, _f32, _ptr, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+_SIZE = ("struct_size", C.c_uint32)
 
 
-class GlaDecodeArgs(C.Structure):
+class _Args(C.Structure):
+    """An argument struct of the library: the leading ``struct_size`` is filled in on construction with the size of
+    this declaration, which every entry point compares with its own."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if not self.struct_size:
+            self.struct_size = C.sizeof(type(self))
+
+
+class GlaDecodeArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("q", _ptr), ("k", _ptr), ("v", _ptr), ("g", _ptr), ("out", _ptr), ("state", _ptr),
         ("slot_idx", _ptr), ("lower_bound", _ptr), ("out_norm_weight", _ptr),
         ("batch", _i32), ("num_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
@@ -51,8 +63,9 @@ class GlaDecodeArgs(C.Structure):
     ]
 
 
-class GlaPrefillArgs(C.Structure):
+class GlaPrefillArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("q", _ptr), ("k", _ptr), ("v", _ptr), ("g", _ptr), ("out", _ptr), ("state", _ptr),
         ("slot_idx", _ptr), ("cu_seqlens", _ptr), ("context_lens", _ptr), ("meta_state", _ptr),
         ("lower_bound", _ptr), ("out_norm_weight", _ptr),
@@ -72,8 +85,9 @@ class GlaPrefillArgs(C.Structure):
     ]
 
 
-class ReshapeAndCacheArgs(C.Structure):
+class ReshapeAndCacheArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("key", _ptr), ("value", _ptr), ("key_cache", _ptr), ("value_cache", _ptr),
         ("slot_mapping", _ptr),
         ("num_tokens", _i32), ("num_kv_heads", _i32), ("head_dim", _i32), ("block_size", _i32),
@@ -85,8 +99,9 @@ class ReshapeAndCacheArgs(C.Structure):
     ]
 
 
-class PagedDecodeArgs(C.Structure):
+class PagedDecodeArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("q", _ptr), ("out", _ptr), ("key_cache", _ptr), ("value_cache", _ptr),
         ("block_tables", _ptr), ("cache_seqlens", _ptr), ("meta_key", _ptr), ("meta_value", _ptr),
         ("workspace", _ptr), ("workspace_bytes", _sz),
@@ -105,8 +120,9 @@ class PagedDecodeArgs(C.Structure):
     ]
 
 
-class SwaPrefillArgs(C.Structure):
+class SwaPrefillArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("q", _ptr), ("key", _ptr), ("value", _ptr), ("key_cache", _ptr), ("value_cache", _ptr),
         ("block_tables", _ptr), ("cu_seqlens_q", _ptr), ("cu_seqlens_k", _ptr), ("seq_lens_k", _ptr),
         ("meta_query", _ptr), ("meta_key", _ptr), ("meta_value", _ptr), ("out", _ptr),
@@ -126,8 +142,9 @@ class SwaPrefillArgs(C.Structure):
     ]
 
 
-class RopeArgs(C.Structure):
+class RopeArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("q", _ptr), ("k", _ptr), ("positions", _ptr), ("cos_sin_cache", _ptr),
         ("num_tokens", _i32), ("num_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
         ("rot_dim", _i32), ("max_position", _i32),
@@ -136,8 +153,9 @@ class RopeArgs(C.Structure):
     ]
 
 
-class CombineArgs(C.Structure):
+class CombineArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("o_attn", _ptr), ("o_lin", _ptr), ("weight1", _ptr), ("weight2", _ptr), ("stats", _ptr),
         ("out", _ptr),
         ("num_tokens", _i32), ("hidden_local", _i32),
@@ -146,8 +164,9 @@ class CombineArgs(C.Structure):
     ]
 
 
-class AddRmsNormArgs(C.Structure):
+class AddRmsNormArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("x", _ptr), ("residual", _ptr), ("weight", _ptr), ("out", _ptr),
         ("num_tokens", _i32), ("hidden", _i32),
         ("x_stride_t", _i64), ("residual_stride_t", _i64), ("out_stride_t", _i64),
@@ -155,16 +174,18 @@ class AddRmsNormArgs(C.Structure):
     ]
 
 
-class LowrankGateArgs(C.Structure):
+class LowrankGateArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("x", _ptr), ("w0", _ptr), ("w1", _ptr), ("bias", _ptr), ("out", _ptr),
         ("num_tokens", _i32), ("hidden", _i32), ("rank", _i32), ("out_features", _i32),
         ("x_stride_t", _i64), ("out_stride_t", _i64),
     ]
 
 
-class GptqGemmArgs(C.Structure):
+class GptqGemmArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("x", _ptr), ("qweight", _ptr), ("qzeros", _ptr), ("scales", _ptr), ("bias", _ptr), ("out", _ptr),
         ("workspace", _ptr), ("workspace_bytes", _sz),
         ("M", _i32), ("K", _i32), ("N", _i32), ("bits", _i32), ("group_size", _i32),
@@ -173,16 +194,18 @@ class GptqGemmArgs(C.Structure):
     ]
 
 
-class Bf16GemmArgs(C.Structure):
+class Bf16GemmArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("x", _ptr), ("weight", _ptr), ("bias", _ptr), ("out", _ptr), ("workspace", _ptr), ("workspace_bytes", _sz),
         ("M", _i32), ("K", _i32), ("N", _i32), ("split_k", _i32),
         ("x_stride_m", _i64), ("w_stride_n", _i64), ("out_stride_m", _i64),
     ]
 
 
-class W8A8GemmArgs(C.Structure):
+class W8A8GemmArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("x", _ptr), ("qweight", _ptr), ("w_scale", _ptr), ("bias", _ptr), ("out", _ptr),
         ("xq", _ptr), ("x_scale", _ptr),
         ("M", _i32), ("K", _i32), ("N", _i32),
@@ -191,15 +214,17 @@ class W8A8GemmArgs(C.Structure):
     ]
 
 
-class GemmPartials(C.Structure):
+class GemmPartials(_Args):
     _fields_ = [
+        _SIZE,
         ("slabs", _ptr), ("splits", _i32), ("is_int32", _i32), ("x_scale", _ptr), ("w_scale", _ptr), ("bias", _ptr),
         ("M", _i32), ("N", _i32),
     ]
 
 
-class MoeRouteArgs(C.Structure):
+class MoeRouteArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("router_logits", _ptr), ("topk_ids", _ptr), ("topk_weights", _ptr), ("counts", _ptr), ("cursors", _ptr),
         ("expert_offsets", _ptr), ("sorted_pair", _ptr), ("pair_pos", _ptr),
         ("num_tokens", _i32), ("num_experts", _i32), ("top_k", _i32), ("renormalize", _i32), ("logits_dtype", _i32),
@@ -208,8 +233,9 @@ class MoeRouteArgs(C.Structure):
     ]
 
 
-class MoeRouterArgs(C.Structure):
+class MoeRouterArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("x", _ptr), ("gate_weight", _ptr), ("logits_out", _ptr), ("topk_ids", _ptr), ("topk_weights", _ptr),
         ("expert_offsets", _ptr), ("sorted_pair", _ptr), ("pair_pos", _ptr), ("ticket", _ptr),
         ("num_tokens", _i32), ("num_experts", _i32), ("top_k", _i32), ("renormalize", _i32), ("hidden", _i32),
@@ -221,8 +247,9 @@ class MoeRouterArgs(C.Structure):
 MOE_ROUTER_MAX_TOKENS = 256
 
 
-class MoeGemmArgs(C.Structure):
+class MoeGemmArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("x", _ptr), ("weights", _ptr), ("out", _ptr), ("expert_offsets", _ptr), ("a_rows", _ptr), ("scale_rows", _ptr),
         ("row_scale", _ptr),
         ("a_rows_div", _i32), ("max_rows", _i32), ("K", _i32), ("N", _i32),
@@ -232,8 +259,9 @@ class MoeGemmArgs(C.Structure):
     ]
 
 
-class MoeCombineArgs(C.Structure):
+class MoeCombineArgs(_Args):
     _fields_ = [
+        _SIZE,
         ("y", _ptr), ("shared", _ptr), ("out", _ptr), ("pair_pos", _ptr), ("topk_weights", _ptr),
         ("num_tokens", _i32), ("hidden", _i32), ("top_k", _i32),
         ("y_stride_m", _i64), ("shared_stride_m", _i64), ("out_stride_m", _i64),
@@ -317,7 +345,10 @@ STRUCTS = {
     "hymeta_lowrank_gate_args": LowrankGateArgs,
     "hymeta_gptq_gemm_args": GptqGemmArgs,
     "hymeta_w8a8_gemm_args": W8A8GemmArgs,
+    "hymeta_bf16_gemm_args": Bf16GemmArgs,
+    "hymeta_gemm_partials": GemmPartials,
     "hymeta_moe_route_args": MoeRouteArgs,
+    "hymeta_moe_router_args": MoeRouterArgs,
     "hymeta_moe_gemm_args": MoeGemmArgs,
     "hymeta_moe_combine_args": MoeCombineArgs,
 }

@@ -30,7 +30,7 @@ from ..lm_head import LmHeadMixin, lm_head_logits
 from ..models.attention import bind_kv_cache, current_attn_metadata, forward_context, standalone_prefix
 from ..models.block import GLAswaBlock, HymetaRMSNorm
 from ..models.moe import HymetaMLP
-from ..parallel import shard_heads, tp_rank_and_size
+from ..parallel import exchange_enabled, raise_on_exchange_timeout, shard_heads, tp_rank_and_size
 from .gla_attention import GatedLinearAttention
 from .gla_cache import GLACacheManager, GLACacheParams
 from .window_attention import SlidingWindowAttention, rope_cos_sin_cache, swa_attention_layer
@@ -156,6 +156,10 @@ class GLAswaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
         self.kv_cache = [torch.tensor([]) for _ in config.attn_layers]
 
     def copy_inputs_before_cuda_graphs(self, input_buffers, **kwargs):
+        """The engine calls this on the host before every replay of a captured step: also the place where a timeout of
+        the tensor-parallel group's one-shot exchange in an earlier step becomes an error (``raise_on_exchange_timeout``)."""
+        if self.model.tp_group is not None and exchange_enabled(self.model.tp_group):
+            raise_on_exchange_timeout(self.model.tp_group)
         return self.model.gla_cache.copy_inputs_before_cuda_graphs(input_buffers, **kwargs)
 
     def get_seqlen_agnostic_capture_inputs(self, batch_size: int):
@@ -165,6 +169,9 @@ class GLAswaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
         return self.model.get_input_embeddings(input_ids)
 
     def forward(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None, **kwargs):
+        tp_group = self.model.tp_group
+        if tp_group is not None and exchange_enabled(tp_group) and not torch.cuda.is_current_stream_capturing():
+            raise_on_exchange_timeout(tp_group)      # eager steps: the check a replayed step gets from the hook above
         return self.model(input_ids, positions, intermediate_tensors, inputs_embeds, **kwargs)
 
     def compute_logits(self, hidden_states: torch.Tensor, sampling_metadata=None) -> torch.Tensor:

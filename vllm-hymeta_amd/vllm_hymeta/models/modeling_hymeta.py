@@ -31,7 +31,7 @@ from .._compat import HasInnerState, IntermediateTensors, IsHybrid, SupportsPP, 
 from ..linear import HymetaLinear, LinearColumns
 from ..lm_head import LmHeadMixin, lm_head_logits
 from ..model_for_7B.window_attention import rope_cos_sin_cache
-from ..parallel import shard_heads, tp_rank_and_size
+from ..parallel import exchange_enabled, raise_on_exchange_timeout, shard_heads, tp_rank_and_size
 from .attention import MetaAttention, bind_kv_cache, current_attn_metadata, forward_context, standalone_prefix
 from .block import HybridBlock, HymetaRMSNorm
 from .hybrid_attention import HLinearAttention, IntraHybridAttention, MetaFlashAttention
@@ -201,6 +201,10 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
         self.kv_cache = [torch.tensor([]) for _ in range(config.num_hidden_layers)]
 
     def copy_inputs_before_cuda_graphs(self, input_buffers, **kwargs):
+        """The engine calls this on the host before every replay of a captured step: also the place where a timeout of
+        the tensor-parallel group's one-shot exchange in an earlier step becomes an error (``raise_on_exchange_timeout``)."""
+        if self.model.tp_group is not None and exchange_enabled(self.model.tp_group):
+            raise_on_exchange_timeout(self.model.tp_group)
         return self.model.hymeta_cache.copy_inputs_before_cuda_graphs(input_buffers, **kwargs)
 
     def get_seqlen_agnostic_capture_inputs(self, batch_size: int):
@@ -210,6 +214,9 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
         return self.model.get_input_embeddings(input_ids)
 
     def forward(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None, **kwargs):
+        tp_group = self.model.tp_group
+        if tp_group is not None and exchange_enabled(tp_group) and not torch.cuda.is_current_stream_capturing():
+            raise_on_exchange_timeout(tp_group)      # eager steps: the check a replayed step gets from the hook above
         return self.model(input_ids, positions, intermediate_tensors, inputs_embeds, **kwargs)
 
     def compute_logits(self, hidden_states: torch.Tensor, sampling_metadata=None) -> torch.Tensor:

@@ -287,8 +287,44 @@ class InProcessGroup:
 _ONE_SHOT: dict = {}
 
 
+class OneShotTimeout(RuntimeError):
+    """A wait of the one-shot exchange for a peer ran into its limit: the step that contains it holds NaN rows."""
+
+
+def raise_on_exchange_timeout(group=None) -> None:
+    """The serving path's check of the one-shot exchange, made where the host waits for the device anyway (before a
+    step's graph is replayed, at the start of an eager forward): if a wait of ``group``'s exchange (of every group's
+    without one) has run into its limit since the last look, the exchange is switched off for that group -- after a
+    timeout the ranks' epochs may have drifted apart and it must not be used again; the group's collectives go back to
+    its backend -- and ``OneShotTimeout`` is raised.  The kernel has written NaN over the rows it could not sum, so the
+    step that missed a peer cannot have produced plausible tokens in the meantime.  The raise is local: under an engine
+    it ends the worker, which ends the job on every rank.  Costs one 4-byte read from the device per exchange."""
+    if isinstance(group, InProcessGroup):
+        n = group.comm.timeouts()
+        if n:
+            raise OneShotTimeout(f"one-shot all-reduce: {n} waits for a peer timed out on rank {group.rank} of {group.size}")
+        return
+    groups = [group] if group is not None else list(_ONE_SHOT)
+    for g in groups:
+        comm = _ONE_SHOT.get(g)
+        if comm is None:
+            continue
+        n = comm.timeouts()
+        if n:
+            comm.group = None          # no barrier on the way out: the peers may be the ones that are gone
+            _ONE_SHOT.pop(g, None)
+            comm.close()
+            raise OneShotTimeout(f"one-shot all-reduce: {n} waits for a peer timed out on rank {comm.rank} of {comm.world}; "
+                                 "the group falls back to its backend")
+
+
 def _exchange_of(group) -> Optional[OneShotAllReduce]:
     return group.comm if isinstance(group, InProcessGroup) else _ONE_SHOT.get(group)
+
+
+def exchange_enabled(group) -> bool:
+    """Whether ``group``'s small all-reduces go through a one-shot exchange."""
+    return _exchange_of(group) is not None
 
 
 def enable_one_shot_all_reduce(group: dist.ProcessGroup, device: torch.device, max_bytes: int = ONE_SHOT_MAX_BYTES) -> OneShotAllReduce:
