@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Check and time the 4-bit GPTQ linear at the 7B shapes on cold weights (needs a GPU).  Env ROWS, and the library's
-HYMETA_GPTQ_STREAM_FROM (rows from which the weight-streaming kernel runs; 1000 = the older kernels)."""
+HYMETA_GPTQ_STREAM_FROM (rows from which the weight-streaming kernel runs; 1000 = the older kernels); SHAPES (a comma
+list of qkv, o, gate_up, down) keeps some of the matrices."""
 import os
 import sys
 
@@ -14,6 +15,8 @@ from vllm_hymeta import hip_ops  # noqa: E402
 
 dev = torch.device("cuda")
 SHAPES = [("qkv", 3584, 4608), ("o", 3584, 3584), ("gate_up", 3584, 37888), ("down", 18944, 3584)]
+if os.environ.get("SHAPES"):
+    SHAPES = [sh for sh in SHAPES if sh[0] in os.environ["SHAPES"].split(",")]
 ROWS = [int(r) for r in os.environ.get("ROWS", "1,16,64").split(",")]
 G = 128
 for M in ROWS:
