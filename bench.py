@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--rccl-only", action="store_true",
                     help="tensor-parallel mode: keep every all-reduce on RCCL (default: the small ones take the one-shot "
                          "exchange over peer-mapped buffers when its self-check passes on every rank)")
+    ap.add_argument("--ep", action="store_true",
+                    help="tensor-parallel mode: expert parallelism for the mixture layers (the reference's --enable-expert-parallel): "
+                         "whole experts dealt to the ranks of a TP group instead of every expert cut along its intermediate size")
     ap.add_argument("--force-tp", action="store_true",
                     help="run the tensor-parallel mode with whatever WORLD_SIZE the launcher set, 1 included (a one-GPU rehearsal "
                          "of the multi-GPU step: the collectives run over a one-rank group)")
@@ -232,9 +235,10 @@ class DecodeRunner:
                 hip_ops.argmax_rows(self.model.compute_logits(h), out=self.input_ids)
         return h
 
-    def capture(self, before_capture=None):
-        """``before_capture``: called after the eager warm-up, right before recording starts (the tensor-parallel mode
-        waits there until the process group's watchdog holds no eager work)."""
+    def capture(self, before_capture=None, capture_error_mode="global"):
+        """``before_capture``: called after the eager warm-up, right before recording starts; ``capture_error_mode``: as
+        ``torch.cuda.graph`` takes it (the tensor-parallel mode records in "thread_local" mode: the process group's
+        watchdog thread makes runtime calls of its own while a capture is open)."""
         for _ in range(2):                       # sizes every workspace, loads every kernel
             self.eager_step()
         torch.cuda.synchronize()
@@ -244,7 +248,7 @@ class DecodeRunner:
             self.eager_step()
             if before_capture is not None:
                 before_capture()
-            with torch.cuda.graph(self.graph, stream=side):
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode=capture_error_mode):
                 self.out = self.eager_step()
         torch.cuda.synchronize()
 

@@ -20,7 +20,6 @@ from __future__ import annotations
 import json
 import os
 import sys
-import time
 
 import torch
 import torch.distributed as dist
@@ -95,12 +94,12 @@ def synthetic_checkpoint_70b(cfg, dev, quant, seed=0):
             yield from mlp(p + "shared_mlp", cfg.shared_intermediate_size)
 
 
-def build_model_70b(dev, quant, max_num_seqs, tp_group, layers):
+def build_model_70b(dev, quant, max_num_seqs, tp_group, layers, expert_parallel=False):
     from vllm_hymeta.models.modeling_hymeta import HymetaForCausalLM
 
     cfg = config_70b(layers)
     q = {"bits": 4, "group_size": B1.GROUP, "zero_offset": 1} if quant == "gptq4" else None
-    model = HymetaForCausalLM(cfg, max_num_seqs=max_num_seqs, quant=q, tp_group=tp_group, device=dev)
+    model = HymetaForCausalLM(cfg, max_num_seqs=max_num_seqs, quant=q, tp_group=tp_group, device=dev, expert_parallel=expert_parallel)
     model.load_weights(synthetic_checkpoint_70b(cfg, dev, quant))
     return model, cfg
 
@@ -123,6 +122,7 @@ class VocabParallelGreedy:
         self.weight = model._lm_head[self.lo:self.lo + V // tp].contiguous()
         model._lm_head = self.weight                  # the rank keeps only its rows
         self.group, self.tp = group, tp
+        self.rank_in_group = rank_in_group % n
         self.exchange = tp > 1 or parallel.SINGLE_RANK_COLLECTIVES
         self.pair = torch.zeros(batch, 2, dtype=torch.float32, device=dev)
         self.flat = torch.zeros(n * batch, 2, dtype=torch.float32, device=dev)     # the ranks' pairs, rank-major
@@ -135,10 +135,12 @@ class VocabParallelGreedy:
 
         logits = lm_head_logits(hidden, self.weight)
         idx = hip_ops.argmax_rows(logits) if logits.is_cuda else logits.argmax(-1)     # (CPU: the gloo test of the exchange)
+        from vllm_hymeta import parallel
+
         self.pair[:, 0] = logits.gather(1, idx.unsqueeze(1)).squeeze(1)
         self.pair[:, 1] = (idx + self.lo).float()      # indices below 2^24: exact in fp32
-        if self.exchange:
-            dist.all_gather_into_tensor(self.flat, self.pair, group=self.group)
+        if self.exchange:      # through the group's one-shot exchange when it has one: a captured step then holds no backend call
+            parallel.all_gather_rows(self.pair, self.all, self.group, self.rank_in_group)
         else:
             self.all[0].copy_(self.pair)
         best = self.all[:, :, 0].argmax(0)
@@ -146,16 +148,18 @@ class VocabParallelGreedy:
 
 
 def experts_hit(model, runner):
-    """Distinct experts the batch routes to, per mixture layer (one eager step with a hook on each mixture: the host
-    read stays outside the timed region)."""
+    """Distinct experts the batch routes to, per mixture layer -- with expert parallelism: those among them that this
+    rank owns (one eager step with a hook on each mixture: the host read stays outside the timed region)."""
     from vllm_hymeta.models.moe import HymetaMoE
 
     hit, hooks = [], []
 
     def pre(mod, inputs):
         x = inputs[0].reshape(-1, inputs[0].shape[-1])
-        top = torch.nn.functional.linear(x, mod.gate_weight).float().topk(mod.top_k, dim=-1).indices
-        hit.append(int(top.unique().numel()))
+        top = torch.nn.functional.linear(x, mod.gate_weight).float().topk(mod.top_k, dim=-1).indices.unique()
+        if mod.local_experts is not None:
+            top = top[(top >= mod.local_experts[0]) & (top < mod.local_experts[1])]
+        hit.append(int(top.numel()))
 
     for mod in model.modules():
         if isinstance(mod, HymetaMoE):
@@ -167,10 +171,11 @@ def experts_hit(model, runner):
     return hit
 
 
-def step_bytes_70b(cfg, quant, tp, batch, ctx, hit):
+def step_bytes_70b(cfg, quant, tp, batch, ctx, hit, expert_parallel=False):
     """Algorithmic HBM bytes of one step of ONE rank: every linear's weight share once, the routed experts' shares the
-    batch touches, the visible K/V rows (window + meta, or the whole sequence on the 4 full-attention layers) of this
-    rank's kv-heads, the GLA states of its heads read + written."""
+    batch touches (a 1 / tp slice of every expert that is hit; with expert parallelism the whole of those the rank owns:
+    ``hit`` then counts the rank's own), the visible K/V rows (window + meta, or the whole sequence on the 4
+    full-attention layers) of this rank's kv-heads, the GLA states of its heads read + written."""
     wb = B1.WBYTES[quant]
     L = cfg.num_hidden_layers
     HIDDEN, INTER, H, HKV, D = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -179,7 +184,7 @@ def step_bytes_70b(cfg, quant, tp, batch, ctx, hit):
     moe_layers = [i for i in range(L) if cfg.num_layer_experts[i] > 1]
     dense_w = (L - len(moe_layers)) * 3 * INTER * HIDDEN * wb / tp
     shared_w = len(moe_layers) * 3 * cfg.shared_intermediate_size * HIDDEN * wb / tp
-    expert_w = sum(hit) * 3 * INTER * HIDDEN * 2.0 / tp
+    expert_w = sum(hit) * 3 * INTER * HIDDEN * 2.0 / (1 if expert_parallel else tp)
     kvh, heads = max(1, HKV // tp), H // tp
     full = [i for i in range(L) if i in FULL_LAYERS]
     kv = batch * 2 * kvh * D * 2 * ((L - len(full)) * (min(ctx + 1, cfg.sliding_window) + M_META) + len(full) * (ctx + 1 + M_META))
@@ -191,12 +196,15 @@ def step_bytes_70b(cfg, quant, tp, batch, ctx, hit):
 
 
 def settle():
-    """Let the process group's watchdog thread retire every eager collective before a stream capture starts.  The
-    watchdog polls the end events of the eager work it still holds; a poll that lands while the group's communication
-    stream is being captured is refused by HIP (hipErrorCapturedEvent) and takes the process down.  The watchdog wakes
-    every 100 ms; the event cache is switched off in ``tp_main`` so that eager work never holds an event a capture used."""
+    """Called right before a stream capture.  What used to take the process down here: the process group's watchdog
+    thread polls the end events of the eager collectives it still holds, those events sit on the group's communication
+    stream, and a poll of one while that stream is being captured is refused by HIP (hipErrorCapturedEvent).  The cause is
+    removed in ``tp_main``, not waited out: collectives recorded into a graph go over a process group of their own
+    (``parallel.set_capture_group``) whose stream never holds an eager event, the capture runs in thread-local error mode
+    (another thread's runtime calls are not the capture's business), the event cache is off so that eager work never
+    holds an event a capture used, and with the one-shot exchange a captured step holds no backend call at all.  Left
+    here: the device is idle when recording starts."""
     torch.cuda.synchronize()
-    time.sleep(1.0)
 
 
 def note(rank, msg):
@@ -210,7 +218,7 @@ def collectives_alone(cfg, batch, group, dev, reps=5):
     with no compute between them."""
     stats = torch.zeros(batch, 2, dtype=torch.float32, device=dev)
     y = torch.zeros(batch, cfg.hidden_size, dtype=torch.bfloat16, device=dev)
-    gathered = torch.zeros(dist.get_world_size(group) * batch, 2, dtype=torch.float32, device=dev)
+    gathered = torch.zeros(dist.get_world_size(group), batch, 2, dtype=torch.float32, device=dev)
 
     from vllm_hymeta import parallel
 
@@ -219,14 +227,14 @@ def collectives_alone(cfg, batch, group, dev, reps=5):
             parallel.all_reduce_variance(stats, group)      # the calls the layers make: one-shot exchange or RCCL
             parallel.all_reduce_sum(y, group)
             parallel.all_reduce_sum(y, group)
-        dist.all_gather_into_tensor(gathered, stats, group=group)
+        parallel.all_gather_rows(stats, gathered, group, dist.get_rank(group))
 
     run()
     graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
     with torch.cuda.stream(side):
         run()
         settle()
-        with torch.cuda.graph(graph, stream=side):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
             run()
     graph.replay()
     torch.cuda.synchronize()
@@ -244,6 +252,16 @@ def tp_layout(world):
     heads / 4 kv-heads: the reference's sharding rules admit 1, 2 and 4)."""
     tp = 4 if world % 4 == 0 else 2 if world % 2 == 0 else 1
     return tp, world // tp
+
+
+def tp_plan(rank, world):
+    """Where ``rank`` of a job of ``world`` processes stands: the tensor-parallel degree and replica count
+    (``tp_layout``), its replica and its rank inside that replica's group, the ranks of every group (every process
+    creates every group, in this order), and the seed of its replica's batch (the ranks of a group decode the same
+    sequences; replicas decode different ones)."""
+    tp, replicas = tp_layout(world)
+    return {"tp": tp, "replicas": replicas, "replica": rank // tp, "rank_in_group": rank % tp,
+            "group_ranks": [list(range(r * tp, (r + 1) * tp)) for r in range(replicas)], "batch_seed": rank // tp}
 
 
 class EagerRunner:
@@ -270,9 +288,16 @@ def tp_main(args):
     dist.init_process_group(backend=args.dist_backend, device_id=dev if args.dist_backend == "nccl" else None)
     from vllm_hymeta import hip_ops, parallel  # noqa: F401  (fails loudly if the HIP library is missing)
 
-    tp, replicas = tp_layout(world)
-    groups = [dist.new_group(list(range(r * tp, (r + 1) * tp))) for r in range(replicas)]   # every rank creates every group
-    tp_group = groups[rank // tp]
+    plan = tp_plan(rank, world)
+    tp, replicas = plan["tp"], plan["replicas"]
+    groups = [dist.new_group(ranks) for ranks in plan["group_ranks"]]   # every rank creates every group
+    tp_group = groups[plan["replica"]]
+    # the collectives of captured steps go over a second group of the same ranks (see settle()); one eager call now, long
+    # before the first capture, builds its communicator
+    capture_groups = [dist.new_group(ranks) for ranks in plan["group_ranks"]]
+    if args.dist_backend == "nccl":
+        dist.all_reduce(torch.zeros(1, device=dev), group=capture_groups[plan["replica"]])
+        parallel.set_capture_group(tp_group, capture_groups[plan["replica"]])
     if tp == 1:
         parallel.SINGLE_RANK_COLLECTIVES = True      # one-GPU rehearsal: keep the collectives in the step
     shard_tp = tp
@@ -297,9 +322,9 @@ def tp_main(args):
 
     batch, ctx, total = args.batch, args.ctx if args.ctx_given else 32768, args.warmup + args.steps
     note(rank, f"{world} ranks: tp{tp} x {replicas}; building the model")
-    model, cfg = build_model_70b(dev, args.quant, batch, tp_group, args.tp_layers)
-    runner = B1.DecodeRunner(model, batch, ctx, total + 8, dev, seed=rank // tp)
-    runner.sampler = VocabParallelGreedy(model, tp_group, rank % tp, shard_tp, batch, dev, ranks_in_exchange=tp)
+    model, cfg = build_model_70b(dev, args.quant, batch, tp_group, args.tp_layers, expert_parallel=args.ep)
+    runner = B1.DecodeRunner(model, batch, ctx, total + 8, dev, seed=plan["batch_seed"])
+    runner.sampler = VocabParallelGreedy(model, tp_group, plan["rank_in_group"], shard_tp, batch, dev, ranks_in_exchange=tp)
     hit = experts_hit(model, runner)
     note(rank, f"model built ({torch.cuda.memory_allocated(dev) / 2 ** 30:.1f} GiB allocated), experts hit {hit}")
     if args.tp_eager:
@@ -307,7 +332,7 @@ def tp_main(args):
             runner.eager_step()
         stepper = EagerRunner(runner)
     else:
-        runner.capture(before_capture=settle)
+        runner.capture(before_capture=settle, capture_error_mode="thread_local")
         stepper = runner
     torch.cuda.synchronize()
     note(rank, "step ready; timing")
@@ -326,7 +351,7 @@ def tp_main(args):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     one_shot_timeouts = int(t[0])
 
-    nbytes, parts = step_bytes_70b(cfg, args.quant, shard_tp, batch, ctx, hit)
+    nbytes, parts = step_bytes_70b(cfg, args.quant, shard_tp, batch, ctx, hit, expert_parallel=args.ep and shard_tp > 1)
     achieved = nbytes / (gpu_ms * 1e-3) / 1e9
     line = {
         "metric": "decode output tokens/s (whole model step)",
@@ -354,7 +379,8 @@ def tp_main(args):
             "ctx": ctx,
             "linears": args.quant,
             "layers": cfg.num_hidden_layers,
-            "parallelism": f"tp{tp}" + (f" x {replicas} replicas" if replicas > 1 else "") +
+            "parallelism": f"tp{tp}" + (" + expert parallelism (whole experts per rank, one all-reduce)" if args.ep and shard_tp > 1 else "") +
+                           (f" x {replicas} replicas" if replicas > 1 else "") +
                            (f"; REHEARSAL of rank 0's shard of tp{shard_tp} on one GPU (one rank's kernels at the shard shapes, "
                             "collectives as one-rank exchanges): not a throughput of the job" if shard_tp != tp else ""),
             "rccl_ranks": world,
@@ -387,5 +413,6 @@ def tp_main(args):
     if rank == 0:
         print(json.dumps(line), flush=True)
     parallel.disable_one_shot_all_reduce(tp_group)
+    parallel.set_capture_group(tp_group, None)
     dist.barrier()
     dist.destroy_process_group()

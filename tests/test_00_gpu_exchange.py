@@ -213,8 +213,12 @@ def test_exchange_takes_a_k_sliced_linear_straight_from_its_partial_sums(kind):
 D = 128
 
 
-def test_two_tensor_parallel_ranks_on_one_gpu_equal_the_unsharded_model():
-    """Configs with tensor parallelism, collectives included, on one GPU: two ranks of HymetaForCausalLM live in one
+@pytest.mark.parametrize("expert_parallel", [False, True])
+def test_two_tensor_parallel_ranks_on_one_gpu_equal_the_unsharded_model(expert_parallel):
+    """``expert_parallel``: the routed experts dealt whole to the ranks (2 of the 4 each, only those held) instead of
+    every expert cut along its intermediate size -- the reference's ``--enable-expert-parallel``; either way the layer's
+    one all-reduce sums the ranks.
+    Configs with tensor parallelism, collectives included, on one GPU: two ranks of HymetaForCausalLM live in one
     process, each in its own thread on its own stream, with the layers' all-reduces (branch variances, out_proj, dense
     MLP, expert mixture + shared expert) running through the one-shot exchange between them.  Both ranks cut their
     shards from the same checkpoint, prefill two prompts and decode one token.  The ranks' hidden states are bit-identical
@@ -250,8 +254,16 @@ def test_two_tensor_parallel_ranks_on_one_gpu_equal_the_unsharded_model():
     def run_rank(group, out):
         """One rank: build, load, prefill, decode.  ``group`` None = the unsharded model."""
         kvh = cfg.num_key_value_heads // (group.size if group is not None else 1)
-        model = HymetaForCausalLM(cfg, max_num_seqs=4, tp_group=group, device=dev)
+        model = HymetaForCausalLM(cfg, max_num_seqs=4, tp_group=group, device=dev, expert_parallel=expert_parallel)
         model.load_weights(ckpt.items())
+        if group is not None:
+            from vllm_hymeta.models.moe import HymetaMoE
+            moes = [m for m in model.modules() if isinstance(m, HymetaMoE)]
+            assert moes
+            for m in moes:      # a rank holds two whole experts, or a half of each of the four
+                assert tuple(m.w13.shape) == ((2, 2 * cfg.intermediate_size, cfg.hidden_size) if expert_parallel
+                                              else (4, cfg.intermediate_size, cfg.hidden_size))
+                assert m.local_experts == ((2 * group.rank, 2 * group.rank + 2) if expert_parallel else None)
         kv_caches = [torch.zeros(2, 2 * per_seq + 1, bs, kvh, D, dtype=torch.bfloat16, device=dev)
                      for _ in range(cfg.num_hidden_layers)]
         run = dict(request_ids_to_seq_ids={"a": [0], "b": [1]}, finished_requests_ids=[])

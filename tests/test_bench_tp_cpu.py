@@ -19,6 +19,36 @@ def test_tp_layout():
     assert [tp_layout(n) for n in (1, 2, 4, 8, 6)] == [(1, 1), (2, 1), (4, 1), (4, 2), (2, 3)]
 
 
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_rank_bookkeeping_of_the_tensor_parallel_bench(world):
+    """What every rank of a job of N processes derives for itself agrees over the job: the groups partition the ranks
+    in order, a rank is a member of the group it picks at the place it claims, the ranks of a group share their batch
+    (replicas do not), their shares of the published vocabulary are whole multiples of 64 rows that tile it, and the
+    byte model of the step is the same on every rank of a group, with and without expert parallelism."""
+    import bench_tp
+    from bench import VOCAB
+
+    plans = [bench_tp.tp_plan(r, world) for r in range(world)]
+    tp, replicas = bench_tp.tp_layout(world)
+    assert tp * replicas == world and tp in (1, 2, 4)       # 28 query heads / 4 kv-heads: never 8
+    assert all(p["group_ranks"] == plans[0]["group_ranks"] for p in plans)      # every rank creates the same groups in the same order
+    assert sorted(sum(plans[0]["group_ranks"], [])) == list(range(world))
+    for r, p in enumerate(plans):
+        mine = p["group_ranks"][p["replica"]]
+        assert mine[p["rank_in_group"]] == r and len(mine) == tp
+        assert all(plans[q]["batch_seed"] == p["batch_seed"] for q in mine)
+    assert len({p["batch_seed"] for p in plans}) == replicas
+    assert VOCAB % (64 * tp) == 0
+    rows = [(p["rank_in_group"] * (VOCAB // tp), (p["rank_in_group"] + 1) * (VOCAB // tp)) for p in plans if p["replica"] == 0]
+    assert rows[0][0] == 0 and rows[-1][1] == VOCAB and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    cfg = bench_tp.config_70b()
+    n_mix = sum(1 for n in cfg.num_layer_experts if n > 1)
+    total, parts = bench_tp.step_bytes_70b(cfg, "bf16", tp, 64, 32768, [16] * n_mix)
+    total_ep, parts_ep = bench_tp.step_bytes_70b(cfg, "bf16", tp, 64, 32768, [16 // tp] * n_mix, expert_parallel=tp > 1)
+    assert parts_ep["routed_experts"] == parts["routed_experts"]      # every expert hit: a 1 / tp slice of each = 16 / tp whole ones
+    assert total_ep == total
+
+
 def test_step_bytes_of_the_published_geometry():
     from bench_tp import config_70b, step_bytes_70b
     cfg = config_70b()

@@ -156,6 +156,39 @@ def test_moe_expert_parallel_shares_sum_to_the_whole():
     assert_bf16_ulp((parts[0] + parts[1]).to(torch.bfloat16), full, "EP shares summed vs single rank", ulps=1)
     with pytest.raises(ValueError):
         expert_range(16, 3, 0)
+    # a rank that holds ONLY its experts (what an expert-parallel rank of the model keeps): the same bits as its share
+    # computed from the full tensors
+    for r in range(2):
+        lo, hi = expert_range(E, 2, r)
+        whole = hip_ops.moe_forward(x.cuda(), logits.cuda(), w13.cuda(), w2.cuda(), local_experts=(lo, hi))
+        held = hip_ops.moe_forward(x.cuda(), logits.cuda(), w13[lo:hi].contiguous().cuda(), w2[lo:hi].contiguous().cuda(),
+                                   local_experts=(lo, hi))
+        torch.cuda.synchronize()
+        assert torch.equal(whole, held)
+    with pytest.raises(ValueError):      # neither all experts nor exactly the local ones
+        hip_ops.moe_forward(x.cuda(), logits.cuda(), w13[:5].contiguous().cuda(), w2[:5].contiguous().cuda(), local_experts=(0, 8))
+
+
+@pytest.mark.parametrize("T", [8, 300])
+def test_a_row_of_nan_logits_gives_a_nan_row_and_nothing_else(T):
+    """Both routing kernels (router inside the launch up to 256 tokens; separate launches above): a token whose logits are
+    NaN picks a valid expert with a NaN weight -- its output row is NaN, every other row is what it is without that
+    token, and no counter is indexed out of range."""
+    from vllm_hymeta import hip_ops
+
+    H, inter, E = 256, 128, 16
+    x, gate_w, w13, w2, _ = _problem(17, T, H, inter, E)
+    bad = 3
+    xn = x.clone()
+    xn[bad] = float("nan")
+    xd, gw, a, b = xn.cuda(), gate_w.cuda(), w13.cuda(), w2.cuda()
+    shared = randn_bf16(gen(18), T, H).cuda()
+    out = hip_ops.moe_forward(xd, None, a, b, gate_weight=gw, shared=shared)
+    ref = hip_ops.moe_forward(x.cuda(), None, a, b, gate_weight=gw, shared=shared)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out[bad]).all())
+    keep = [i for i in range(T) if i != bad]
+    assert_bf16_ulp(out[keep], ref[keep], "rows beside the NaN row", ulps=1)
 
 
 def test_moe_tiled_regime_expert_parallel_share():

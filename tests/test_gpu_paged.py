@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from _util import assert_bf16_close, gen, randn_bf16
+from _util import assert_bf16_close, assert_bf16_ulp, gen, randn_bf16
 
 pytestmark = pytest.mark.gpu
 
@@ -254,3 +254,63 @@ def test_paged_decode_all_kv_heads_fused_kv_write(splits, monkeypatch):
     assert torch.equal(k_a.cpu().view(torch.int16), k_b.cpu().view(torch.int16))
     assert torch.equal(v_a.cpu().view(torch.int16), v_b.cpu().view(torch.int16))
     assert torch.equal(out_a.cpu().view(torch.int16), out_b.cpu().view(torch.int16))
+
+
+def test_paged_decode_through_a_window_trimmed_block_table():
+    """What the engine hands the backend for decodes under a sliding window (the V0 runner's lengths clamped to the
+    block-aligned window plus the last block's fill, and the builder's table cut to the window's last blocks,
+    reference vllm_hymeta/attention/meta_attention.py:479-485; builder here: MetaAttentionMetadataBuilder._add_seq_group):
+    the kernel reads the same physical rows through the trimmed table as through the whole one, the NaNs that fill every
+    row outside the trimmed view never show, and the result is the oracle's for the untrimmed sequence."""
+    import types
+
+    from oracle import meta_swa_paged_decode_ref
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta.attention.meta_attention import MetaAttentionMetadataBuilder
+
+    H, Hkv, bs, M, window = 7, 1, 16, 32, 32
+    window_blocks = (window + bs - 1) // bs
+    seq_lens = [70, 64, 33, 20, 129]                 # last block part full / full; one sequence shorter than the window
+    kc, vc, bt = _paged_problem(41, seq_lens, Hkv, bs)
+    g_ = gen(42)
+    q = randn_bf16(g_, len(seq_lens), H, D)
+    k2, v2 = randn_bf16(g_, M, Hkv, D), randn_bf16(g_, M, Hkv, D)
+    ref = meta_swa_paged_decode_ref(q, kc, vc, seq_lens, bt, k2, v2, window - 1)
+
+    # the engine's view: lengths clamped, and how many trailing blocks of each table the builder keeps
+    inter, clamped = [], []
+    for i, L in enumerate(seq_lens):
+        suff = L % bs
+        cur = min(L, window_blocks * bs + suff)
+        nblk = window_blocks + (1 if suff > 0 else 0)
+        table = bt[i, : (L + bs - 1) // bs].tolist()
+        inter.append(types.SimpleNamespace(
+            is_prompt=False, block_tables={i: table}, seq_ids=[i], input_tokens=[[0]], orig_seq_lens=[L], seq_lens=[cur],
+            query_lens=[1], context_lens=[L - 1], curr_sliding_window_blocks=[nblk], prefix_cache_hit=False,
+            multi_modal_placeholder_maps=None))
+        clamped.append(cur)
+    runner = types.SimpleNamespace(device=torch.device("cuda"), pin_memory=False)
+    ib = types.SimpleNamespace(runner=runner, sliding_window=window, block_size=bs, chunked_prefill_enabled=False,
+                               inter_data_list=inter)
+    b = MetaAttentionMetadataBuilder(ib)
+    b.prepare()
+    md = b.build(clamped, [1] * len(seq_lens), -1, len(seq_lens))
+    assert md.seq_lens_tensor.tolist() == clamped and md.block_tables.shape[1] == window_blocks + 1
+    for i, L in enumerate(seq_lens):                  # the new token's slot still comes from the whole table
+        assert int(md.slot_mapping[i]) == int(bt[i, (L - 1) // bs]) * bs + (L - 1) % bs
+
+    # poison every cache row the trimmed view does not reach
+    reach = torch.zeros(kc.shape[0], bs, dtype=torch.bool)
+    for i, cur in enumerate(clamped):
+        for p in range(cur):
+            reach[int(md.block_tables[i, p // bs]), p % bs] = True
+    kc_bad, vc_bad = kc.clone(), vc.clone()
+    kc_bad[~reach] = float("nan")
+    vc_bad[~reach] = float("nan")
+    out = hip_ops.meta_swa_paged_decode(q.cuda(), kc_bad.cuda(), vc_bad.cuda(), md.seq_lens_tensor, md.block_tables, k2.cuda(), v2.cuda(),
+                                        window_left=window - 1)
+    whole = hip_ops.meta_swa_paged_decode(q.cuda(), kc.cuda(), vc.cuda(), torch.tensor(seq_lens, dtype=torch.int32).cuda(), bt.cuda(),
+                                          k2.cuda(), v2.cuda(), window_left=window - 1)
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), ref, "paged decode through the trimmed table")
+    assert_bf16_ulp(out.cpu(), whole.cpu(), "trimmed against whole table", ulps=1)

@@ -67,12 +67,47 @@ def test_decodes_before_prefills_are_refused_and_reordered():
     assert b.reorder_batch(batch, sched) is False
 
 
+def test_a_new_prompt_of_one_token_is_a_prefill():
+    """Scheduled for one token with nothing computed yet: a prompt (the reference's V0 builder goes by is_prompt), so
+    that the prefill pass resets its recurrent-state slot; a decode has tokens behind it."""
+    assert split_prefills_and_decodes([1, 1], [0, 7]) == 1
+    with pytest.raises(ValueError):
+        split_prefills_and_decodes([1, 1], [7, 0])            # the new prompt behind a decode: reorder first
+    common, _ = _common([1, 1, 1], [1, 30, 9])                  # request 0: a one-token prompt
+    md = MetaAttentionMetadataBuilderV1(SimpleNamespace(block_size=16)).build(0, common)
+    assert (md.num_prefills, md.num_prefill_tokens, md.num_decode_tokens) == (1, 1, 2)
+    assert md.prefill_metadata.context_lens_tensor.tolist() == [0] and md.decode_metadata.seq_lens_tensor.tolist() == [30, 9]
+
+    class Batch:
+        def __init__(self, ids, computed):
+            self.req_ids, self.num_computed_tokens_cpu = list(ids), list(computed)
+
+        def swap_states(self, i, j):
+            self.req_ids[i], self.req_ids[j] = self.req_ids[j], self.req_ids[i]
+            self.num_computed_tokens_cpu[i], self.num_computed_tokens_cpu[j] = self.num_computed_tokens_cpu[j], self.num_computed_tokens_cpu[i]
+
+    sched = SimpleNamespace(num_scheduled_tokens={"d0": 1, "new": 1, "d1": 1})
+    batch = Batch(["d0", "new", "d1"], [12, 0, 5])
+    assert MetaAttentionMetadataBuilderV1().reorder_batch(batch, sched) is True
+    assert batch.req_ids == ["new", "d0", "d1"]
+
+
 def test_capture_metadata_is_pure_decode_over_the_whole_table():
     common, _ = _common([1, 1, 1], [17, 90, 3])
     b = MetaAttentionMetadataBuilderV1(SimpleNamespace(block_size=16))
     md = b.build_for_cudagraph_capture(common)
     assert md.use_cuda_graph and md.num_decode_tokens == 3 and md.seq_lens is None
     assert md.max_decode_seq_len == 8 * 16
+    # what a captured kernel reads IS the runner's buffer; what was derived at build time is absent, not stale
+    same = lambda a, b_: a.data_ptr() == b_.data_ptr() and a.dtype == b_.dtype
+    assert same(md.seq_lens_tensor, common.seq_lens) and same(md.slot_mapping, common.slot_mapping) and same(md.block_tables, common.block_table_tensor)
+    assert md.context_lens_tensor is None and md.seq_start_loc is None and md.query_start_loc is None
+    dec = md.decode_metadata
+    assert same(dec.seq_lens_tensor, common.seq_lens) and dec.num_decode_tokens == 3
+    converted, _ = _common([1, 1, 1], [17, 90, 3])
+    converted.seq_lens = converted.seq_lens.long()
+    with pytest.raises(TypeError):
+        b.build_for_cudagraph_capture(converted)
     mixed, _ = _common([4, 1], [4, 20])
     with pytest.raises(ValueError):
         b.build_for_cudagraph_capture(mixed)

@@ -50,8 +50,10 @@ __global__ __launch_bounds__(256) void moe_route_kernel(hymeta_moe_route_args a)
   int pick[2] = {0, 0};
   float pw[2] = {0.f, 0.f};
   for (int j = 0; j < a.top_k; ++j) {
-    int best = -1;
-    float bv = -1.f;
+    // starts from the first expert not taken: a row of NaN logits compares false everywhere and keeps it, with a NaN
+    // weight -- a valid index for the counters below and a NaN row out, never index -1
+    int best = (j == 1 && pick[0] == 0) ? 1 : 0;
+    float bv = logit[best];
     for (int e = 0; e < a.num_experts; ++e) {
       const bool taken = j == 1 && e == pick[0];
       if (!taken && logit[e] > bv) {   // first maximum wins, as torch.topk on ties of distinct indices
@@ -164,8 +166,10 @@ __global__ __launch_bounds__(256) void moe_router_kernel(hymeta_moe_router_args 
     int pick[2] = {0, 0};
     float pw[2] = {0.f, 0.f};
     for (int j = 0; j < a.top_k; ++j) {
-      int best = -1;
-      float bv = -1.f;
+      // starts from the first expert not taken: a row of NaN logits compares false everywhere and keeps it, with a
+      // NaN weight -- a valid index for the counting below and a NaN row out, never index -1
+      int best = (j == 1 && pick[0] == 0) ? 1 : 0;
+      float bv = s_logit[best];
       for (int e = 0; e < E; ++e) {
         const bool taken = j == 1 && e == pick[0];
         if (!taken && s_logit[e] > bv) {   // first maximum wins

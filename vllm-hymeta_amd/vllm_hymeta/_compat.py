@@ -83,6 +83,7 @@ class ModelBuildArgs:
     device: Any
     cache_config: Any
     prefix: str
+    expert_parallel: bool = False      # ``--enable-expert-parallel`` (``parallel_config.enable_expert_parallel``)
 
 
 def quant_args(quant_config) -> Optional[Dict[str, int]]:
@@ -126,4 +127,5 @@ def model_build_args(vllm_config, prefix: str = "") -> ModelBuildArgs:
     return ModelBuildArgs(config=config, max_num_seqs=int(vllm_config.scheduler_config.max_num_seqs),
                           quant=quant_args(getattr(vllm_config, "quant_config", None)),
                           tp_group=tensor_parallel_group(tp), device=device,
-                          cache_config=getattr(vllm_config, "cache_config", None), prefix=prefix)
+                          cache_config=getattr(vllm_config, "cache_config", None), prefix=prefix,
+                          expert_parallel=bool(getattr(pc, "enable_expert_parallel", False)))

@@ -25,13 +25,25 @@ import torch
 from .meta_attention import MetaAttentionMetadata
 
 
-def split_prefills_and_decodes(query_lens: List[int]) -> int:
-    """Number of leading prefill requests of a batch ordered prefills-first; raises if a request scheduled for more
-    than one token follows a decode (the kernels index decode rows after all prefill rows)."""
+def is_prefill_request(query_len: int, num_computed_tokens: int) -> bool:
+    """A request runs through the prefill kernels when it is scheduled for more than one token OR has nothing computed
+    yet: a brand-new prompt of ONE token is a prompt, as the reference's V0 path treats it (``is_prompt``,
+    ``vllm_hymeta/attention/meta_attention.py:435-470``) -- its recurrent-state slot is reset by the prefill pass
+    (``context_lens == 0``), which a decode step would skip."""
+    return query_len > 1 or num_computed_tokens == 0
+
+
+def split_prefills_and_decodes(query_lens: List[int], computed: Optional[List[int]] = None) -> int:
+    """Number of leading prefill requests (``is_prefill_request``) of a batch ordered prefills-first; raises if a prefill
+    follows a decode (the kernels index decode rows after all prefill rows).  ``computed``: tokens already computed per
+    request; without it only the query lengths decide."""
+    if computed is None:
+        computed = [1] * len(query_lens)
+    flags = [is_prefill_request(q, c) for q, c in zip(query_lens, computed)]
     n = 0
-    while n < len(query_lens) and query_lens[n] > 1:
+    while n < len(flags) and flags[n]:
         n += 1
-    if any(q != 1 for q in query_lens[n:]):
+    if any(flags[n:]) or any(q != 1 for q in query_lens[n:]):
         raise ValueError("batch is not ordered prefills first, then single-token decodes: call reorder_batch()")
     return n
 
@@ -53,11 +65,13 @@ class MetaAttentionMetadataBuilderV1:
 
     # ------------------------------------------------------------------ batch order
     def reorder_batch(self, input_batch, scheduler_output) -> bool:
-        """Put the requests scheduled for more than one token in front (stable on both sides).  ``input_batch`` has
-        ``req_ids`` and ``swap_states(i, j)``; ``scheduler_output.num_scheduled_tokens`` maps request id -> tokens of
-        this step.  Returns whether anything moved."""
+        """Put the prefill requests (``is_prefill_request``) in front (stable on both sides).  ``input_batch`` has
+        ``req_ids``, ``swap_states(i, j)`` and, per request, ``num_computed_tokens_cpu``;
+        ``scheduler_output.num_scheduled_tokens`` maps request id -> tokens of this step.  Returns whether anything moved."""
         ids = list(input_batch.req_ids)
-        is_prefill = [scheduler_output.num_scheduled_tokens[r] > 1 for r in ids]
+        computed = getattr(input_batch, "num_computed_tokens_cpu", None)
+        is_prefill = [is_prefill_request(scheduler_output.num_scheduled_tokens[r], int(computed[i]) if computed is not None else 1)
+                      for i, r in enumerate(ids)]
         moved = False
         front = 0                       # first position not yet holding a prefill
         for i in range(len(ids)):
@@ -79,7 +93,9 @@ class MetaAttentionMetadataBuilderV1:
         qsl_cpu = m.query_start_loc_cpu[: num_reqs + 1]
         query_lens = (qsl_cpu[1:] - qsl_cpu[:-1]).tolist()
         seq_lens = m.seq_lens_cpu[:num_reqs].tolist()
-        n_pre = split_prefills_and_decodes(query_lens)
+        computed = getattr(m, "num_computed_tokens_cpu", None)
+        computed = [int(c) for c in computed[:num_reqs]] if computed is not None else [s - q for s, q in zip(seq_lens, query_lens)]
+        n_pre = split_prefills_and_decodes(query_lens, computed)
         t_pre = int(qsl_cpu[n_pre])
         device = m.query_start_loc.device
         seq_lens_dev = m.seq_lens[:num_reqs].to(torch.int32)
@@ -98,17 +114,31 @@ class MetaAttentionMetadataBuilderV1:
             query_start_loc=qsl_dev, seq_start_loc=seq_start)
 
     def build_for_cudagraph_capture(self, common_attn_metadata) -> MetaAttentionMetadata:
-        """Pure-decode batch with every tensor a view of the runner's persistent buffers (their contents change
-        between replays, their addresses do not).  ``max_decode_seq_len`` is what the graph's kernels size their key
-        splits for: the longest sequence the buffers can describe."""
-        md = self.build(0, common_attn_metadata)
-        if md.num_prefills != 0:
+        """Pure-decode batch for a graph.  The captured kernels (fused KV write + single-token paged decode, GLA decode)
+        read three tensors of the metadata: ``seq_lens_tensor``, ``block_tables`` and ``slot_mapping``.  Each must BE the
+        runner's persistent buffer (a view: contents change between replays, the address does not), so a buffer whose
+        dtype would need a converted copy is refused.  Everything derived at build time -- context lengths, start
+        offsets, the host list of lengths -- would be stale on the first replay and is left out (``None``): a decode
+        kernel that reached for one would fail at capture, not read old numbers.  ``max_decode_seq_len`` is what the
+        graph's kernels size their key splits for: the longest sequence the buffers can describe."""
+        m = common_attn_metadata
+        num_reqs, num_tokens = int(m.num_reqs), int(m.num_actual_tokens)
+        if num_tokens != num_reqs:
             raise ValueError("only pure-decode batches are captured")
-        md.use_cuda_graph = True
-        md.seq_lens = None                                   # host copy would go stale between replays
-        if self.block_size is not None:
-            md.max_decode_seq_len = int(md.block_tables.shape[1]) * int(self.block_size)
-        return md
+        if m.seq_lens.dtype != torch.int32 or m.slot_mapping.dtype != torch.long or m.block_table_tensor.dtype != torch.int32:
+            raise TypeError("graph capture needs the runner's buffers as they are: seq_lens int32, slot_mapping int64, "
+                            "block_table int32 (a dtype conversion would capture a copy)")
+        block_tables = m.block_table_tensor[:num_reqs]
+        longest = int(block_tables.shape[1]) * int(self.block_size) if self.block_size is not None else int(m.seq_lens_cpu[:num_reqs].max())
+        return MetaAttentionMetadata(
+            num_prefills=0, num_prefill_tokens=0, num_decode_tokens=num_tokens,
+            slot_mapping=m.slot_mapping[:num_tokens],
+            multi_modal_placeholder_index_maps=None, enable_kv_scales_calculation=False,
+            seq_lens=None, seq_lens_tensor=m.seq_lens[:num_reqs],
+            max_prefill_seq_len=0, max_decode_seq_len=longest,
+            context_lens_tensor=None, block_tables=block_tables,
+            use_cuda_graph=True, max_query_len=1, max_decode_query_len=1,
+            query_start_loc=None, seq_start_loc=None)
 
     def use_cascade_attention(self, *args, **kwargs) -> bool:
         return False

@@ -1146,15 +1146,22 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
                 gate_weight: Optional[torch.Tensor] = None, logits_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Sparse MoE block: x bf16 [T,H], router_logits [T,E] (bf16 | fp32), w13 bf16 [E,2I,H], w2 bf16
     [E,H,I]; ``shared`` bf16 [T,H] is added to the result; ``local_experts = (lo, hi)`` computes only
-    this rank's experts (the caller all-reduces).  Returns bf16 [T,H].
+    this rank's experts (the caller all-reduces); the weight tensors may then hold just those experts
+    (``[hi - lo, 2I, H]`` / ``[hi - lo, H, I]``, expert ``lo`` first: an expert-parallel rank keeps nothing else), with the
+    number of experts taken from the router (``gate_weight`` rows / ``router_logits`` columns).  Returns bf16 [T,H].
     With ``router_logits=None`` and ``gate_weight`` bf16 [E,H] the block computes the logits itself: decode-sized batches
     in the routing launch (``moe_router_fused``; ``logits_out`` bf16 [T,E] then receives them), larger ones through the
     linear layer."""
     _dev(x, router_logits, w13, w2, shared, out, gate_weight)
     T, H = x.shape
-    E, two_i, Hw = w13.shape
+    E_held, two_i, Hw = w13.shape
     inter = two_i // 2
     _require(router_logits is not None or gate_weight is not None, "router_logits or gate_weight must be given")
+    E = gate_weight.shape[0] if gate_weight is not None else router_logits.shape[1]
+    lo, hi = local_experts if local_experts is not None else (0, E)
+    _require(0 <= lo <= hi <= E, "local_experts must lie inside the router's experts")
+    compact = E_held != E                   # only the local experts are held: slot 0 = expert lo
+    _require(E_held == E or E_held == hi - lo, "w13 / w2 must hold every expert or exactly the local ones")
     fused_router = router_logits is None and T > 0 and moe_router_fused(x, gate_weight)
     if router_logits is None and not fused_router:
         _require(gate_weight.shape == (E, H), "gate_weight must be [E, H]")
@@ -1163,11 +1170,10 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
             logits_out.copy_(router_logits)
     _require(x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [T, H]")
     _require(w13.dtype == torch.bfloat16 and w13.is_contiguous() and Hw == H, "w13 must be contiguous bf16 [E, 2I, H]")
-    _require(w2.dtype == torch.bfloat16 and w2.is_contiguous() and w2.shape == (E, H, inter),
+    _require(w2.dtype == torch.bfloat16 and w2.is_contiguous() and w2.shape == (E_held, H, inter),
              "w2 must be contiguous bf16 [E, H, I]")
     _require(fused_router or (router_logits.shape == (T, E) and router_logits.dtype in _DT and router_logits.stride(1) == 1),
              "router_logits must be [T, E] bf16 | fp32")
-    lo, hi = local_experts if local_experts is not None else (0, E)
     dev = x.device
     P = T * top_k
     ids = torch.empty(T, top_k, dtype=torch.int32, device=dev)
@@ -1207,7 +1213,11 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
 
     h13 = torch.empty(P, two_i, dtype=torch.bfloat16, device=dev)
     g = _C.MoeGemmArgs()
-    g.x, g.weights, g.out, g.expert_offsets = _p(x), _p(w13), _p(h13), _p(offsets)
+    # the kernels index the weights by the expert's number: tensors that hold the local experts only are addressed from
+    # where expert 0 would lie (only experts lo .. hi - 1 are ever read)
+    w13_base = C.c_void_p(w13.data_ptr() - (lo * w13.stride(0) * 2 if compact else 0))
+    w2_base = C.c_void_p(w2.data_ptr() - (lo * w2.stride(0) * 2 if compact else 0))
+    g.x, g.weights, g.out, g.expert_offsets = _p(x), w13_base, _p(h13), _p(offsets)
     g.a_rows, g.a_rows_div, g.max_rows, g.K, g.N = _p(sorted_pair), top_k, P, H, two_i
     g.local_expert_begin, g.local_expert_end = lo, hi
     g.x_stride_m, g.out_stride_m, g.w_stride_e = x.stride(0), h13.stride(0), w13.stride(0)
@@ -1226,7 +1236,7 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
     d = _C.MoeGemmArgs()
     d.x, d.x_stride_m = _p(hact), hact.stride(0)
     y = out if fuse_combine else torch.empty(P, H, dtype=torch.bfloat16, device=dev)
-    d.weights, d.out, d.expert_offsets = _p(w2), _p(y), _p(offsets)
+    d.weights, d.out, d.expert_offsets = w2_base, _p(y), _p(offsets)
     d.scale_rows, d.row_scale = _p(sorted_pair), _p(wts)
     d.a_rows_div, d.max_rows, d.K, d.N = 1, P, inter, H
     d.local_expert_begin, d.local_expert_end = lo, hi

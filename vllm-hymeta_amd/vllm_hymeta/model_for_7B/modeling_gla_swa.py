@@ -24,7 +24,7 @@ from typing import Dict, Iterable, List, Optional, Set, Tuple
 import torch
 
 from .. import loader
-from .._compat import HasInnerState, IntermediateTensors, IsHybrid, SupportsPP, SupportsV0Only, model_build_args
+from .._compat import HasInnerState, IsHybrid, SupportsV0Only, model_build_args
 from ..linear import HymetaLinear
 from ..lm_head import LmHeadMixin, lm_head_logits
 from ..models.attention import bind_kv_cache, current_attn_metadata, forward_context, standalone_prefix
@@ -126,7 +126,7 @@ class GLAswaModel(torch.nn.Module):
         return self.norm(hidden_states, residual)[0] if residual is not None else self.norm(hidden_states)
 
 
-class GLAswaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only, SupportsPP):
+class GLAswaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only):
     packed_modules_mapping = {
         "qkv_proj": ["q_proj", "k_proj", "v_proj"],
         "gate_up_proj": ["gate_proj", "up_proj"],
@@ -181,11 +181,6 @@ class GLAswaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
         if idx is not None:
             hidden_states = hidden_states.index_select(0, idx)
         return lm_head_logits(hidden_states, self._lm_head)
-
-    def make_empty_intermediate_tensors(self, batch_size: int, dtype: torch.dtype, device: torch.device) -> IntermediateTensors:
-        return IntermediateTensors({
-            "hidden_states": torch.zeros((batch_size, self.config.hidden_size), dtype=dtype, device=device),
-            "residual": torch.zeros((batch_size, self.config.hidden_size), dtype=dtype, device=device)})
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]) -> Set[str]:

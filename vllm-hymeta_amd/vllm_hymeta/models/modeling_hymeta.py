@@ -16,8 +16,9 @@ What differs in mechanism:
 * a new sequence's state slot is seeded from the meta state by the prefill kernel
   (``context_lens == 0``), not zeroed on the host (``_clear_prefill_cache``, ``:1202-1227``);
 * tensors are ingested in checkpoint format and cut for the rank by ``vllm_hymeta.loader``.
-Pipeline parallelism is not implemented (a ``pipeline_parallel_size`` above 1 is refused when the model is built);
-``make_empty_intermediate_tensors`` keeps the reference's interface.
+Pipeline parallelism is not implemented: the classes do not declare ``SupportsPP`` (vLLM then refuses a
+``pipeline_parallel_size`` above 1 by itself, and ``_compat.model_build_args`` refuses it when the model is built).
+The reference's 8-GPU recipe is TP4 x PP2 (``readme.md:113-114``); here 8 GPUs run as two TP4 replicas.
 """
 
 from __future__ import annotations
@@ -27,7 +28,7 @@ from typing import Dict, Iterable, List, Optional, Set, Tuple
 import torch
 
 from .. import loader
-from .._compat import HasInnerState, IntermediateTensors, IsHybrid, SupportsPP, SupportsV0Only, model_build_args
+from .._compat import HasInnerState, IsHybrid, SupportsV0Only, model_build_args
 from ..linear import HymetaLinear, LinearColumns
 from ..lm_head import LmHeadMixin, lm_head_logits
 from ..model_for_7B.window_attention import rope_cos_sin_cache
@@ -36,7 +37,7 @@ from .attention import MetaAttention, bind_kv_cache, current_attn_metadata, forw
 from .block import HybridBlock, HymetaRMSNorm
 from .hybrid_attention import HLinearAttention, IntraHybridAttention, MetaFlashAttention
 from .hymeta_cache import HymetaCacheManager, HymetaCacheParams
-from .moe import HymetaMLP, HymetaMoE
+from .moe import HymetaMLP, HymetaMoE, expert_range
 
 
 def _layer_experts(config, layer_idx: int) -> int:
@@ -64,8 +65,13 @@ def _layer_window(config, layer_idx: int) -> Optional[int]:
 
 class HymetaModel(torch.nn.Module):
     def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda",
-                 cache_config=None, prefix: Optional[str] = None):
-        """``prefix``: name of this module in the whole model (``"model"`` under vLLM); the softmax branch of layer
+                 cache_config=None, prefix: Optional[str] = None, expert_parallel: bool = False):
+        """``expert_parallel`` (``--enable-expert-parallel`` of the reference's serving commands, ``readme.md:115,167``):
+        the routed experts of a mixture layer are dealt whole to the ranks of the tensor-parallel group (16 / tp each)
+        instead of every expert being cut along its intermediate size; every rank still sees every token, computes the
+        pairs routed to its experts, and the layer's all-reduce sums the ranks -- what vLLM's ``FusedMoE`` does under
+        expert parallelism without data parallelism (``models/modeling_hymeta.py:312-324``).
+        ``prefix``: name of this module in the whole model (``"model"`` under vLLM); the softmax branch of layer
         ``i`` registers its attention layer as ``<prefix>.layers.<i>.attn.vanilla_attn.attn`` (reference ``:742,
         843,955,1133``), the name under which the engine binds that layer's paged KV cache.  ``None``: a private
         name (models built directly, several per process)."""
@@ -75,6 +81,7 @@ class HymetaModel(torch.nn.Module):
         self.device = torch.device(device)
         self.tp_group = tp_group
         self.tp_rank, self.tp_size = tp_rank_and_size(tp_group)
+        self.expert_parallel = bool(expert_parallel) and self.tp_size > 1
         self.quant = dict(bits=4, group_size=128, zero_offset=1)
         self.quant.update(quant or {})
         self.use_lower_bound = config.use_lower_bound
@@ -166,14 +173,14 @@ class HymetaModel(torch.nn.Module):
         return self.norm(hidden_states, residual)[0] if residual is not None else self.norm(hidden_states)
 
 
-class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only, SupportsPP):
+class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only):
     packed_modules_mapping = {
         "qkv_proj": ["q_proj", "k_proj", "v_proj"],
         "gate_up_proj": ["gate_proj", "up_proj"],
     }
 
     def __init__(self, config=None, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda",
-                 *, vllm_config=None, prefix: Optional[str] = None):
+                 *, vllm_config=None, prefix: Optional[str] = None, expert_parallel: bool = False):
         """vLLM constructs the class as ``HymetaForCausalLM(vllm_config=..., prefix=...)`` (reference ``:1386-1411``):
         the HF config, ``scheduler_config.max_num_seqs`` (state slots), the quantisation parameters, the
         tensor-parallel group and the cache config are read from ``vllm_config``.  The keyword form
@@ -185,6 +192,7 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
             args = model_build_args(vllm_config, prefix or "")
             config, max_num_seqs, quant, tp_group, device, cache_config = (
                 args.config, args.max_num_seqs, args.quant, args.tp_group, args.device, args.cache_config)
+            expert_parallel = bool(getattr(args, "expert_parallel", False))
             model_prefix = f"{prefix}.model" if prefix else "model"          # maybe_prefix(prefix, "model"), :1410
         else:
             if config is None:
@@ -196,7 +204,7 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
             config.sliding_window = None
         self.unpadded_vocab_size = config.vocab_size
         self.model = HymetaModel(config, max_num_seqs=max_num_seqs, quant=quant, tp_group=tp_group, device=device,
-                                 cache_config=cache_config, prefix=model_prefix)
+                                 cache_config=cache_config, prefix=model_prefix, expert_parallel=expert_parallel)
         self.lm_head = None             # [vocab, hidden]; reads as fp32 (:1429), see lm_head.py
         self.kv_cache = [torch.tensor([]) for _ in range(config.num_hidden_layers)]
 
@@ -226,12 +234,6 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
         if idx is not None:
             hidden_states = hidden_states.index_select(0, idx)
         return lm_head_logits(hidden_states, self._lm_head)
-
-    def make_empty_intermediate_tensors(self, batch_size: int, dtype: torch.dtype, device: torch.device) -> IntermediateTensors:
-        """Reference ``:1471-1483``."""
-        return IntermediateTensors({
-            "hidden_states": torch.zeros((batch_size, self.config.hidden_size), dtype=dtype, device=device),
-            "residual": torch.zeros((batch_size, self.config.hidden_size), dtype=dtype, device=device)})
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]) -> Set[str]:
@@ -270,7 +272,13 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
                 if tensor.dtype not in (torch.bfloat16, torch.float16, torch.float32):
                     raise ValueError(f"{name}: quantised experts are not supported, expected a floating-point weight")
                 layer = loader._layer_of(name)
-                cut = row if route.shard_id == "w2" else col          # experts are cut along their intermediate size
+                if m.expert_parallel:      # whole experts, dealt to the ranks in contiguous equal shares
+                    lo, hi = expert_range(_layer_experts(cfg, layer), m.tp_size, m.tp_rank)
+                    if not lo <= route.expert_id < hi:
+                        continue
+                    cut = loader.Cut()
+                else:
+                    cut = row if route.shard_id == "w2" else col          # experts are cut along their intermediate size
                 piece = loader.own(loader.cut_leaf("weight", tensor, cut), dev).to(torch.bfloat16)
                 experts.setdefault(layer, {}).setdefault(route.expert_id, {})[proj_of[route.shard_id]] = piece
                 continue
@@ -322,12 +330,14 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
                 ffn = mlp(f"{p}.mlp")
             else:
                 mine = experts.pop(i)
-                w13, w2 = loader.stack_experts([mine[e] for e in range(n_experts)])       # already this rank's slices
+                local = expert_range(n_experts, m.tp_size, m.tp_rank) if m.expert_parallel else None
+                w13, w2 = loader.stack_experts([mine[e] for e in (range(*local) if local else range(n_experts))])   # this rank's
                 del mine
                 # the shared expert's partial sums ride in the experts' all-reduce
                 shared = mlp(f"{p}.shared_mlp", reduce_results=False) if _shared_intermediate(cfg, i) > 0 else None
                 ffn = HymetaMoE(plain[f"{p}.block_sparse_moe.gate.weight"].to(torch.bfloat16), w13, w2,
-                                top_k=cfg.num_experts_per_topk, renormalize=False, shared_mlp=shared, group=m.tp_group)
+                                top_k=cfg.num_experts_per_topk, renormalize=False, shared_mlp=shared, group=m.tp_group,
+                                local_experts=local)
             m.layers.append(HybridBlock(HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.attn_norm.weight"]), attn,
                                         HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.mlp_norm.weight"]), ffn))
         if dev.type == "cuda":

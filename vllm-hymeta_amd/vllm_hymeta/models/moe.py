@@ -55,9 +55,13 @@ def expert_range(num_experts: int, ep_size: int, ep_rank: int) -> Tuple[int, int
 
 
 class HymetaMoE(torch.nn.Module):
-    """Top-k routed experts (+ optional shared expert).  ``w13 [E, 2I, H]`` / ``w2 [E, H, I]`` hold ALL
-    expert slots (a rank that owns experts ``[lo, hi)`` may leave the other slots unallocated-sized
-    views of anything: they are never read)."""
+    """Top-k routed experts (+ optional shared expert).  ``w13 [E, 2I, H]`` / ``w2 [E, H, I]`` hold every expert, or,
+    for a rank that owns experts ``local_experts = [lo, hi)`` under expert parallelism, those experts only
+    (``[hi - lo, 2I, H]`` / ``[hi - lo, H, I]``).  Every rank routes every token; a rank computes the pairs that went
+    to its experts (rows of the others stay zero, the shared expert's partial sums are added on every rank) and the
+    all-reduce over ``group`` sums the ranks: expert parallelism without data parallelism, as vLLM runs it for the
+    reference's serving commands (``readme.md:115,167``).  An all-to-all dispatch would only pay with data parallelism
+    (ranks holding different tokens), which the reference never runs."""
 
     def __init__(self, gate_weight: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, top_k: int = 1,
                  renormalize: bool = False, shared_mlp: Optional[HymetaMLP] = None,

@@ -392,6 +392,31 @@ def one_shot_self_check(group: dist.ProcessGroup, device: torch.device, rows=(1,
     return good, ("" if good else (why or "another rank failed the check"))
 
 
+# A second process group over the same ranks that carries the collectives recorded into HIP graphs.  The backend's
+# watchdog thread polls the completion events of EAGER collectives; those events sit on the group's communication
+# stream, and a poll of one while that stream is being captured is refused by the runtime and takes the process down.
+# With the captured calls on a group of their own, the stream that is being captured never holds an eager event.
+_CAPTURE_GROUP: dict = {}
+
+
+def set_capture_group(group: dist.ProcessGroup, capture_group: Optional[dist.ProcessGroup]) -> None:
+    """Collectives over ``group`` that are issued while the current stream is being captured go over ``capture_group``
+    instead (same ranks, same order; ``None`` removes the entry).  The caller runs one eager collective on
+    ``capture_group`` first, well before any capture, so that its communicator exists."""
+    if capture_group is None:
+        _CAPTURE_GROUP.pop(group, None)
+    else:
+        _CAPTURE_GROUP[group] = capture_group
+
+
+def backend_group(group):
+    """The process group a collective over ``group`` is sent on right now (see ``set_capture_group``)."""
+    alias = _CAPTURE_GROUP.get(group)
+    if alias is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return alias
+    return group
+
+
 def defers_into_all_reduce(group) -> bool:
     """Whether a row-parallel linear in front of ``all_reduce_sum(…, group)`` may hand over its K slices' partial sums
     (``defer=True``): the group's one-shot exchange adds them while it reads its message."""
@@ -413,7 +438,7 @@ def all_reduce_sum(x, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor
         if comm is not None and (comm.supports(x) or isinstance(group, InProcessGroup)):
             comm.all_reduce(data=x)
         else:
-            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=backend_group(group))
     return x
 
 
@@ -427,9 +452,25 @@ def all_reduce_variance(stats: torch.Tensor, group: Optional[dist.ProcessGroup] 
         if comm is not None and (comm.supports(None, stats) or isinstance(group, InProcessGroup)):
             comm.all_reduce(stats=stats, stats_scale=1.0 / size)      # the division rides in the exchange: no launch of its own
         else:
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=backend_group(group))
             stats /= size
     return stats
+
+
+def all_gather_rows(mine: torch.Tensor, out: torch.Tensor, group, rank: int) -> torch.Tensor:
+    """``out [W, *mine.shape]`` (fp32, contiguous) = every rank's ``mine``, rank-major.  Small messages go through the
+    group's one-shot exchange as a sum of the ranks' own rows and zeros elsewhere (exact: x + 0), so that a captured step
+    holds no call into the backend; otherwise an all-gather on the group's backend."""
+    comm = _exchange_of(group) if _active(group) else None
+    if comm is not None and out.dtype == torch.float32 and out.is_contiguous() and comm.supports(None, out):
+        out.zero_()
+        out[rank].copy_(mine)
+        comm.all_reduce(stats=out)
+    elif _active(group):
+        dist.all_gather_into_tensor(out.view(-1, *mine.shape[1:]) if mine.dim() > 1 else out.view(-1), mine, group=backend_group(group))
+    else:
+        out[0].copy_(mine)
+    return out
 
 
 def tp_rank_and_size(group: Optional[dist.ProcessGroup] = None) -> Tuple[int, int]:
