@@ -14,6 +14,12 @@ and outputs, no source).  What loads by file path without the GPU-only third-par
   import two decorators from ``fla.utils`` (``contiguous``: make tensor arguments contiguous; ``autocast_custom_fwd``:
   autocast bookkeeping); fla is not installed, and the script registers a module of that name holding those two
   decorators (no arithmetic in either) before loading the files           -> ref_gla_decode.npz
+* vllm_hymeta/attention/fa_kernel_metatoken.py: ``naive_metatoken_flash_attn`` (:377-410), the reference's own
+  dense-mask definition of window + meta-token attention, and ``_update_out_and_lse`` (:110-122), its merge of the two
+  partial softmaxes.  Both are plain torch.  The module's import lines name flash_attn (absent here, GPU-only): the
+  script registers modules of those names whose every attribute raises when called, so that nothing but the two torch
+  functions can run; the naive function moves its mask with ``.cuda()`` (:407), which the script makes a no-op for the
+  duration of the call (no GPU here; the mask is the same tensor wherever it lives)      -> ref_meta_attention.npz
 
 bf16 tensors are stored as their uint16 bit patterns (key suffix ``_bf16``)."""
 import importlib.util
@@ -204,8 +210,78 @@ def gla_decode():
     return {k: getattr(v, "shape", ()) for k, v in out.items()}
 
 
+def _flash_attn_placeholders():
+    """Modules that satisfy ``from flash_attn.flash_attn_interface import ...`` and ``import flash_attn_2_cuda``; any use
+    of what they hold raises."""
+    def refuse(name):
+        def call(*a, **k):
+            raise RuntimeError(f"{name}: flash_attn is not installed here; only the module's plain-torch functions run")
+        return call
+
+    class Placeholder(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return refuse(f"{self.__name__}.{name}")
+
+    for name in ("flash_attn", "flash_attn.flash_attn_interface", "flash_attn_2_cuda"):
+        if name not in sys.modules:
+            sys.modules[name] = Placeholder(name)
+    sys.modules["flash_attn"].flash_attn_interface = sys.modules["flash_attn.flash_attn_interface"]
+
+
+def meta_attention():
+    """``naive_metatoken_flash_attn`` on fp32 inputs: equal lengths with meta queries, a chunk against a longer key
+    range (bottom-right alignment), a window shorter and one longer than the sequence; ``_update_out_and_lse`` on two
+    partial softmaxes."""
+    _flash_attn_placeholders()
+    mod = _load_file(os.path.join(REF, "vllm_hymeta/attention/fa_kernel_metatoken.py"), "ref_fa_kernel_metatoken")
+    gen = torch.Generator().manual_seed(104)
+    H, D, M = 3, 32, 8
+    out = {"num_meta": np.int64(M), "scale": np.float64(D ** -0.5)}
+    cases = [("eq_q2", 11, 11, 5, True), ("chunk", 4, 13, 6, False), ("short_window", 9, 9, 1, False), ("long_window", 7, 7, 50, False)]
+    out["cases"] = np.array([c[0] for c in cases])
+    # two cases at the kernels' own geometry (head size 128, 32 meta tokens, inputs that are exact in bf16, stored as bf16)
+    kernel_cases = [("k_eq_q2", 70, 70, 24, True, 2, 128, 32), ("k_chunk", 20, 90, 33, False, 2, 128, 32)]
+    out["kernel_cases"] = np.array([c[0] for c in kernel_cases])
+    out["kernel_num_meta"], out["kernel_scale"] = np.int64(32), np.float64(128 ** -0.5)
+    saved_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, Lq, Lk, win, with_q2, H, D, M in [c + (H, D, M) for c in cases] + kernel_cases:
+            as_bf16 = tag.startswith("k_")
+            rnd = (lambda *shape: torch.randn(*shape, generator=gen).to(torch.bfloat16)) if as_bf16 else \
+                (lambda *shape: torch.randn(*shape, generator=gen))
+            q1 = rnd(1, Lq, H, D)
+            k1, v1 = rnd(1, Lk, H, D), rnd(1, Lk, H, D)
+            k2, v2 = rnd(1, M, H, D), rnd(1, M, H, D)
+            q2 = rnd(1, M, H, D) if with_q2 else None
+            f32 = lambda t: None if t is None else t.float()           # the function runs in fp32 on the bf16 values
+            o = mod.naive_metatoken_flash_attn(f32(q1), f32(q2), f32(k1), f32(k2), f32(v1), f32(v2), softmax_scale=D ** -0.5,
+                                               num_meta_tokens=M, sliding_window=(win, 0))
+            for name, t in (("q1", q1), ("k1", k1), ("v1", v1), ("k2", k2), ("v2", v2)):
+                put(out, f"{tag}_{name}", t[0])
+            if q2 is not None:
+                put(out, f"{tag}_q2", q2[0])
+            out[f"{tag}_window"] = np.int64(win)      # sliding_window[0]: keys with q - k < window are visible
+            put(out, f"{tag}_out", o[0])              # real-query rows first, meta-query rows (if any) last
+    finally:
+        torch.Tensor.cuda = saved_cuda
+    # the merge: [batch, seq, heads, dim] outputs and [batch, heads, seq] log-sum-exps of two key sets
+    L = 6
+    o1, o2 = torch.randn(1, L, H, D, generator=gen).to(torch.bfloat16), torch.randn(1, L, H, D, generator=gen).to(torch.bfloat16)
+    l1, l2 = torch.randn(1, H, L, generator=gen) * 3, torch.randn(1, H, L, generator=gen) * 3
+    mo, ml = mod._update_out_and_lse(o1, l1, o2, l2)
+    for name, t in (("merge_out1", o1[0]), ("merge_lse1", l1[0]), ("merge_out2", o2[0]), ("merge_lse2", l2[0]), ("merge_out", mo[0]),
+                    ("merge_lse", ml[0])):
+        put(out, name, t)
+    np.savez_compressed(os.path.join(HERE, "ref_meta_attention.npz"), **out)
+    return {k: getattr(v, "shape", ()) for k, v in out.items()}
+
+
 if __name__ == "__main__":
     print("rmsnorm", rmsnorm())
     print("rope", rope())
     print("cache", cache())
     print("gla_decode", gla_decode())
+    print("meta_attention", meta_attention())

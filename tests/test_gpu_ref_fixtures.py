@@ -102,3 +102,52 @@ def test_rope_kernel_vs_reference_rotary():
     # device keeps one product exact, so single elements move by an ulp
     _ulp_close(q, f["bf16_q_out"][0].transpose(0, 1), "rope q", max_frac=0.25)
     _ulp_close(k, f["bf16_k_out"][0].transpose(0, 1), "rope k", max_frac=0.25)
+
+
+def test_attention_kernels_vs_the_reference_dense_definition():
+    """The prefill and paged-decode kernels against outputs of ``naive_metatoken_flash_attn``
+    (vllm_hymeta/attention/fa_kernel_metatoken.py:377-410) itself, at the kernels' geometry (head size 128, 32 meta
+    tokens, bf16 inputs, window given as ``sliding_window[0] = w`` there = ``window_left = w - 1`` here):
+    a whole sequence with the meta queries (their rows come first here, last there); a 20-token chunk against 90 keys
+    (bottom-right aligned), un-paged and through a block table; and the chunk's last row as a paged single-token decode."""
+    from _util import assert_bf16_close
+    from vllm_hymeta import hip_ops
+
+    f = load("ref_meta_attention.npz")
+    M, scale = int(f["kernel_num_meta"]), float(f["kernel_scale"])
+    dev = torch.device("cuda")
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+
+    t = "k_eq_q2"
+    q1, k1, v1, k2, v2, q2 = (f[f"{t}_{n}"].to(dev) for n in ("q1", "k1", "v1", "k2", "v2", "q2"))
+    L, wl = q1.shape[0], int(f[f"{t}_window"]) - 1
+    out = hip_ops.meta_swa_prefill(q1, i32([0, L]), L, key=k1, value=v1, cu_seqlens_k=i32([0, L]), meta_query=q2, meta_key=k2,
+                                   meta_value=v2, window_left=wl, scale=scale)
+    torch.cuda.synchronize()
+    want = f[f"{t}_out"]
+    assert_bf16_close(out[M:].cpu(), want[:L], "prefill, real rows vs the reference's dense definition")
+    assert_bf16_close(out[:M].cpu(), want[L:], "prefill, meta-query rows vs the reference's dense definition")
+
+    t = "k_chunk"
+    q1, k1, v1, k2, v2 = (f[f"{t}_{n}"].to(dev) for n in ("q1", "k1", "v1", "k2", "v2"))
+    Lq, Lk, wl = q1.shape[0], k1.shape[0], int(f[f"{t}_window"]) - 1
+    want = f[f"{t}_out"]
+    out = hip_ops.meta_swa_prefill(q1, i32([0, Lq]), Lq, key=k1, value=v1, cu_seqlens_k=i32([0, Lk]), meta_key=k2, meta_value=v2,
+                                   window_left=wl, scale=scale)
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), want, "chunk against a longer key range, un-paged")
+    # the same keys in a paged cache with a scattered block table
+    bs, Hkv = 16, k1.shape[1]
+    nb = (Lk + bs - 1) // bs
+    perm = torch.randperm(nb + 3, generator=torch.Generator().manual_seed(7))[:nb].to(torch.int32)
+    kc = torch.full((nb + 3, bs, Hkv, 128), float("nan"), dtype=torch.bfloat16, device=dev)
+    vc = torch.full_like(kc, float("nan"))
+    for p in range(Lk):
+        kc[int(perm[p // bs]), p % bs], vc[int(perm[p // bs]), p % bs] = k1[p], v1[p]
+    bt = perm.view(1, nb).to(dev)
+    out = hip_ops.meta_swa_prefill(q1, i32([0, Lq]), Lq, key_cache=kc, value_cache=vc, block_tables=bt, seq_lens_k=i32([Lk]),
+                                   meta_key=k2, meta_value=v2, window_left=wl, scale=scale)
+    dec = hip_ops.meta_swa_paged_decode(q1[-1:].contiguous(), kc, vc, i32([Lk]), bt, k2, v2, window_left=wl, scale=scale)
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), want, "chunk through a block table")
+    assert_bf16_close(dec.cpu(), want[-1:], "last row as a paged single-token decode")

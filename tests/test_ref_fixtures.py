@@ -17,6 +17,8 @@ def load(name):
     for k in z.files:
         if k.endswith("_bf16"):
             out[k[:-5]] = torch.from_numpy(z[k].view(np.int16).copy()).view(torch.bfloat16)
+        elif z[k].dtype.kind in "US":
+            out[k] = [str(x) for x in np.atleast_1d(z[k])]
         else:
             out[k] = torch.from_numpy(np.asarray(z[k]).copy()) if z[k].shape else z[k].item()
     return out
@@ -142,3 +144,49 @@ def test_gla_decode_scale_is_rounded_to_the_activation_dtype():
     assert float(sc) == 0.08837890625
     assert float(o[0, 0, 0]) == float(sc)
     assert float(o[0, 0, 1]) == float((q[0, 0, 1] * sc))
+
+
+def test_meta_attention_restatement_equals_the_reference_dense_definition():
+    """``naive_metatoken_flash_attn`` (vllm_hymeta/attention/fa_kernel_metatoken.py:377-410), the reference's own
+    executable definition of window + meta-token attention, run on fp32 inputs: ``meta_swa_dense_ref`` gives the same
+    rows (its meta-query rows come first, the vLLM-path order; the naive function appends them) for equal lengths with
+    meta queries, a chunk against a longer key range (bottom-right alignment) and windows shorter / longer than the
+    sequence.  ``sliding_window[0] = w`` there shows keys with q - k < w: ``window_left = w - 1`` here."""
+    from oracle.meta_swa import meta_swa_dense_ref, meta_swa_two_pass_ref
+
+    f = load("ref_meta_attention.npz")
+    for tag in f["cases"] + f["kernel_cases"]:
+        M = int(f["kernel_num_meta" if tag.startswith("k_") else "num_meta"])
+        q1, k1, v1, k2, v2 = (f[f"{tag}_{n}"] for n in ("q1", "k1", "v1", "k2", "v2"))
+        q2 = f.get(f"{tag}_q2")
+        want = f[f"{tag}_out"]
+        Lq = q1.shape[0]
+        scale = float(f["kernel_scale" if tag.startswith("k_") else "scale"])
+        got, _ = meta_swa_dense_ref(q1, k1, v1, k2, v2, q2, window_left=int(f[f"{tag}_window"]) - 1, scale=scale)
+        if q2 is not None:
+            assert got.shape[0] == M + Lq
+            got = torch.cat([got[M:], got[:M]], dim=0)          # the naive function's order: real rows, then meta rows
+        assert got.shape == want.shape, tag
+        assert torch.allclose(got.float(), want, rtol=2e-5, atol=2e-6), (tag, float((got.float() - want).abs().max()))
+        # the two-pass form the kernels' structure follows (window pass + meta pass + merge) is the same function
+        if tag.startswith("k_"):
+            continue          # bf16 inputs: the two-pass form rounds its partial outputs to bf16, as flash-attn does
+        two = meta_swa_two_pass_ref(q1, k1, v1, k2, v2, q2, window_left=int(f[f"{tag}_window"]) - 1, scale=scale)
+        if q2 is not None:
+            two = torch.cat([two[M:], two[:M]], dim=0)
+        assert torch.allclose(two, want, rtol=2e-5, atol=2e-6), tag
+
+
+def test_lse_merge_ref_equals_reference_update_out_and_lse():
+    """``_update_out_and_lse`` (fa_kernel_metatoken.py:110-122) on bf16 partial outputs: bit for bit, and equal to the
+    plain log-sum-exp form the kernels' online softmax computes."""
+    from oracle.meta_swa import lse_merge_ref
+
+    f = load("ref_meta_attention.npz")
+    out, lse = lse_merge_ref(f["merge_out1"], f["merge_lse1"], f["merge_out2"], f["merge_lse2"])
+    assert out.dtype == torch.bfloat16 and torch.equal(out, f["merge_out"]) and torch.equal(lse, f["merge_lse"])
+    l1, l2 = f["merge_lse1"].double(), f["merge_lse2"].double()
+    both = torch.logaddexp(l1, l2)
+    plain = (f["merge_out1"].double() * torch.exp(l1 - both).t()[..., None] + f["merge_out2"].double() * torch.exp(l2 - both).t()[..., None])
+    assert torch.allclose(lse.double(), both, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(out.double(), plain, rtol=0, atol=2.0 ** -7 * float(plain.abs().max()))
