@@ -383,6 +383,24 @@ class PrefillRunner:
         return hip_ops.argmax_rows(self.model.compute_logits(h[-1:]))
 
 
+def ttft_only(model, dev, L, runs=3):
+    """p50 of the time to first token of ONE ``L``-token prompt (see ``prefill_and_latency``), for the side table of the
+    quantised checkpoints."""
+    pre = PrefillRunner(model, L, 8, dev)
+    pre.prefill()
+    torch.cuda.synchronize()
+    ttft = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        pre.prefill()
+        torch.cuda.synchronize()
+        ttft.append((time.perf_counter() - t0) * 1e3)
+    ttft.sort()
+    del pre
+    torch.cuda.empty_cache()
+    return round(ttft[len(ttft) // 2], 2)
+
+
 def prefill_and_latency(model, dev, L, new_tokens=128, runs=5):
     """The reference's latency protocol (hf_7B_model/speed_7B.py:196-221, bench/speed_vllm.py:41-53): one request =
     an L-token prompt + 128 generated tokens, batch 1.  TTFT = the prompt through all 28 layers (projections and MLP
@@ -712,6 +730,8 @@ def main():
             del rq
             torch.cuda.empty_cache()
             line["model_decode"][q]["batch1_ms_per_token"] = decode_b1(mq)
+            if not args.no_prefill:
+                line["model_decode"][q]["ttft_ms_p50"] = ttft_only(mq, dev, args.prefill_ctx)
             del mq
             torch.cuda.empty_cache()
         line["shard_70b_tp4"] = shard70b_side_measurement(dev)

@@ -186,26 +186,48 @@ def test_w8a8_streaming_kernel_matches_the_library_path_exactly(M, K, N):
     assert_bf16_close(out.cpu(), w8a8_gemm_ref(x, wq, ws, bias), f"w8a8 streaming M={M}", rel=6e-3)
 
 
-@pytest.mark.parametrize("M,K,N", [(300, 512, 256), (1024, 3584, 4608), (129, 3584, 4608), (200, 2048, 256)])
-def test_w8a8_linear_prefill_regime_matches_fused_kernel_exactly(M, K, N):
-    """Above 128 rows the linear runs quantise -> library int8 GEMM -> scale; the int32 sums are exact on both
-    paths, so the outputs agree bit for bit with the fused kernel's and with the oracle within the bf16 tolerance."""
+@pytest.mark.parametrize("M,K,N", [(300, 512, 256), (1024, 3584, 4608), (129, 3584, 4608), (200, 2048, 256), (513, 3584, 3584),
+                                   (8192, 3584, 4608), (1100, 18944, 256), (129, 3584, 37888), (300, 1024, 16384), (130, 320, 192)])
+def test_w8a8_linear_prefill_regime_both_paths_give_the_same_bits(M, K, N):
+    """Above 128 rows a W8A8 linear is the tiled int8-MFMA kernel (quantisation launch, then ONE GEMM launch with the
+    scales and the bias in its epilogue) or quantise -> library int8 GEMM -> scale, whichever ``w8a8_use_library`` picks
+    for the shape: the int32 sums are exact on both, the scaling rule is shared, so the two agree bit for bit (row counts
+    that are no multiple of the tiles, 128 x 128 and 256 x 256 tiles, one K step that is not a multiple of 128: library
+    only) and with the oracle within the bf16 tolerance."""
     from oracle.quant import w8a8_gemm_ref
     from vllm_hymeta import hip_ops
     from vllm_hymeta.linear import HymetaLinear, w8a8_use_library
 
-    assert w8a8_use_library(M, K, N) and not w8a8_use_library(128, K, N)
+    assert not w8a8_use_library(128, K, N)
     g_ = gen(21)
     x = randn_bf16(g_, M, K)
     wq = torch.randint(-127, 128, (N, K), generator=g_, dtype=torch.int8)
     ws = torch.rand(N, generator=g_) * 0.02 + 0.001
     bias = randn_bf16(g_, N, scale=0.1)
-    lin = HymetaLinear.from_w8a8(wq.cuda(), ws.cuda(), bias.cuda())
-    out = lin(x.cuda())
-    fused = hip_ops.w8a8_gemm(x.cuda(), wq.cuda(), ws.cuda(), bias=bias.cuda())
+    xd, wd, sd, bd = x.cuda(), wq.cuda(), ws.cuda(), bias.cuda()
+    lin = HymetaLinear.from_w8a8(wd, sd, bd)
+    out = lin(xd)
+    xq, xs = hip_ops.w8a8_quantize(xd)
+    library = hip_ops.w8a8_scale_out(torch._int_mm(xq, wd.t()), xs, sd, bias=bd)
     torch.cuda.synchronize()
-    assert torch.equal(out, fused)
-    assert_bf16_close(out.cpu(), w8a8_gemm_ref(x, wq, ws, bias), f"w8a8 linear M={M}", rel=6e-3)
+    assert torch.equal(out, library)
+    if K % 128 == 0 and N % 128 == 0:
+        tiled = hip_ops.w8a8_gemm(xd, wd, sd, bias=bd)          # the entry point itself: the tiled kernel above 128 rows
+        torch.cuda.synchronize()
+        assert torch.equal(tiled, library)
+    else:
+        assert w8a8_use_library(M, K, N)
+    if M <= 2048:
+        assert_bf16_close(out.cpu(), w8a8_gemm_ref(x, wq, ws, bias), f"w8a8 linear M={M}", rel=6e-3)
+
+
+def test_w8a8_path_choice_above_the_streaming_rows():
+    from vllm_hymeta.linear import w8a8_use_library
+
+    assert not w8a8_use_library(129, 3584, 37888) and not w8a8_use_library(32768, 3584, 37888)      # gate_up: tiled from 129 rows
+    assert w8a8_use_library(512, 3584, 4608) and not w8a8_use_library(1024, 3584, 4608)             # qkv / o: from 1024
+    assert w8a8_use_library(2048, 18944, 3584) and not w8a8_use_library(4096, 18944, 3584)          # down: from 4096
+    assert w8a8_use_library(4096, 3584 + 64, 4608) and w8a8_use_library(4096, 3584, 4608 + 64)      # shapes the tiles do not cut
 
 
 @pytest.mark.parametrize("tp", [2, 4])

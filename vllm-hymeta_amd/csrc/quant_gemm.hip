@@ -847,6 +847,144 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(hymeta_w8a8_gemm_args a,
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// W8A8 at prefill-sized row counts: out = bf16( (xq wq^T) * x_scale[m] * w_scale[n] + bias ) as ONE tiled launch.
+// The library path it replaces runs an int8 GEMM that writes its int32 sums to memory and a second launch that reads
+// them back to scale them: 10 bytes of traffic per output element that this kernel never makes.
+// BM rows x BN columns per workgroup, WM x WN waves that own (BM / WM) x (BN / WN) each, v_mfma_i32_16x16x64_i8.  Both
+// operands are K-contiguous int8; a 128-deep step of each (128 bytes per row) is staged once per workgroup through
+// double-buffered LDS images (16-byte chunks XOR-ed with the row, so the sixteen rows of a fragment read hit distinct
+// banks): registers -> LDS right behind the barrier that frees the buffer, the next step's loads issued at once.  The
+// epilogue applies the scales to the exact int32 sums with the rounding rule of every W8A8 kernel here (w8a8_scaled),
+// stages the bf16 tile through LDS and stores whole rows.  grid = (N / BN, ceil(M / BM)), column tiles fastest: the
+// workgroups that share a row tile of x run together.
+// ---------------------------------------------------------------------------------------------
+constexpr int kI8StepBytes = 128;                  // bytes of one staged row = 128 k
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void w8a8_tiled_kernel(hymeta_w8a8_gemm_args a) {
+  constexpr int kThreads = 64 * WM * WN;
+  constexpr int MT = BM / WM / 16, NT = BN / WN / 16;       // 16 x 16 tiles per wave
+  constexpr int kXBytes = BM * kI8StepBytes, kWBytes = BN * kI8StepBytes;
+  constexpr int kRowsPerPass = kThreads / 8;
+  constexpr int XP = BM / kRowsPerPass, WP = BN / kRowsPerPass;   // staging passes per operand
+  __shared__ __attribute__((aligned(16))) char sm[2][kXBytes + kWBytes];   // [buffer][x | w]
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int c = lane >> 4, n = lane & 15;
+  const int wm = wave / WN, wn = wave % WN;
+  const int col0 = blockIdx.x * BN;
+  const int row0 = blockIdx.y * BM;
+
+  // staging role: thread = 16-byte chunk sc of rows sr + kRowsPerPass i of both operand tiles (rows past M re-read the last row)
+  const int sr = tid >> 3, sc = tid & 7;
+  const int8_t* xp[XP];
+  const int8_t* wp[WP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) xp[i] = a.xq + static_cast<int64_t>(min(row0 + sr + kRowsPerPass * i, a.M - 1)) * a.K + 16 * sc;
+#pragma unroll
+  for (int i = 0; i < WP; ++i)
+    wp[i] = static_cast<const int8_t*>(a.qweight) + static_cast<int64_t>(col0 + sr + kRowsPerPass * i) * a.K + 16 * sc;
+  u32x4 xr[XP], wr[WP];
+  auto issue = [&](int it) {
+#pragma unroll
+    for (int i = 0; i < XP; ++i) xr[i] = ld16g(xp[i] + it * kI8StepBytes);
+#pragma unroll
+    for (int i = 0; i < WP; ++i) wr[i] = ld16g(wp[i] + it * kI8StepBytes);
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int r = sr + kRowsPerPass * i;
+      st16(&sm[buf][r * kI8StepBytes + 16 * (sc ^ (r & 7))], xr[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const int r = sr + kRowsPerPass * i;
+      st16(&sm[buf][kXBytes + r * kI8StepBytes + 16 * (sc ^ (r & 7))], wr[i]);
+    }
+  };
+
+  i32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = i32x4{0, 0, 0, 0};
+
+  const int nk = a.K / kI8StepBytes;
+  issue(0);
+  commit(0);
+  if (nk > 1) issue(1);
+  __syncthreads();
+  for (int it = 0; it < nk; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nk) commit(buf ^ 1);
+    if (it + 2 < nk) issue(it + 2);
+    const char* ximg = sm[buf] + (16 * MT * wm + n) * kI8StepBytes;
+    const char* wimg = sm[buf] + kXBytes + (16 * NT * wn + n) * kI8StepBytes;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {          // two 64-deep k-steps per staged step; lane (n, c) holds k = 16 c .. 16 c + 15 of its row
+      const int off = 16 * ((4 * ks + c) ^ (n & 7));   // rows 16 t + n: (row & 7) = (n & 7)
+      i32x4 xf[MT], wf[NT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) xf[t] = __builtin_bit_cast(i32x4, ld16(ximg + 16 * t * kI8StepBytes + off));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wf[t] = __builtin_bit_cast(i32x4, ld16(wimg + 16 * t * kI8StepBytes + off));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xf[mt], wf[nt], acc[mt][nt], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // acc[mt][nt][r] = C[row 16 MT wm + 16 mt + 4c + r][col 16 NT wn + 16 nt + n]: scales and bias on the exact int32 sums,
+  // one rounding, staged through LDS (the operand images are free) 128 rows at a time and stored as whole rows
+  constexpr int kCPitch = 2 * BN + 16;
+  constexpr int kStageRows = BM < 128 ? BM : 128;
+  static_assert(kStageRows * kCPitch <= 2 * (kXBytes + kWBytes), "output staging fits the operand images");
+  static_assert(kStageRows % (16 * MT) == 0 && BM % kStageRows == 0, "a wave's rows fall into one staging pass");
+  char* cst = &sm[0][0];
+  float wsc[NT], bia[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = col0 + 16 * NT * wn + 16 * nt + n;
+    wsc[nt] = a.w_scale[col];
+    bia[nt] = a.bias != nullptr ? bf2f(static_cast<const uint16_t*>(a.bias)[col]) : 0.f;
+  }
+#pragma unroll
+  for (int half = 0; half < BM / kStageRows; ++half) {
+    if ((16 * MT * wm) / kStageRows == half) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * MT * wm + 16 * mt + 4 * c + r;
+          const float xs = a.x_scale[min(row0 + row, a.M - 1)];
+          uint16_t* crow = reinterpret_cast<uint16_t*>(cst + (row - kStageRows * half) * kCPitch) + 16 * NT * wn + n;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) crow[16 * nt] = f2bf(w8a8_scaled(acc[mt][nt][r], xs, wsc[nt], bia[nt]));
+        }
+    }
+    __syncthreads();
+    constexpr int kChunksPerRow = BN / 8;
+    for (int id = tid; id < kStageRows * kChunksPerRow; id += kThreads) {
+      const int row = id / kChunksPerRow, ch = id % kChunksPerRow;
+      const int grow = row0 + kStageRows * half + row;
+      if (grow < a.M)
+        st16(static_cast<uint16_t*>(a.out) + static_cast<int64_t>(grow) * a.out_stride_m + col0 + 8 * ch, ld16(cst + row * kCPitch + 16 * ch));
+    }
+    if (half + 1 < BM / kStageRows) __syncthreads();
+  }
+}
+
+// Rows from which the tiled kernel runs, and whether the shape fits it (K in whole 128-deep steps, N in whole tiles).
+constexpr int kW8A8TiledFromRows = 129;
+static bool w8a8_tiled_fits(int M, int K, int N) { return M >= kW8A8TiledFromRows && K % kI8StepBytes == 0 && N % 128 == 0; }
+
 }  // namespace hymeta
 
 using namespace hymeta;
@@ -1114,6 +1252,22 @@ static int w8a8_gemm_impl(const hymeta_w8a8_gemm_args* args, hymeta_stream_t str
       }
       return stream_gemm_launch<true>(sa, plan, s, deferred != nullptr);
     }
+  }
+  // prefill-sized row counts: the tiled kernel (scales in its epilogue), behind the per-token quantisation when x is given
+  static const int tiled_from = [] { const char* e = getenv("HYMETA_W8A8_TILED_FROM"); return e ? atoi(e) : kW8A8TiledFromRows; }();
+  if (a.split_k <= 0 && a.M >= tiled_from && w8a8_tiled_fits(a.M, a.K, a.N)) {
+    hipStream_t s = begin_launches(stream);
+    if (a.x != nullptr) {
+      hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
+      if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+    }
+    // 256 x 256 tiles (8 waves of 64 x 128) once they fill the chip, 128 x 128 (4 waves of 64 x 64) below
+    const int64_t big_tiles = static_cast<int64_t>(a.N / 256) * ((a.M + 255) / 256);
+    if (a.N % 256 == 0 && big_tiles >= 192)
+      hipLaunchKernelGGL((w8a8_tiled_kernel<256, 256, 4, 2>), dim3(a.N / 256, (a.M + 255) / 256), dim3(512), 0, s, a);
+    else
+      hipLaunchKernelGGL((w8a8_tiled_kernel<128, 128, 2, 2>), dim3(a.N / 128, (a.M + 127) / 128), dim3(256), 0, s, a);
+    return launch_status();
   }
   const int ksteps = a.K / 64;
   int splits = a.split_k > 0 ? a.split_k : (a.workspace != nullptr ? hymeta_w8a8_gemm_split_k(a.M, a.K, a.N) : 1);

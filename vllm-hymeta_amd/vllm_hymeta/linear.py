@@ -24,7 +24,22 @@ W8A8_LIBRARY_ROWS = 128
 
 
 def w8a8_use_library(rows: int, in_features: int, out_features: int) -> bool:
-    return rows > W8A8_LIBRARY_ROWS
+    """Above the streaming kernel's rows a W8A8 linear is either ONE tiled int8-MFMA launch with the scales in its
+    epilogue (``hymeta_w8a8_gemm``: K in whole 128-deep steps, N in whole 128-column tiles) or quantise -> library int8
+    GEMM -> scale (three launches, the int32 sums through memory); both give the same bits.  The tiled kernel takes the
+    shapes where it was measured ahead (7B shapes, us, tiled / library): gate_up 70 / 72 at 129 rows, 68 / 101 at 256,
+    331 / 412 at 2048, 4400 / 5568 at 32768; qkv 67 / 71 at 2048, 601 / 736 at 32768; o 51 / 57 and 481 / 594; the deep
+    narrow down projection (K = 5.3 N: few tiles, long K loops) 587 / 683 at 8192 and level at 32768 -- and leaves the
+    rest to the library (qkv / o below 1024 rows, down below 4096: 210 / 189 at 2048)."""
+    if rows <= W8A8_LIBRARY_ROWS:
+        return False
+    if in_features % 128 != 0 or out_features % 128 != 0:
+        return True
+    if out_features >= 16384:
+        return False
+    if in_features >= 4 * out_features:
+        return rows < 4096
+    return rows < 1024
 
 
 class HymetaLinear(torch.nn.Module):
