@@ -628,6 +628,14 @@ int hymeta_gptq_dequant(const int32_t* qweight, const int32_t* qzeros, const voi
                         int32_t K, int32_t N, int32_t bits, int32_t group_size, int32_t scales_dtype,
                         int32_t zero_offset, hymeta_stream_t stream);
 
+/* The same expansion written transposed: out bf16 [N, K] = w[k, n], the layout of a torch Linear weight (so that
+ * y = F.linear(x, out)), which the library bf16 GEMM runs faster at prefill-sized M than the [K, N] one.  Needs
+ * N % 64 == 0 and K % (32 * (32 / bits)) == 0 (K % 256 for 4-bit, K % 128 for 8-bit); anything else is
+ * HYMETA_ERR_UNSUPPORTED and the caller uses hymeta_gptq_dequant. */
+int hymeta_gptq_dequant_nk(const int32_t* qweight, const int32_t* qzeros, const void* scales, void* out,
+                           int32_t K, int32_t N, int32_t bits, int32_t group_size, int32_t scales_dtype,
+                           int32_t zero_offset, hymeta_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * bf16 linear for decode-sized batches (M <= 128; 65 to 128 rows need K % 64 == 0, K >= 256 and split_k == 0):
  * out = bf16(x W^T + bias), fp32 accumulation,

@@ -104,6 +104,34 @@ def test_gptq_dequant_is_the_rounded_oracle_matrix(bits, group, scales_dtype):
     torch.cuda.synchronize()
     ref = gptq_dequant_ref(qw, qz, scales, bits, group).float().to(torch.bfloat16)   # s and (q - z) are exact in fp32
     assert torch.equal(w.cpu(), ref)
+    # the transposed form (torch Linear layout, what the prefill-sized linear feeds the library GEMM): the same bits
+    assert hip_ops.gptq_dequant_nk_supported(qw, bits)
+    wt = hip_ops.gptq_dequant(qw.cuda(), qz.cuda(), scales.cuda(), bits, group, transposed=True)
+    torch.cuda.synchronize()
+    assert wt.shape == (N, K) and torch.equal(wt.cpu(), ref.t())
+
+
+def test_gptq_transposed_expansion_covers_whole_tiles_only():
+    """64 columns x 32 packed rows a tile: other shapes are refused by the entry point and the linear keeps the [K, N]
+    expansion for them (same result either way)."""
+    from oracle.quant import gptq_gemm_ref
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta import linear as L
+
+    K, N = 384, 96                                 # K % 256 != 0 and N % 64 != 0
+    qw, qz, scales = _gptq_problem(9, K, N, 4, 128, torch.float16)
+    assert not hip_ops.gptq_dequant_nk_supported(qw, 4)
+    with pytest.raises(ValueError):
+        hip_ops.gptq_dequant(qw.cuda(), qz.cuda(), scales.cuda(), 4, 128, transposed=True)
+    out_nk = torch.empty(N, K, dtype=torch.bfloat16, device="cuda")
+    from vllm_hymeta import _C
+    assert _C.load().hymeta_gptq_dequant_nk(qw.cuda().data_ptr(), qz.cuda().data_ptr(), scales.cuda().data_ptr(), out_nk.data_ptr(),
+                                            K, N, 4, 128, _C.HYMETA_F16, 1, None) == -2
+    lin = L.HymetaLinear.from_gptq(qw.cuda(), qz.cuda(), scales.cuda(), 4, 128)
+    x = randn_bf16(gen(10), L.GPTQ_EXPAND_ROWS + 3, K)
+    out = lin(x.cuda())
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), gptq_gemm_ref(x, qw, qz, scales, 4, 128, None), "gptq [K, N] expansion", rel=8e-3)
 
 
 @pytest.mark.parametrize("scales_dtype,zero_offset", [(torch.float16, 1), (torch.bfloat16, 0)])

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Library bf16 GEMM (F.linear) at the 7B shapes for prefill-sized and 129..256-row batches, cold weights, with and
-without PyTorch's TunableOp (env PYTORCH_TUNABLEOP_ENABLED=1 set by the caller).  Prints us and TFLOP/s per shape."""
+without PyTorch's TunableOp (env PYTORCH_TUNABLEOP_ENABLED=1 set by the caller).  Prints us and TFLOP/s per shape.
+NN=1 stores the weights [in, out] and runs ``matmul(x, w)`` (the layout a GPTQ checkpoint expands to) instead of
+``linear(x, w[out, in])``."""
 import os
 import sys
 import time
@@ -30,11 +32,15 @@ for M in ROWS:
     for name, K, N in SHAPES:
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)
         copies = 1 if M > 4096 else max(2, min(16, int(2.0e9 // (N * K * 2))))
-        ws = [torch.randn(N, K, device=dev).to(torch.bfloat16) for _ in range(copies)]
+        nn_layout = os.environ.get("NN") == "1"
+        ws = [torch.randn(*((K, N) if nn_layout else (N, K)), device=dev).to(torch.bfloat16) for _ in range(copies)]
 
         def run():
             for w in ws:
-                torch.nn.functional.linear(x, w)
+                if nn_layout:
+                    torch.matmul(x, w)
+                else:
+                    torch.nn.functional.linear(x, w)
 
         t = bench(run, 3 if M > 4096 else 5) / copies
         total += t

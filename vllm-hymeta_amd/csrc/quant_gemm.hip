@@ -679,6 +679,50 @@ __global__ __launch_bounds__(256) void gptq_dequant_kernel(const int32_t* __rest
   }
 }
 
+// The same expansion written as W^T: out[n][k], the layout of a torch Linear weight, which the library's bf16 GEMM
+// runs measurably faster at prefill-sized M than the [K, N] one (7B shapes, 32768 rows: 10.4 ms against 11.8 ms a
+// layer).  Workgroup = 64 columns x 32 packed rows: lane = column (256-byte row reads of the packed words), each
+// thread expands its words into an LDS tile [column][k], which then leaves as whole 32*PACK-element runs of one
+// output row (512 or 256 bytes).  Needs N % 64 == 0 and K % (32 * PACK) == 0.
+template <int BITS>
+__global__ __launch_bounds__(256) void gptq_dequant_nk_kernel(const int32_t* __restrict__ qweight, const int32_t* __restrict__ qzeros,
+                                                              const void* __restrict__ scales, uint16_t* __restrict__ out, int K, int N,
+                                                              int group_size, int scales_dtype, int zero_offset) {
+  constexpr int PACK = 32 / BITS;
+  constexpr int TK = 32 * PACK;                 // k values of a tile
+  constexpr int PITCH = TK * 2 + 16;            // bytes of an LDS row: 16-byte pad keeps the column-strided writes off one bank group
+  __shared__ __attribute__((aligned(16))) unsigned char tile[64 * PITCH];
+  const int n0 = blockIdx.x * 64, kp0 = blockIdx.y * 32;
+  const int lane_n = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int n = n0 + lane_n;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int kp = kp0 + sub + 4 * i;
+    const int g = kp * PACK / group_size;
+    const uint32_t qw = static_cast<uint32_t>(qweight[static_cast<int64_t>(kp) * N + n]);
+    const uint32_t zw = static_cast<uint32_t>(qzeros[static_cast<int64_t>(g) * (N / PACK) + n / PACK]);
+    const float sc = load_scale(scales, static_cast<int64_t>(g) * N + n, scales_dtype);
+    const float zf = static_cast<float>(((zw >> (BITS * (n % PACK))) & ((1u << BITS) - 1u)) + zero_offset);
+    uint32_t w[PACK / 2];
+#pragma unroll
+    for (int j = 0; j < PACK / 2; ++j) {
+      const float lo = sc * (static_cast<float>((qw >> (BITS * (2 * j))) & ((1u << BITS) - 1u)) - zf);
+      const float hi = sc * (static_cast<float>((qw >> (BITS * (2 * j + 1))) & ((1u << BITS) - 1u)) - zf);
+      w[j] = pack_bf16x2(lo, hi);
+    }
+    unsigned char* dst = tile + lane_n * PITCH + (sub + 4 * i) * (PACK * 2);
+    if constexpr (PACK == 8) *reinterpret_cast<u32x4*>(dst) = u32x4{w[0], w[1], w[2], w[3]};
+    else *reinterpret_cast<u32x2*>(dst) = u32x2{w[0], w[1]};
+  }
+  __syncthreads();
+  constexpr int CHUNKS = TK * 2 / 16;           // 16-byte pieces of one row of the tile
+  for (int c = threadIdx.x; c < 64 * CHUNKS; c += 256) {
+    const int row = c / CHUNKS, piece = c % CHUNKS;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * PITCH + piece * 16);
+    *reinterpret_cast<u32x4*>(out + static_cast<int64_t>(n0 + row) * K + static_cast<int64_t>(kp0) * PACK + piece * 8) = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // W8A8
 // ---------------------------------------------------------------------------------------------
@@ -1183,6 +1227,26 @@ extern "C" int hymeta_gptq_dequant(const int32_t* qweight, const int32_t* qzeros
   uint16_t* o = static_cast<uint16_t*>(out);
   if (bits == 4) hipLaunchKernelGGL(gptq_dequant_kernel<4>, grid, block, 0, s, qweight, qzeros, scales, o, K, N, group_size, scales_dtype, zero_offset);
   else hipLaunchKernelGGL(gptq_dequant_kernel<8>, grid, block, 0, s, qweight, qzeros, scales, o, K, N, group_size, scales_dtype, zero_offset);
+  return launch_status();
+}
+
+extern "C" int hymeta_gptq_dequant_nk(const int32_t* qweight, const int32_t* qzeros, const void* scales, void* out,
+                                      int32_t K, int32_t N, int32_t bits, int32_t group_size, int32_t scales_dtype,
+                                      int32_t zero_offset, hymeta_stream_t stream) {
+  if (!qweight || !qzeros || !scales || !out || K <= 0 || N <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (bits != 4 && bits != 8) return HYMETA_ERR_UNSUPPORTED;
+  const int pack = 32 / bits;
+  if (group_size <= 0 || group_size % pack != 0 || K % group_size != 0) return HYMETA_ERR_UNSUPPORTED;
+  if (N % 64 != 0 || K % (32 * pack) != 0) return HYMETA_ERR_UNSUPPORTED;
+  if (scales_dtype != HYMETA_F16 && scales_dtype != HYMETA_BF16) return HYMETA_ERR_UNSUPPORTED;
+  if (zero_offset != 0 && zero_offset != 1) return HYMETA_ERR_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(out) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  dim3 grid(static_cast<unsigned>(N / 64), static_cast<unsigned>(K / (32 * pack))), block(256);
+  if (grid.y > 65535u) return HYMETA_ERR_UNSUPPORTED;
+  hipStream_t s = begin_launches(stream);
+  uint16_t* o = static_cast<uint16_t*>(out);
+  if (bits == 4) hipLaunchKernelGGL(gptq_dequant_nk_kernel<4>, grid, block, 0, s, qweight, qzeros, scales, o, K, N, group_size, scales_dtype, zero_offset);
+  else hipLaunchKernelGGL(gptq_dequant_nk_kernel<8>, grid, block, 0, s, qweight, qzeros, scales, o, K, N, group_size, scales_dtype, zero_offset);
   return launch_status();
 }
 

@@ -294,6 +294,7 @@ _SIGNATURES = {
     "hymeta_gptq_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "hymeta_gptq_gemm": (C.c_int, [C.POINTER(GptqGemmArgs), _ptr]),
     "hymeta_gptq_dequant": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    "hymeta_gptq_dequant_nk": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "hymeta_bf16_gemm": (C.c_int, [C.POINTER(Bf16GemmArgs), _ptr]),
     "hymeta_bf16_gemm_silu_mul": (C.c_int, [C.POINTER(Bf16GemmArgs), _ptr]),
     "hymeta_bf16_gemm_f32out": (C.c_int, [C.POINTER(Bf16GemmArgs), _ptr]),

@@ -858,9 +858,16 @@ def gptq_gemm(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scal
     return out
 
 
+def gptq_dequant_nk_supported(qweight: torch.Tensor, bits: int) -> bool:
+    """The transposed expansion covers whole 64-column x 32-packed-row tiles."""
+    pack = 32 // bits
+    return qweight.shape[1] % 64 == 0 and (qweight.shape[0] * pack) % (32 * pack) == 0
+
+
 def gptq_dequant(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor, bits: int, group_size: int,
-                 zero_offset: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """GPTQ tensors -> bf16 weights [K, N] (so that y = x @ W)."""
+                 zero_offset: int = 1, out: Optional[torch.Tensor] = None, transposed: bool = False) -> torch.Tensor:
+    """GPTQ tensors -> bf16 weights [K, N] (so that y = x @ W), or with ``transposed`` [N, K] as torch stores a Linear
+    weight (so that y = F.linear(x, W)): the layout the library GEMM runs faster at prefill-sized batches."""
     _dev(qweight, qzeros, scales, out)
     pack = 32 // bits
     K, N = qweight.shape[0] * pack, qweight.shape[1]
@@ -869,10 +876,17 @@ def gptq_dequant(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tens
              "qzeros must be contiguous int32 [K/group, N/pack]")
     _require(scales.dtype in (torch.float16, torch.bfloat16) and scales.is_contiguous()
              and scales.shape == (K // group_size, N), "scales must be contiguous fp16/bf16 [K/group, N]")
+    shape = (N, K) if transposed else (K, N)
     if out is None:
-        out = torch.empty(K, N, dtype=torch.bfloat16, device=qweight.device)
-    _require(out.shape == (K, N) and out.dtype == torch.bfloat16 and out.is_contiguous(), "out must be contiguous bf16 [K, N]")
+        out = torch.empty(shape, dtype=torch.bfloat16, device=qweight.device)
+    _require(out.shape == shape and out.dtype == torch.bfloat16 and out.is_contiguous(),
+             "out must be contiguous bf16 [K, N] ([N, K] when transposed)")
     sd = _C.HYMETA_F16 if scales.dtype == torch.float16 else _C.HYMETA_BF16
+    if transposed:
+        _require(gptq_dequant_nk_supported(qweight, bits), "transposed expansion needs N % 64 == 0 and K % (32 * pack) == 0")
+        _C.check(_C.load().hymeta_gptq_dequant_nk(_p(qweight), _p(qzeros), _p(scales), _p(out), K, N, bits, group_size, sd,
+                                                  zero_offset, _stream(qweight)), "hymeta_gptq_dequant_nk")
+        return out
     _C.check(_C.load().hymeta_gptq_dequant(_p(qweight), _p(qzeros), _p(scales), _p(out), K, N, bits, group_size, sd,
                                            zero_offset, _stream(qweight)), "hymeta_gptq_dequant")
     return out

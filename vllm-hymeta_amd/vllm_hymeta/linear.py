@@ -102,9 +102,13 @@ class HymetaLinear(torch.nn.Module):
             return torch.nn.functional.linear(x, self.weight, self.bias)
         if self.kind == "gptq":
             if x.shape[0] > GPTQ_EXPAND_ROWS:
-                # prefill regime: expand the weights once, plain library bf16 GEMM on them
+                # prefill regime: expand the weights once, plain library bf16 GEMM on them -- as W^T [N, K] where the
+                # expansion kernel's tiles cover the matrix, the layout the library runs 12 % faster at 32768 rows
+                nk = hip_ops.gptq_dequant_nk_supported(self.qweight, self.meta["bits"])
                 w = hip_ops.gptq_dequant(self.qweight, self.qzeros, self.scales, self.meta["bits"],
-                                         self.meta["group_size"], zero_offset=self.meta.get("zero_offset", 1))
+                                         self.meta["group_size"], zero_offset=self.meta.get("zero_offset", 1), transposed=nk)
+                if nk:
+                    return torch.nn.functional.linear(x, w, self.bias)
                 y = torch.matmul(x, w)
                 return y if self.bias is None else y.add_(self.bias)
             return hip_ops.gptq_gemm(x, self.qweight, self.qzeros, self.scales, self.meta["bits"],
