@@ -249,6 +249,27 @@ def test_w8a8_linear_prefill_regime_both_paths_give_the_same_bits(M, K, N):
         assert_bf16_close(out.cpu(), w8a8_gemm_ref(x, wq, ws, bias), f"w8a8 linear M={M}", rel=6e-3)
 
 
+@pytest.mark.parametrize("M,K,N", [(129, 512, 256), (300, 512, 37888), (1000, 1024, 1024), (2048, 3584, 9472), (257, 640, 384)])
+def test_w8a8_gate_up_with_the_activation_in_the_tiled_epilogue(M, K, N):
+    """Above the streaming kernel's rows the fused gate / up projection of a W8A8 MLP runs the tiled kernel with gate and
+    up rows of the same output columns in one tile and silu(gate) * up in its store pass (128 x 128 and 256 x 256 tiles,
+    ragged row counts, a 70B TP=4 shard's width): the bits of the linear followed by silu_and_mul."""
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta.linear import HymetaLinear
+
+    g_ = gen(31)
+    x = randn_bf16(g_, M, K).cuda()
+    wq = torch.randint(-127, 128, (N, K), generator=g_, dtype=torch.int8).cuda()
+    ws = (torch.rand(N, generator=g_) * 0.004 + 0.0005).cuda()
+    lin = HymetaLinear.from_w8a8(wq, ws)
+    assert hip_ops.gemm_silu_mul_supported(x, wq)
+    fused = lin.forward_silu_mul(x)
+    two = hip_ops.silu_and_mul(lin(x))
+    torch.cuda.synchronize()
+    assert fused.shape == (M, N // 2) and torch.equal(fused, two)
+    assert float(fused.float().abs().max()) > 0.01
+
+
 def test_w8a8_path_choice_above_the_streaming_rows():
     from vllm_hymeta.linear import w8a8_use_library
 

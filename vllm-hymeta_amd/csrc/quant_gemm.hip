@@ -903,10 +903,14 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(hymeta_w8a8_gemm_args a,
 // epilogue applies the scales to the exact int32 sums with the rounding rule of every W8A8 kernel here (w8a8_scaled),
 // stages the bf16 tile through LDS and stores whole rows.  grid = (N / BN, ceil(M / BM)), column tiles fastest: the
 // workgroups that share a row tile of x run together.
+// GATED (a fused gate / up projection, weight rows = gate, then up): the tile's first BN / 2 weight rows are gate rows
+// and the other half the up rows of the same output columns, so the staged bf16 tile holds both factors of BN / 2 output
+// columns side by side and the store pass writes silu(bf16 gate) * bf16 up -- the bits of this kernel followed by
+// silu_and_mul, without the [M, N] intermediate (2.5 GB written and read back at 32768 rows of the 7B MLP).
 // ---------------------------------------------------------------------------------------------
 constexpr int kI8StepBytes = 128;                  // bytes of one staged row = 128 k
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool GATED>
 __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void w8a8_tiled_kernel(hymeta_w8a8_gemm_args a) {
   constexpr int kThreads = 64 * WM * WN;
   constexpr int MT = BM / WM / 16, NT = BN / WN / 16;       // 16 x 16 tiles per wave
@@ -920,8 +924,10 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void w8a8_tiled
   const int lane = tid & 63;
   const int c = lane >> 4, n = lane & 15;
   const int wm = wave / WN, wn = wave % WN;
-  const int col0 = blockIdx.x * BN;
+  const int col0 = blockIdx.x * (GATED ? BN / 2 : BN);      // first output column of the tile
   const int row0 = blockIdx.y * BM;
+  // weight row (= column of x W^T) behind column t of the tile
+  auto wrow = [&](int t) { return GATED ? (t < BN / 2 ? col0 + t : a.N / 2 + col0 + (t - BN / 2)) : col0 + t; };
 
   // staging role: thread = 16-byte chunk sc of rows sr + kRowsPerPass i of both operand tiles (rows past M re-read the last row)
   const int sr = tid >> 3, sc = tid & 7;
@@ -931,7 +937,7 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void w8a8_tiled
   for (int i = 0; i < XP; ++i) xp[i] = a.xq + static_cast<int64_t>(min(row0 + sr + kRowsPerPass * i, a.M - 1)) * a.K + 16 * sc;
 #pragma unroll
   for (int i = 0; i < WP; ++i)
-    wp[i] = static_cast<const int8_t*>(a.qweight) + static_cast<int64_t>(col0 + sr + kRowsPerPass * i) * a.K + 16 * sc;
+    wp[i] = static_cast<const int8_t*>(a.qweight) + static_cast<int64_t>(wrow(sr + kRowsPerPass * i)) * a.K + 16 * sc;
   u32x4 xr[XP], wr[WP];
   auto issue = [&](int it) {
 #pragma unroll
@@ -995,7 +1001,7 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void w8a8_tiled
   float wsc[NT], bia[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int col = col0 + 16 * NT * wn + 16 * nt + n;
+    const int col = wrow(16 * NT * wn + 16 * nt + n);
     wsc[nt] = a.w_scale[col];
     bia[nt] = a.bias != nullptr ? bf2f(static_cast<const uint16_t*>(a.bias)[col]) : 0.f;
   }
@@ -1014,12 +1020,21 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void w8a8_tiled
         }
     }
     __syncthreads();
-    constexpr int kChunksPerRow = BN / 8;
+    constexpr int kChunksPerRow = (GATED ? BN / 2 : BN) / 8;      // 8-column pieces of a row of the output tile
     for (int id = tid; id < kStageRows * kChunksPerRow; id += kThreads) {
       const int row = id / kChunksPerRow, ch = id % kChunksPerRow;
       const int grow = row0 + kStageRows * half + row;
-      if (grow < a.M)
-        st16(static_cast<uint16_t*>(a.out) + static_cast<int64_t>(grow) * a.out_stride_m + col0 + 8 * ch, ld16(cst + row * kCPitch + 16 * ch));
+      if (grow >= a.M) continue;
+      u32x4 o = ld16(cst + row * kCPitch + 16 * ch);
+      if constexpr (GATED) {
+        const u32x4 up = ld16(cst + row * kCPitch + BN + 16 * ch);    // the up factors sit BN / 2 columns on
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g0 = lo_bf(o[e]), g1 = hi_bf(o[e]);
+          o[e] = pack_bf16x2(g0 * sigmoidf(g0) * lo_bf(up[e]), g1 * sigmoidf(g1) * hi_bf(up[e]));
+        }
+      }
+      st16(static_cast<uint16_t*>(a.out) + static_cast<int64_t>(grow) * a.out_stride_m + col0 + 8 * ch, o);
     }
     if (half + 1 < BM / kStageRows) __syncthreads();
   }
@@ -1028,6 +1043,16 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void w8a8_tiled
 // Rows from which the tiled kernel runs, and whether the shape fits it (K in whole 128-deep steps, N in whole tiles).
 constexpr int kW8A8TiledFromRows = 129;
 static bool w8a8_tiled_fits(int M, int K, int N) { return M >= kW8A8TiledFromRows && K % kI8StepBytes == 0 && N % 128 == 0; }
+
+// 256 x 256 tiles (8 waves of 64 x 128) once they fill the chip, 128 x 128 (4 waves of 64 x 64) below
+template <bool GATED>
+static void w8a8_tiled_launch(const hymeta_w8a8_gemm_args& a, hipStream_t s) {
+  const int64_t big_tiles = static_cast<int64_t>(a.N / 256) * ((a.M + 255) / 256);
+  if (a.N % 256 == 0 && big_tiles >= 192)
+    hipLaunchKernelGGL((w8a8_tiled_kernel<256, 256, 4, 2, GATED>), dim3(a.N / 256, (a.M + 255) / 256), dim3(512), 0, s, a);
+  else
+    hipLaunchKernelGGL((w8a8_tiled_kernel<128, 128, 2, 2, GATED>), dim3(a.N / 128, (a.M + 127) / 128), dim3(256), 0, s, a);
+}
 
 }  // namespace hymeta
 
@@ -1325,12 +1350,7 @@ static int w8a8_gemm_impl(const hymeta_w8a8_gemm_args* args, hymeta_stream_t str
       hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
       if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
     }
-    // 256 x 256 tiles (8 waves of 64 x 128) once they fill the chip, 128 x 128 (4 waves of 64 x 64) below
-    const int64_t big_tiles = static_cast<int64_t>(a.N / 256) * ((a.M + 255) / 256);
-    if (a.N % 256 == 0 && big_tiles >= 192)
-      hipLaunchKernelGGL((w8a8_tiled_kernel<256, 256, 4, 2>), dim3(a.N / 256, (a.M + 255) / 256), dim3(512), 0, s, a);
-    else
-      hipLaunchKernelGGL((w8a8_tiled_kernel<128, 128, 2, 2>), dim3(a.N / 128, (a.M + 127) / 128), dim3(256), 0, s, a);
+    w8a8_tiled_launch<false>(a, s);
     return launch_status();
   }
   const int ksteps = a.K / 64;
@@ -1397,8 +1417,9 @@ extern "C" int hymeta_w8a8_gemm_deferred(const hymeta_w8a8_gemm_args* args, hyme
 }
 
 // W8A8 gate/up projection with the activation in the epilogue (see hymeta_bf16_gemm_silu_mul): quantises x per row, then
-// out [M, N / 2] = silu(gate) * up from the int8 sums.  Shapes the streaming kernel does not take whole are
-// HYMETA_ERR_UNSUPPORTED (the caller runs hymeta_w8a8_gemm + hymeta_silu_and_mul: same bits).
+// out [M, N / 2] = silu(gate) * up from the int8 sums.  Decode-sized batches run the streaming kernel, larger ones the
+// tiled kernel (K % 128 == 0, N % 128 == 0); other shapes are HYMETA_ERR_UNSUPPORTED (the caller runs hymeta_w8a8_gemm +
+// hymeta_silu_and_mul: same bits).
 extern "C" int hymeta_w8a8_gemm_silu_mul(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream) {
   using namespace hymeta;
   if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
@@ -1411,11 +1432,16 @@ extern "C" int hymeta_w8a8_gemm_silu_mul(const hymeta_w8a8_gemm_args* args, hyme
        reinterpret_cast<uintptr_t>(a.xq) | reinterpret_cast<uintptr_t>(a.w_scale)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
   StreamPlan plan;
-  if (!stream_gemm_plan_gated(a.M, a.K, a.N, &plan)) return HYMETA_ERR_UNSUPPORTED;
+  const bool streaming = stream_gemm_plan_gated(a.M, a.K, a.N, &plan);
+  if (!streaming && !w8a8_tiled_fits(a.M, a.K, a.N)) return HYMETA_ERR_UNSUPPORTED;
   hipStream_t s = begin_launches(stream);
   if (a.x != nullptr) {
     hipLaunchKernelGGL(w8a8_quant_kernel, dim3(a.M), dim3(256), 0, s, a);
     if (hipGetLastError() != hipSuccess) return HYMETA_ERR_LAUNCH;
+  }
+  if (!streaming) {
+    w8a8_tiled_launch<true>(a, s);
+    return launch_status();
   }
   StreamArgs sa = {};
   sa.x = reinterpret_cast<const char*>(a.xq), sa.w = reinterpret_cast<const char*>(a.qweight);

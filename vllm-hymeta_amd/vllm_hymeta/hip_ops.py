@@ -1048,10 +1048,11 @@ def w8a8_gemm(x: torch.Tensor, qweight: torch.Tensor, w_scale: torch.Tensor,
 
 
 def gemm_silu_mul_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
-    """Shapes the gate/up projection with the activation in its epilogue takes: decode-sized batches of a bf16 or
-    int8 ``[2 I, K]`` weight (gate rows, then up rows)."""
+    """Shapes the gate/up projection with the activation in its epilogue takes: decode-sized batches of a bf16
+    ``[2 I, K]`` weight (gate rows, then up rows), any batch of an int8 one."""
     esize = 1 if weight.dtype == torch.int8 else 2
-    return (x.dim() == 2 and 0 < x.shape[0] <= BF16_GEMM_MAX_ROWS and x.is_cuda and x.dtype == torch.bfloat16
+    rows = BF16_GEMM_MAX_ROWS if weight.dtype == torch.bfloat16 else 1 << 30      # int8: the tiled kernel above the streaming rows
+    return (x.dim() == 2 and 0 < x.shape[0] <= rows and x.is_cuda and x.dtype == torch.bfloat16
             and weight.dtype in (torch.bfloat16, torch.int8) and x.stride(1) == 1 and weight.is_contiguous()
             and (weight.shape[1] * esize) % 128 == 0 and weight.shape[1] * esize >= 512 and weight.shape[0] % 128 == 0
             and x.stride(0) % 8 == 0)
@@ -1059,8 +1060,8 @@ def gemm_silu_mul_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 def gemm_silu_mul(x: torch.Tensor, weight: torch.Tensor, w_scale: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``silu(x gate^T) * (x up^T)`` in one launch: x bf16 [M <= 128, K]; weight [2 I, K] bf16, or int8 with ``w_scale``
-    fp32 [2 I] (dynamic per-token int8 activations) -> bf16 [M, I].  Bit for bit the linear followed by
+    """``silu(x gate^T) * (x up^T)`` in one launch: x bf16 [M, K]; weight [2 I, K] bf16 (M <= 128), or int8 with ``w_scale``
+    fp32 [2 I] (dynamic per-token int8 activations; any M) -> bf16 [M, I].  Bit for bit the linear followed by
     ``silu_and_mul``."""
     _dev(x, weight, w_scale, out)
     M, K = x.shape
