@@ -600,12 +600,12 @@ def cpu_baseline(args):
 
 
 # --------------------------------------------------------------------------- main (N = 1)
-def read_traffic(B, ctx):
+def read_traffic(B, ctx, quant):
     tpath = os.path.join(ROOT, "profiles", "traffic_model_decode.json")
     if os.path.exists(tpath):
         try:
             rec = json.load(open(tpath))
-            if rec.get("batch") == B and rec.get("ctx") == ctx:
+            if rec.get("batch") == B and rec.get("ctx") == ctx and rec.get("linears", "bf16") == quant:
                 return rec.get("hbm_bytes_per_step")
         except Exception:
             pass
@@ -667,10 +667,10 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": read_traffic(B, args.ctx),
+            "traffic": read_traffic(B, args.ctx, args.quant),
             "traffic_source": "profiles/traffic_model_decode.json: FETCH_SIZE / WRITE_SIZE counter passes (rocprofv3 --pmc, separate runs, "
                               "tools/profile_model_step.sh) over this command on an earlier run of this tree; NOT collected by this run "
-                              "(null when no recorded pass matches this batch and context)",
+                              "(null when no recorded pass matches this batch, context and weight format)",
             "algorithmic_bytes_per_launch": int(step_bytes),
             "linear_weight_bytes": linear_weight_bytes(args.quant),
             "attention_bytes": int(attention_bytes(B, args.ctx, state_heads=state_heads)),

@@ -36,7 +36,7 @@ def main(fetch_dir, write_dir, out):
         wr = w.get(k, [0, 0.0])[1] * 1024 / execs
         total += rd + wr
         rows.append({"kernel": k, "launches_per_step": round(f[k][0] / execs, 2), "read_bytes_per_step": int(rd), "write_bytes_per_step": int(wr)})
-    rec = {"batch": 64, "ctx": 8192, "step_executions_counted": execs, "hbm_bytes_per_step": int(total),
+    rec = {"batch": 64, "ctx": 8192, "linears": os.environ.get("QUANT", "bf16"), "step_executions_counted": execs, "hbm_bytes_per_step": int(total),
            "correction": "FETCH_SIZE (KiB) doubled for gfx950 wide coalesced reads; WRITE_SIZE (KiB) as read",
            "kernels": [r for r in rows if r["read_bytes_per_step"] + r["write_bytes_per_step"] > (1 << 20)]}
     json.dump(rec, open(out, "w"), indent=1)
