@@ -56,7 +56,7 @@ enum hymeta_status {
   HYMETA_ERR_SCRATCH_LIMIT = -5 /* an allocation-free entry point was asked for more than its fixed scratch holds */
 };
 
-enum hymeta_dtype { HYMETA_BF16 = 0, HYMETA_F32 = 1, HYMETA_F16 = 2 };
+enum hymeta_dtype { HYMETA_BF16 = 0, HYMETA_F32 = 1, HYMETA_F16 = 2, HYMETA_I8 = 3 };
 
 /* Fused gate prologue applied to the raw projections before the recurrence. */
 enum hymeta_gate_mode {
@@ -889,15 +889,33 @@ typedef struct hymeta_moe_gemm_args {
   const int32_t* combine_tokens;
   const void* combine_shared;
   int64_t combine_shared_stride_m;
+  /* W8A8 experts (a compressed-tensors "W8A8" checkpoint as hf_model/quant_w8a8.py:121-132 writes it quantises the
+   * experts' Linear layers too; executed in the reference by vLLM's int8 fused_moe -- third-party arithmetic, parity
+   * unpinned): operand_dtype = HYMETA_I8, x = int8 rows (hymeta_w8a8_quantize of the tokens for the first GEMM,
+   * hymeta_silu_and_mul_int8 for the second), x_scale fp32 per SOURCE row (indexed like x), weights int8 [experts, N, K],
+   * w_scale fp32 [experts, N].  out = bf16( (sum_k xq wq) * x_scale[row] * w_scale[e, n] (* row_scale) ): exact int32
+   * sums, scales applied once.  K % 64 == 0; strides in elements, multiples of 16.  HYMETA_BF16 (0): the fields are
+   * ignored. */
+  int32_t operand_dtype;
+  const float* x_scale;
+  const float* w_scale;
 } hymeta_moe_gemm_args;
 
 int hymeta_moe_gemm(const hymeta_moe_gemm_args* args, hymeta_stream_t stream);
-/* 1 when hymeta_moe_gemm runs a problem of these sizes in the kernel that has the fused combine. */
+/* 1 when hymeta_moe_gemm runs a problem of these sizes in the kernel that has the fused combine (K in bf16 elements:
+ * pass K / 2 for int8 operands, the choice goes by the bytes of a row). */
 int hymeta_moe_gemm_fuses(int32_t max_rows, int32_t experts, int32_t K, int32_t N);
 
 /* num_rows_dev: optional device count of the rows in use (e.g. expert_offsets + E); NULL: num_rows. */
 int hymeta_silu_and_mul(const void* in, void* out, const int32_t* num_rows_dev, int32_t num_rows,
                         int32_t inter, int64_t in_stride, int64_t out_stride, hymeta_stream_t stream);
+
+/* The same activation followed by the row's dynamic int8 quantisation (the input of a W8A8 down projection): the bf16
+ * values hymeta_silu_and_mul would write are quantised as hymeta_w8a8_quantize quantises them (s = max|h| / 127,
+ * q = clamp(rint(h / s))) without passing through memory: out_q int8 [num_rows, inter] contiguous, out_scale fp32
+ * [num_rows].  inter % 8 == 0 and inter <= 24576; one workgroup per row. */
+int hymeta_silu_and_mul_int8(const void* in, int8_t* out_q, float* out_scale, const int32_t* num_rows_dev, int32_t num_rows,
+                             int32_t inter, int64_t in_stride, hymeta_stream_t stream);
 
 typedef struct hymeta_moe_combine_args {
   uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */

@@ -66,3 +66,32 @@ def moe_ref(x: torch.Tensor, router_logits: torch.Tensor, w13: torch.Tensor, w2:
     if shared is not None:
         out = (out.float() + shared.float()).to(x.dtype)
     return out
+
+
+def moe_w8a8_ref(x: torch.Tensor, router_logits: torch.Tensor, w13: torch.Tensor, w13_scale: torch.Tensor, w2: torch.Tensor,
+                 w2_scale: torch.Tensor, top_k: int = 1, renormalize: bool = False, shared: Optional[torch.Tensor] = None,
+                 local_experts: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """The block with W8A8 experts (a compressed-tensors W8A8 checkpoint quantises the experts' Linear layers too,
+    ``hf_model/quant_w8a8.py:121-132``; vLLM runs them through its int8 ``fused_moe``, third party: parity unpinned):
+    ``w13 int8 [E,2I,H]`` with ``w13_scale fp32 [E,2I]``, ``w2 int8 [E,H,I]`` with ``w2_scale fp32 [E,H]``.  Per (token,
+    choice): the token is quantised per row, ``h = bf16((xq W13q^T) s_x s_w13)``, ``a = silu_and_mul(h)`` is quantised per
+    row again, ``y = bf16(w * ((aq W2q^T) s_a s_w2))``; the rest as ``moe_ref``."""
+    from .quant import w8a8_gemm_ref
+
+    T, H = x.shape
+    ids, w = moe_route_ref(router_logits, top_k, renormalize)
+    out = torch.zeros(T, H, dtype=torch.float64)
+    lo, hi = local_experts if local_experts is not None else (0, w13.shape[0])
+    for t in range(T):
+        for j in range(top_k):
+            e = int(ids[t, j])
+            if not lo <= e < hi:
+                continue
+            h = w8a8_gemm_ref(x[t:t + 1], w13[e], w13_scale[e]).to(x.dtype)
+            a = silu_and_mul_ref(h)
+            y = (float(w[t, j]) * w8a8_gemm_ref(a, w2[e], w2_scale[e]))[0].to(x.dtype)
+            out[t] = (out[t] + y.double()).to(x.dtype).double() if j else y.double()
+    out = out.to(x.dtype)
+    if shared is not None:
+        out = (out.float() + shared.float()).to(x.dtype)
+    return out

@@ -229,6 +229,113 @@ def test_hymeta_moe_module_and_dense_mlp():
     assert_bf16_close(out.cpu().view(T, H), ref, "HymetaMoE + shared expert", rel=8e-3)
 
 
+def _w8a8_experts(seed, E, H, inter):
+    g_ = gen(seed)
+    w13 = torch.randint(-127, 128, (E, 2 * inter, H), generator=g_, dtype=torch.int8)
+    w2 = torch.randint(-127, 128, (E, H, inter), generator=g_, dtype=torch.int8)
+    s13 = (torch.rand(E, 2 * inter, generator=g_) + 0.5) * (H ** -0.5 / 73.0)     # int8 weights of unit-variance rows
+    s2 = (torch.rand(E, H, generator=g_) + 0.5) * (inter ** -0.5 / 73.0)
+    return w13, s13, w2, s2
+
+
+@pytest.mark.parametrize("inter", [320, 4736])
+def test_silu_and_mul_int8_is_the_activation_then_the_row_quantisation(inter):
+    from vllm_hymeta import hip_ops
+
+    x = randn_bf16(gen(3), 41, 2 * inter, scale=2.0).cuda()
+    q, sc = hip_ops.silu_and_mul_int8(x)
+    q2, sc2 = hip_ops.w8a8_quantize(hip_ops.silu_and_mul(x))
+    torch.cuda.synchronize()
+    assert torch.equal(q, q2) and torch.equal(sc, sc2)
+
+
+@pytest.mark.parametrize("T,E,top_k,renorm,with_shared,H,inter", [
+    (1, 16, 1, False, False, 256, 192),      # one decode token; the down GEMM's K = 192 is no whole number of 128-byte lines
+    (64, 16, 1, False, True, 1024, 384),     # decode batch: whole-line loads on both GEMMs, the combine inside the down GEMM
+    (64, 16, 1, False, True, 512, 320),      # the down GEMM on fragment-shaped loads
+    (100, 4, 2, True, False, 256, 128),      # two choices, renormalised, 64-row tiles
+    (300, 16, 1, False, True, 512, 384),     # prefill chunk: 128 x 128 tiles, ragged expert sizes
+    (900, 4, 1, False, True, 256, 256),      # many rows per expert: 256 x 256 tiles
+])
+def test_moe_forward_with_w8a8_experts(T, E, top_k, renorm, with_shared, H, inter):
+    """Experts as a compressed-tensors W8A8 checkpoint holds them (int8 weights, per-output-channel scales): tokens and
+    activated rows are quantised per row, the grouped GEMMs run on the int8 matrix cores with exact int32 sums and apply
+    the scales once -- every kernel form (fragment loads, whole-line loads, both tiles) against the CPU restatement."""
+    from oracle.moe import moe_w8a8_ref
+    from vllm_hymeta import hip_ops
+
+    x, gate_w, _, _, logits = _problem(5, T, H, 64, E)
+    w13, s13, w2, s2 = _w8a8_experts(6, E, H, inter)
+    shared = randn_bf16(gen(7), T, H) if with_shared else None
+    ref = moe_w8a8_ref(x, logits, w13, s13, w2, s2, top_k, renorm, shared)
+    args = (x.cuda(), logits.cuda(), w13.cuda(), w2.cuda())
+    kw = dict(top_k=top_k, renormalize=renorm, shared=None if shared is None else shared.cuda(), w13_scale=s13.cuda(), w2_scale=s2.cuda())
+    out, again = hip_ops.moe_forward(*args, **kw), hip_ops.moe_forward(*args, **kw)
+    torch.cuda.synchronize()
+    # Dynamic quantisation makes the comparison with an independent restatement loose by construction: when a last-bit
+    # difference in the activated row (sigmoid, fp32 against fp64 scaling) moves the row's maximum by one bf16 ulp, the
+    # row's scale moves with it and about a seventh of its int8 values change by one step -- as large as the
+    # quantisation noise itself (about 1 % of the output).  The sharp check is the staged one below.
+    assert_bf16_close(out.cpu(), ref, f"w8a8 moe T={T} E={E} k={top_k}", rel=2.5e-2, frac=0.08)
+    assert torch.equal(out, again)
+    if top_k == 1:
+        # the same chain with the kernels' own quantisation launches and exact integer products on the CPU in between:
+        # every rounding is the kernels' (float(acc) * s_x, * s_w, * routing weight, one bf16 rounding), so only the
+        # routing weight's last fp32 bit (softmax on the GPU against torch's) can differ
+        from oracle.moe import moe_route_ref
+        ids, wts = moe_route_ref(logits, 1, renorm)
+        xq, xs = hip_ops.w8a8_quantize(x.cuda())
+        xq, xs = xq.cpu(), xs.cpu()
+        staged = torch.zeros(T, H, dtype=torch.bfloat16)
+        for e in range(E):
+            rows = (ids[:, 0] == e).nonzero().flatten()
+            if rows.numel() == 0:
+                continue
+            acc1 = (xq[rows].long() @ w13[e].long().t()).float()
+            h = ((acc1 * xs[rows, None]) * s13[e][None, :]).to(torch.bfloat16)
+            aq, a_s = hip_ops.w8a8_quantize(hip_ops.silu_and_mul(h.cuda()))
+            acc2 = (aq.cpu().long() @ w2[e].long().t()).float()
+            staged[rows] = (((acc2 * a_s.cpu()[:, None]) * s2[e][None, :]) * wts[rows, 0:1]).to(torch.bfloat16)
+        if shared is not None:
+            staged = (staged.float() + shared.float()).to(torch.bfloat16)
+        assert_bf16_ulp(out.cpu(), staged, f"w8a8 moe staged T={T}", ulps=1)
+        assert float((out.cpu() != staged).float().mean()) < 0.01
+    if top_k == 1 and T <= 64:
+        saved = hip_ops.MOE_FUSE_DOWN
+        hip_ops.MOE_FUSE_DOWN = False
+        try:
+            plain = hip_ops.moe_forward(*args, **kw)
+        finally:
+            hip_ops.MOE_FUSE_DOWN = saved
+        torch.cuda.synchronize()
+        assert torch.equal(out, plain)          # the combine inside the down GEMM: the same bits
+
+
+def test_w8a8_experts_expert_parallel_shares():
+    """A rank that holds experts [lo, hi) only (compact int8 tensors and scales) gives the bits of the full tensors with
+    ``local_experts``; the shares add up to the whole block."""
+    from oracle.moe import moe_w8a8_ref
+    from vllm_hymeta import hip_ops
+
+    T, E, H, inter = 64, 8, 512, 256
+    x, gate_w, _, _, logits = _problem(8, T, H, 64, E)
+    w13, s13, w2, s2 = _w8a8_experts(9, E, H, inter)
+    xd, ld = x.cuda(), logits.cuda()
+    total = torch.zeros(T, H)
+    for lo, hi in ((0, 4), (4, 8)):
+        whole = hip_ops.moe_forward(xd, ld, w13.cuda(), w2.cuda(), local_experts=(lo, hi), w13_scale=s13.cuda(), w2_scale=s2.cuda())
+        held = hip_ops.moe_forward(xd, ld, w13[lo:hi].contiguous().cuda(), w2[lo:hi].contiguous().cuda(), local_experts=(lo, hi),
+                                   w13_scale=s13[lo:hi].contiguous().cuda(), w2_scale=s2[lo:hi].contiguous().cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(whole, held)
+        assert_bf16_close(whole.cpu(), moe_w8a8_ref(x, logits, w13, s13, w2, s2, local_experts=(lo, hi)), f"EP share {lo}", rel=2.5e-2,
+                          frac=0.08)
+        total += whole.float().cpu()
+    full = hip_ops.moe_forward(xd, ld, w13.cuda(), w2.cuda(), w13_scale=s13.cuda(), w2_scale=s2.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(total.to(torch.bfloat16), full.cpu())      # top-1: every token's row comes from exactly one share
+
+
 def test_moe_rejects_unsupported():
     from vllm_hymeta import hip_ops
     from vllm_hymeta._C import HymetaError

@@ -13,6 +13,7 @@
 //   combine  out[t] = sum_k y[pos[t,k]] (+ shared[t]), y weighted in the down GEMM; pairs of non-local experts
 //            (expert parallelism) carry pos = -1 and add nothing
 #include "common.h"
+#include "w8a8_quant.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -27,6 +28,42 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const 
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ bf16x8 as_frag(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+// The expert GEMMs in two operand types: bf16 (fp32 sums), or int8 weights with per-output-channel scales against
+// per-row int8 activations (W8A8: exact int32 sums, the scales applied once on the way out).  A 16-byte fragment piece
+// is 8 bf16 or 16 int8 k-values of one row, a 64-byte k-step one v_mfma_f32_16x16x32_bf16 or one v_mfma_i32_16x16x64_i8:
+// in BYTES the two walk the operands identically, which is how the kernels below are written.
+template <bool I8> struct MoeAcc { typedef f32x4 type; };
+template <> struct MoeAcc<true> { typedef i32x4 type; };
+
+template <bool I8>
+__device__ __forceinline__ typename MoeAcc<I8>::type moe_mma(const u32x4& a, const u32x4& b, const typename MoeAcc<I8>::type& c) {
+  if constexpr (I8) {
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a), as_frag(b), c, 0, 0, 0);
+  }
+}
+
+// source row of a slot (the token of a pair for the first GEMM, the slot itself for the second)
+__device__ __forceinline__ int moe_src_row(const hymeta_moe_gemm_args& a, int slot) {
+  return a.a_rows != nullptr ? a.a_rows[slot] / a.a_rows_div : slot;
+}
+
+// fp32 value of four summed columns of one row: the sums themselves, or (W8A8) the int32 sums times the row's and the
+// columns' scales with the rounding rule every W8A8 kernel here shares
+template <bool I8>
+__device__ __forceinline__ f32x4 moe_sums_to_f32(const hymeta_moe_gemm_args& a, const typename MoeAcc<I8>::type& s, int e, int slot,
+                                                 int col) {
+  if constexpr (I8) {
+    const float xs = a.x_scale[moe_src_row(a, slot)];
+    const f32x4 ws = *reinterpret_cast<const f32x4*>(a.w_scale + static_cast<int64_t>(e) * a.N + col);
+    return f32x4{w8a8_scaled(s[0], xs, ws[0], 0.f), w8a8_scaled(s[1], xs, ws[1], 0.f), w8a8_scaled(s[2], xs, ws[2], 0.f),
+                 w8a8_scaled(s[3], xs, ws[3], 0.f)};
+  } else {
+    return s;
+  }
+}
 
 }  // namespace
 
@@ -229,10 +266,12 @@ __global__ __launch_bounds__(256) void moe_router_kernel(hymeta_moe_router_args 
 // grid = (N / 64, local experts); rows of expert e = sorted slots [offsets[e], offsets[e + 1]).
 // Row tiles of 16 MT rows are walked inside the workgroup (weights of the 64 columns are re-read
 // per tile, from L2 after the first).
-template <int MT>
+template <int MT, bool I8>
 __global__ __launch_bounds__(256) void moe_gemm_kernel(hymeta_moe_gemm_args a) {
+  typedef typename MoeAcc<I8>::type acc_t;
+  constexpr int ES = I8 ? 1 : 2;                      // bytes per operand element
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* s_red = reinterpret_cast<float*>(smem_raw);  // [4 waves][16 MT rows][64 cols]
+  float* s_red = reinterpret_cast<float*>(smem_raw);  // [4 waves][16 MT rows][64 cols] of 4-byte sums
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -243,32 +282,32 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(hymeta_moe_gemm_args a) {
   const int row_lo = a.expert_offsets[e], row_hi = a.expert_offsets[e + 1];
   if (row_lo >= row_hi) return;
 
-  const uint16_t* wbase = reinterpret_cast<const uint16_t*>(a.weights) + static_cast<int64_t>(e) * a.w_stride_e;
-  const uint16_t* wrow[4];
+  const int64_t kb = static_cast<int64_t>(a.K) * ES;   // bytes of a weight row
+  const char* wbase = static_cast<const char*>(a.weights) + static_cast<int64_t>(e) * a.w_stride_e * ES;
+  const char* wrow[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) wrow[i] = wbase + static_cast<int64_t>(nb * kCols + 16 * i + n) * a.K + 8 * c;
-  const int ksteps = a.K / 32;
+  for (int i = 0; i < 4; ++i) wrow[i] = wbase + static_cast<int64_t>(nb * kCols + 16 * i + n) * kb + 16 * c;
+  const int ksteps = static_cast<int>(kb / 64);
   const int nsteps = wave < ksteps ? (ksteps - wave + 3) / 4 : 0;   // this wave's k-steps: wave, wave + 4, ...
   const int last = nsteps - 1;
 
   for (int r0 = row_lo; r0 < row_hi; r0 += 16 * MT) {
-    const uint16_t* xrow[MT];
+    const char* xrow[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int slot = min(r0 + 16 * mt + n, row_hi - 1);   // rows past the expert's end re-read its last row
-      const int src = a.a_rows != nullptr ? a.a_rows[slot] / a.a_rows_div : slot;
-      xrow[mt] = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(src) * a.x_stride_m + 8 * c;
+      xrow[mt] = static_cast<const char*>(a.x) + static_cast<int64_t>(moe_src_row(a, slot)) * a.x_stride_m * ES + 16 * c;
     }
-    f32x4 acc[MT][4];
+    acc_t acc[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[mt][i] = {0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 4; ++i) acc[mt][i] = acc_t{0, 0, 0, 0};
 
     // two register sets, unconditional loads (steps past the end re-read the last step)
     u32x4 wa[4], xa[MT], wb[4], xb[MT];
     auto load = [&](int s, u32x4 (&w)[4], u32x4 (&x)[MT]) {
-      const int k0 = 32 * (wave + 4 * min(s, last));
+      const int k0 = 64 * (wave + 4 * min(s, last));
 #pragma unroll
       for (int i = 0; i < 4; ++i) w[i] = ld16g(wrow[i] + k0);
 #pragma unroll
@@ -278,7 +317,7 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(hymeta_moe_gemm_args a) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[mt][i] = mfma16(as_frag(x[mt]), as_frag(w[i]), acc[mt][i]);
+        for (int i = 0; i < 4; ++i) acc[mt][i] = moe_mma<I8>(x[mt], w[i], acc[mt][i]);
     };
     if (nsteps > 0) {
       load(0, wa, xa);
@@ -298,8 +337,11 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(hymeta_moe_gemm_args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          s_red[(static_cast<size_t>(wave) * 16 * MT + 16 * mt + 4 * c + r) * kCols + 16 * i + n] = acc[mt][i][r];
+        for (int r = 0; r < 4; ++r) {
+          float v;
+          if constexpr (I8) v = __int_as_float(acc[mt][i][r]); else v = acc[mt][i][r];
+          s_red[(static_cast<size_t>(wave) * 16 * MT + 16 * mt + 4 * c + r) * kCols + 16 * i + n] = v;
+        }
     __syncthreads();
     const int cg = tid & 15;
     const int col = nb * kCols + 4 * cg;
@@ -308,10 +350,11 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(hymeta_moe_gemm_args a) {
       const int row = (tid >> 4) + 16 * j;
       const int slot = r0 + row;
       if (slot < row_hi) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        acc_t sum = acc_t{0, 0, 0, 0};
 #pragma unroll
         for (int w = 0; w < 4; ++w)
-          s += *reinterpret_cast<const f32x4*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kCols + 4 * cg);
+          sum += *reinterpret_cast<const acc_t*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kCols + 4 * cg);
+        f32x4 s = moe_sums_to_f32<I8>(a, sum, e, slot, col);
         // routing weight applied to the fp32 sums, one rounding (as the fused expert kernel the
         // reference delegates to)
         if (a.row_scale != nullptr) s *= a.row_scale[a.scale_rows != nullptr ? a.scale_rows[slot] : slot];
@@ -332,10 +375,12 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(hymeta_moe_gemm_args a) {
 // conflicts.  The 4 waves take alternate 64-deep pairs of k-steps.
 constexpr int kLineImageBytes = kCols * 128;   // per wave
 
-template <int MT>
+template <int MT, bool I8>
 __global__ __launch_bounds__(256) void moe_gemm_lines_kernel(hymeta_moe_gemm_args a) {
+  typedef typename MoeAcc<I8>::type acc_t;
+  constexpr int ES = I8 ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* s_red = reinterpret_cast<float*>(smem_raw);  // [4 waves][16 MT rows][64 cols], after the k loop
+  float* s_red = reinterpret_cast<float*>(smem_raw);  // [4 waves][16 MT rows][64 cols] of 4-byte sums, after the k loop
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -350,43 +395,43 @@ __global__ __launch_bounds__(256) void moe_gemm_lines_kernel(hymeta_moe_gemm_arg
   // load q of a pair covers image rows 8q .. 8q + 7; this lane: row 8q + (lane >> 3), piece
   // (lane & 7) ^ swizzle(row within its 16-row fragment)
   const int lr = lane >> 3, lp = lane & 7;
-  const uint16_t* wbase = reinterpret_cast<const uint16_t*>(a.weights) + static_cast<int64_t>(e) * a.w_stride_e +
-                          static_cast<int64_t>(nb * kCols + lr) * a.K;
-  const uint16_t* wld[2] = {wbase + 8 * (lp ^ (lr >> 1)), wbase + 8 * static_cast<int64_t>(a.K) + 8 * (lp ^ (4 + (lr >> 1)))};
-  const int64_t frag_stride = 16 * static_cast<int64_t>(a.K);
+  const int64_t kb = static_cast<int64_t>(a.K) * ES;   // bytes of a weight row
+  const char* wbase = static_cast<const char*>(a.weights) + static_cast<int64_t>(e) * a.w_stride_e * ES +
+                      static_cast<int64_t>(nb * kCols + lr) * kb;
+  const char* wld[2] = {wbase + 16 * (lp ^ (lr >> 1)), wbase + 8 * kb + 16 * (lp ^ (4 + (lr >> 1)))};
+  const int64_t frag_stride = 16 * kb;
   char* img_st = img + lane * 16;
   const char* img_ld[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) img_ld[h] = img + n * 128 + (((4 * h + c) ^ ((n >> 1) & 7)) * 16);
 
-  const int pairs = a.K / 64;
+  const int pairs = static_cast<int>(kb / 128);       // 128-byte lines of a row = pairs of 64-byte k-steps
   const int nsteps = wave < pairs ? (pairs - wave + 3) / 4 : 0;   // this wave's pairs: wave, wave + 4, ...
   const int last = nsteps - 1;
 
   for (int r0 = row_lo; r0 < row_hi; r0 += 16 * MT) {
-    const uint16_t* xrow[MT];
+    const char* xrow[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int slot = min(r0 + 16 * mt + n, row_hi - 1);   // rows past the expert's end re-read its last row
-      const int src = a.a_rows != nullptr ? a.a_rows[slot] / a.a_rows_div : slot;
-      xrow[mt] = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(src) * a.x_stride_m + 8 * c;
+      xrow[mt] = static_cast<const char*>(a.x) + static_cast<int64_t>(moe_src_row(a, slot)) * a.x_stride_m * ES + 16 * c;
     }
-    f32x4 acc[MT][4];
+    acc_t acc[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[mt][i] = {0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 4; ++i) acc[mt][i] = acc_t{0, 0, 0, 0};
 
     // two register sets, unconditional loads (pairs past the end re-read the last pair)
     u32x4 wa[8], xa[MT][2], wb[8], xb[MT][2];
     auto load = [&](int s, u32x4 (&w)[8], u32x4 (&x)[MT][2]) {
-      const int k0 = 64 * (wave + 4 * min(s, last));
+      const int k0 = 128 * (wave + 4 * min(s, last));
 #pragma unroll
       for (int q = 0; q < 8; ++q) w[q] = ld16g(wld[q & 1] + (q >> 1) * frag_stride + k0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) x[mt][h] = ld16g(xrow[mt] + k0 + 32 * h);
+        for (int h = 0; h < 2; ++h) x[mt][h] = ld16g(xrow[mt] + k0 + 64 * h);
     };
     auto fma_pair = [&](const u32x4 (&w)[8], const u32x4 (&x)[MT][2]) {
 #pragma unroll
@@ -397,7 +442,7 @@ __global__ __launch_bounds__(256) void moe_gemm_lines_kernel(hymeta_moe_gemm_arg
         for (int i = 0; i < 4; ++i) {
           const u32x4 b = *reinterpret_cast<const u32x4*>(img_ld[h] + i * 2048);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt][i] = mfma16(as_frag(x[mt][h]), as_frag(b), acc[mt][i]);
+          for (int mt = 0; mt < MT; ++mt) acc[mt][i] = moe_mma<I8>(x[mt][h], b, acc[mt][i]);
         }
     };
     if (nsteps > 0) {
@@ -419,8 +464,11 @@ __global__ __launch_bounds__(256) void moe_gemm_lines_kernel(hymeta_moe_gemm_arg
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          s_red[(static_cast<size_t>(wave) * 16 * MT + 16 * mt + 4 * c + r) * kCols + 16 * i + n] = acc[mt][i][r];
+        for (int r = 0; r < 4; ++r) {
+          float v;
+          if constexpr (I8) v = __int_as_float(acc[mt][i][r]); else v = acc[mt][i][r];
+          s_red[(static_cast<size_t>(wave) * 16 * MT + 16 * mt + 4 * c + r) * kCols + 16 * i + n] = v;
+        }
     __syncthreads();
     const int cg = tid & 15;
     const int col = nb * kCols + 4 * cg;
@@ -429,10 +477,11 @@ __global__ __launch_bounds__(256) void moe_gemm_lines_kernel(hymeta_moe_gemm_arg
       const int row = (tid >> 4) + 16 * j;
       const int slot = r0 + row;
       if (slot < row_hi) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        acc_t sum = acc_t{0, 0, 0, 0};
 #pragma unroll
         for (int w = 0; w < 4; ++w)
-          s += *reinterpret_cast<const f32x4*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kCols + 4 * cg);
+          sum += *reinterpret_cast<const acc_t*>(s_red + (static_cast<size_t>(w) * 16 * MT + row) * kCols + 4 * cg);
+        f32x4 s = moe_sums_to_f32<I8>(a, sum, e, slot, col);
         if (a.row_scale != nullptr) s *= a.row_scale[a.scale_rows != nullptr ? a.scale_rows[slot] : slot];
         int64_t out_row = slot;
         if (a.combine_tokens != nullptr) {
@@ -469,8 +518,10 @@ constexpr int kTilePitch = 2 * kTK;                 // bytes per staged row
 constexpr int kTiledMinRowsPerExpert = 8;           // measured: level at 4 rows per expert, 15 % ahead at 16, 2.6x at 512
 constexpr int kBigTileMinRowsPerExpert = 192;
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool I8>
 __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void moe_gemm_tiled_kernel(hymeta_moe_gemm_args a) {
+  typedef typename MoeAcc<I8>::type acc_t;
+  constexpr int ES = I8 ? 1 : 2;
   constexpr int kThreads = 64 * WM * WN;
   constexpr int MT = BM / WM / 16, NT = BN / WN / 16;       // 16 x 16 tiles per wave
   constexpr int kXBytes = BM * kTilePitch, kWBytes = BN * kTilePitch;
@@ -505,24 +556,24 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void moe_gemm_t
 
   // staging role: thread = 16-byte chunk sc of rows sr + kRowsPerPass i of both operand tiles
   const int sr = tid >> 3, sc = tid & 7;
-  const uint16_t* xp[XP];
-  const uint16_t* wp[WP];
+  const int64_t kb = static_cast<int64_t>(a.K) * ES;   // bytes of an operand row
+  const char* xp[XP];
+  const char* wp[WP];
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
     const int slot = min(row_lo + sr + kRowsPerPass * i, row_hi - 1);   // rows past the expert's end re-read its last row
-    const int src = a.a_rows != nullptr ? a.a_rows[slot] / a.a_rows_div : slot;
-    xp[i] = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(src) * a.x_stride_m + 8 * sc;
+    xp[i] = static_cast<const char*>(a.x) + static_cast<int64_t>(moe_src_row(a, slot)) * a.x_stride_m * ES + 16 * sc;
   }
 #pragma unroll
   for (int i = 0; i < WP; ++i)
-    wp[i] = reinterpret_cast<const uint16_t*>(a.weights) + static_cast<int64_t>(e) * a.w_stride_e +
-            static_cast<int64_t>(col0 + sr + kRowsPerPass * i) * a.K + 8 * sc;
+    wp[i] = static_cast<const char*>(a.weights) + static_cast<int64_t>(e) * a.w_stride_e * ES +
+            static_cast<int64_t>(col0 + sr + kRowsPerPass * i) * kb + 16 * sc;
   u32x4 xr[XP], wr[WP];
   auto issue = [&](int it) {
 #pragma unroll
-    for (int i = 0; i < XP; ++i) xr[i] = ld16g(xp[i] + it * kTK);
+    for (int i = 0; i < XP; ++i) xr[i] = ld16g(xp[i] + it * kTilePitch);
 #pragma unroll
-    for (int i = 0; i < WP; ++i) wr[i] = ld16g(wp[i] + it * kTK);
+    for (int i = 0; i < WP; ++i) wr[i] = ld16g(wp[i] + it * kTilePitch);
   };
   auto commit = [&](int buf) {
 #pragma unroll
@@ -537,13 +588,13 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void moe_gemm_t
     }
   };
 
-  f32x4 acc[MT][NT];
+  acc_t acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = {0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
 
-  const int nk = a.K / kTK;
+  const int nk = static_cast<int>(kb / kTilePitch);
   issue(0);
   commit(0);
   if (nk > 1) issue(1);
@@ -557,15 +608,15 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void moe_gemm_t
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int off = 16 * ((4 * ks + c) ^ (n & 7));   // rows 16 t + n: (row & 7) = (n & 7)
-      bf16x8 xf[MT], wf[NT];
+      u32x4 xf[MT], wf[NT];
 #pragma unroll
-      for (int t = 0; t < MT; ++t) xf[t] = as_frag(ld16(ximg + 16 * t * kTilePitch + off));
+      for (int t = 0; t < MT; ++t) xf[t] = ld16(ximg + 16 * t * kTilePitch + off);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wf[t] = as_frag(ld16(wimg + 16 * t * kTilePitch + off));
+      for (int t = 0; t < NT; ++t) wf[t] = ld16(wimg + 16 * t * kTilePitch + off);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(xf[mt], wf[nt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = moe_mma<I8>(xf[mt], wf[nt], acc[mt][nt]);
     }
     __syncthreads();
   }
@@ -578,6 +629,10 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void moe_gemm_t
   static_assert(kStageRows * kCPitch <= 2 * (kXBytes + kWBytes), "output staging fits the operand images");
   static_assert(kStageRows % (16 * MT) == 0 && BM % kStageRows == 0, "a wave's rows fall into one staging pass");
   char* cst = &sm[0][0];
+  float wsc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    wsc[nt] = I8 ? a.w_scale[static_cast<int64_t>(e) * a.N + col0 + 16 * NT * wn + 16 * nt + n] : 1.f;
 #pragma unroll
   for (int half = 0; half < BM / kStageRows; ++half) {
     if ((16 * MT * wm) / kStageRows == half) {
@@ -589,8 +644,14 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void moe_gemm_t
           const int slot = min(row_lo + row, row_hi - 1);
           const float sc_row = a.row_scale != nullptr ? a.row_scale[a.scale_rows != nullptr ? a.scale_rows[slot] : slot] : 1.f;
           uint16_t* crow = reinterpret_cast<uint16_t*>(cst + (row - kStageRows * half) * kCPitch) + 16 * NT * wn + n;
+          if constexpr (I8) {
+            const float xs = a.x_scale[moe_src_row(a, slot)];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) crow[16 * nt] = f2bf(acc[mt][nt][r] * sc_row);
+            for (int nt = 0; nt < NT; ++nt) crow[16 * nt] = f2bf(w8a8_scaled(acc[mt][nt][r], xs, wsc[nt], 0.f) * sc_row);
+          } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) crow[16 * nt] = f2bf(acc[mt][nt][r] * sc_row);
+          }
         }
     }
     __syncthreads();
@@ -626,6 +687,37 @@ __global__ __launch_bounds__(256) void silu_and_mul_kernel(const uint16_t* __res
     }
     st16(out + r * out_stride + 8 * ch, o);
   }
+}
+
+// The activation and the row's dynamic int8 quantisation in one pass (the input of a W8A8 down projection): one workgroup
+// per row forms the bf16 values silu_and_mul_kernel would write, keeps them in registers (NC chunks of 8 per thread) and
+// quantises them with the rule of every W8A8 input here.
+template <int NC>
+__global__ __launch_bounds__(256) void silu_and_mul_int8_kernel(const uint16_t* __restrict__ in, int8_t* __restrict__ out_q,
+                                                                float* __restrict__ out_scale,
+                                                                const int32_t* __restrict__ num_rows_dev, int num_rows, int inter,
+                                                                int64_t in_stride) {
+  __shared__ float s_red[4];
+  const int rows = num_rows_dev != nullptr ? min(*num_rows_dev, num_rows) : num_rows;
+  const int r = blockIdx.x;
+  if (r >= rows) return;                                   // workgroup-uniform
+  const int chunks = inter / 8;
+  const uint16_t* row = in + static_cast<int64_t>(r) * in_stride;
+  u32x4 g[NC], u[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int ch = min(static_cast<int>(threadIdx.x) + 256 * i, chunks - 1);
+    g[i] = ld16(row + 8 * ch);
+    u[i] = ld16(row + inter + 8 * ch);
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g0 = lo_bf(g[i][j]), g1 = hi_bf(g[i][j]);
+      g[i][j] = pack_bf16x2(g0 * sigmoidf(g0) * lo_bf(u[i][j]), g1 * sigmoidf(g1) * hi_bf(u[i][j]));
+    }
+  quantise_chunks_int8<NC>(g, chunks, out_q + static_cast<int64_t>(r) * inter, out_scale + r, s_red);
 }
 
 // out[t] = sum_k y[pos[t,k]] (+ shared[t]); thread = 8 columns of one token.
@@ -737,12 +829,15 @@ extern "C" int hymeta_moe_gemm(const hymeta_moe_gemm_args* args, hymeta_stream_t
   if (a.max_rows == 0 || a.local_expert_end == a.local_expert_begin) return HYMETA_OK;
   if (!a.x || !a.weights || !a.out || !a.expert_offsets) return HYMETA_ERR_INVALID_ARG;
   if (a.a_rows != nullptr && a.a_rows_div <= 0) return HYMETA_ERR_INVALID_ARG;
-  if (a.K % 32 != 0 || a.N % kCols != 0) return HYMETA_ERR_UNSUPPORTED;
-  if ((a.x_stride_m | a.out_stride_m | a.w_stride_e) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
+  if (a.operand_dtype != HYMETA_BF16 && a.operand_dtype != HYMETA_I8) return HYMETA_ERR_UNSUPPORTED;
+  const bool i8 = a.operand_dtype == HYMETA_I8;
+  if (i8 && (!a.x_scale || !a.w_scale || reinterpret_cast<uintptr_t>(a.w_scale) % 16 != 0)) return HYMETA_ERR_INVALID_ARG;
+  if (a.K % (i8 ? 64 : 32) != 0 || a.N % kCols != 0) return HYMETA_ERR_UNSUPPORTED;
+  if ((a.x_stride_m | a.out_stride_m | a.w_stride_e) % (i8 ? 16 : 8) != 0 || a.out_stride_m % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.weights) | reinterpret_cast<uintptr_t>(a.out)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
   const int experts = a.local_expert_end - a.local_expert_begin;
-  const MoeGemmKind kind = moe_gemm_kind(a.max_rows, experts, a.K, a.N);
+  const MoeGemmKind kind = moe_gemm_kind(a.max_rows, experts, i8 ? a.K / 2 : a.K, a.N);   // the kind goes by the bytes of a row
   if (a.combine_tokens != nullptr || a.combine_shared != nullptr) {
     // the fused combine exists in the decode-sized kernel with whole-line loads only (hymeta_moe_gemm_fuses)
     if (kind != MoeGemmKind::kLines) return HYMETA_ERR_UNSUPPORTED;
@@ -754,24 +849,33 @@ extern "C" int hymeta_moe_gemm(const hymeta_moe_gemm_args* args, hymeta_stream_t
   dim3 grid(a.N / kCols, experts), block(256);
   // few rows per expert on average (decode): 16-row tiles; otherwise 64-row tiles
   const bool small = static_cast<int64_t>(a.max_rows) <= 8LL * experts;
+#define HYMETA_MOE_BY_TYPE(LAUNCH_BF16, LAUNCH_I8) do { if (i8) { LAUNCH_I8; } else { LAUNCH_BF16; } } while (0)
   if (kind == MoeGemmKind::kBigTiles) {
     const dim3 tgrid(a.N / 256, (a.max_rows + 255) / 256 + experts);
-    hipLaunchKernelGGL((moe_gemm_tiled_kernel<256, 256, 4, 2>), tgrid, dim3(512), 0, s, a);
+    HYMETA_MOE_BY_TYPE(hipLaunchKernelGGL((moe_gemm_tiled_kernel<256, 256, 4, 2, false>), tgrid, dim3(512), 0, s, a),
+                       hipLaunchKernelGGL((moe_gemm_tiled_kernel<256, 256, 4, 2, true>), tgrid, dim3(512), 0, s, a));
     return launch_status();
   }
   if (kind == MoeGemmKind::kTiles) {
     const dim3 tgrid(a.N / 128, (a.max_rows + 127) / 128 + experts);
-    hipLaunchKernelGGL((moe_gemm_tiled_kernel<128, 128, 2, 2>), tgrid, dim3(256), 0, s, a);
+    HYMETA_MOE_BY_TYPE(hipLaunchKernelGGL((moe_gemm_tiled_kernel<128, 128, 2, 2, false>), tgrid, dim3(256), 0, s, a),
+                       hipLaunchKernelGGL((moe_gemm_tiled_kernel<128, 128, 2, 2, true>), tgrid, dim3(256), 0, s, a));
     return launch_status();
   }
+  const size_t red1 = 4 * 16 * kCols * sizeof(float), red4 = 4 * 64 * kCols * sizeof(float);
   if (kind == MoeGemmKind::kLines) {
     const size_t images = 4 * static_cast<size_t>(kLineImageBytes);
-    if (small) hipLaunchKernelGGL((moe_gemm_lines_kernel<1>), grid, block, std::max(images, 4 * 16 * kCols * sizeof(float)), s, a);
-    else hipLaunchKernelGGL((moe_gemm_lines_kernel<4>), grid, block, std::max(images, 4 * 64 * kCols * sizeof(float)), s, a);
+    if (small) HYMETA_MOE_BY_TYPE(hipLaunchKernelGGL((moe_gemm_lines_kernel<1, false>), grid, block, std::max(images, red1), s, a),
+                                  hipLaunchKernelGGL((moe_gemm_lines_kernel<1, true>), grid, block, std::max(images, red1), s, a));
+    else HYMETA_MOE_BY_TYPE(hipLaunchKernelGGL((moe_gemm_lines_kernel<4, false>), grid, block, std::max(images, red4), s, a),
+                            hipLaunchKernelGGL((moe_gemm_lines_kernel<4, true>), grid, block, std::max(images, red4), s, a));
     return launch_status();
   }
-  if (small) hipLaunchKernelGGL((moe_gemm_kernel<1>), grid, block, 4 * 16 * kCols * sizeof(float), s, a);
-  else hipLaunchKernelGGL((moe_gemm_kernel<4>), grid, block, 4 * 64 * kCols * sizeof(float), s, a);
+  if (small) HYMETA_MOE_BY_TYPE(hipLaunchKernelGGL((moe_gemm_kernel<1, false>), grid, block, red1, s, a),
+                                hipLaunchKernelGGL((moe_gemm_kernel<1, true>), grid, block, red1, s, a));
+  else HYMETA_MOE_BY_TYPE(hipLaunchKernelGGL((moe_gemm_kernel<4, false>), grid, block, red4, s, a),
+                          hipLaunchKernelGGL((moe_gemm_kernel<4, true>), grid, block, red4, s, a));
+#undef HYMETA_MOE_BY_TYPE
   return launch_status();
 }
 
@@ -789,6 +893,27 @@ extern "C" int hymeta_silu_and_mul(const void* in, void* out, const int32_t* num
   hipLaunchKernelGGL(silu_and_mul_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, begin_launches(stream),
                      static_cast<const uint16_t*>(in), static_cast<uint16_t*>(out), num_rows_dev, num_rows, inter, in_stride,
                      out_stride);
+  return launch_status();
+}
+
+extern "C" int hymeta_silu_and_mul_int8(const void* in, int8_t* out_q, float* out_scale, const int32_t* num_rows_dev,
+                                        int32_t num_rows, int32_t inter, int64_t in_stride, hymeta_stream_t stream) {
+  if (num_rows < 0 || inter <= 0) return HYMETA_ERR_INVALID_ARG;
+  if (num_rows == 0) return HYMETA_OK;
+  if (!in || !out_q || !out_scale) return HYMETA_ERR_INVALID_ARG;
+  if (inter % 8 != 0 || inter > 24576 || in_stride % 8 != 0 ||
+      (reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out_q)) % 16 != 0)
+    return HYMETA_ERR_UNSUPPORTED;
+  const uint16_t* src = static_cast<const uint16_t*>(in);
+  hipStream_t s = begin_launches(stream);
+  const int chunks = inter / 8;
+#define HYMETA_SILU_Q(NC) \
+  hipLaunchKernelGGL(silu_and_mul_int8_kernel<NC>, dim3(num_rows), dim3(256), 0, s, src, out_q, out_scale, num_rows_dev, num_rows, inter, in_stride)
+  if (chunks <= 256) HYMETA_SILU_Q(1);
+  else if (chunks <= 768) HYMETA_SILU_Q(3);
+  else if (chunks <= 1536) HYMETA_SILU_Q(6);
+  else HYMETA_SILU_Q(12);
+#undef HYMETA_SILU_Q
   return launch_status();
 }
 

@@ -17,6 +17,7 @@ HYMETA_OK = 0
 HYMETA_BF16 = 0
 HYMETA_F32 = 1
 HYMETA_F16 = 2
+HYMETA_I8 = 3
 
 GATE_NONE = 0
 GATE_7B = 1
@@ -256,6 +257,7 @@ class MoeGemmArgs(_Args):
         ("local_expert_begin", _i32), ("local_expert_end", _i32),
         ("x_stride_m", _i64), ("out_stride_m", _i64), ("w_stride_e", _i64),
         ("combine_tokens", _ptr), ("combine_shared", _ptr), ("combine_shared_stride_m", _i64),
+        ("operand_dtype", _i32), ("x_scale", _ptr), ("w_scale", _ptr),
     ]
 
 
@@ -327,6 +329,7 @@ _SIGNATURES = {
     "hymeta_moe_gemm_fuses": (C.c_int, [_i32, _i32, _i32, _i32]),
     "hymeta_moe_gemm": (C.c_int, [C.POINTER(MoeGemmArgs), _ptr]),
     "hymeta_silu_and_mul": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),
+    "hymeta_silu_and_mul_int8": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i64, _ptr]),
     "hymeta_moe_combine": (C.c_int, [C.POINTER(MoeCombineArgs), _ptr]),
     "hymeta_w8a8_quantize": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i64, _ptr]),
     "hymeta_w8a8_scale_out": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),

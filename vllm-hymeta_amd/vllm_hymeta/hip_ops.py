@@ -1143,6 +1143,20 @@ def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None, num_rows_d
     return out
 
 
+def silu_and_mul_int8(x: torch.Tensor, num_rows_dev: Optional[torch.Tensor] = None):
+    """x bf16 [R, 2I] -> the rows ``silu_and_mul`` would give, quantised per row as ``w8a8_quantize`` quantises them:
+    (int8 [R, I], fp32 scales [R]) in one launch, the bf16 rows never written."""
+    _dev(x, num_rows_dev)
+    R, two_i = x.shape
+    inter = two_i // 2
+    _require(x.dtype == torch.bfloat16 and x.stride(1) == 1 and two_i % 2 == 0, "x must be row-contiguous bf16 [R, 2I]")
+    q = torch.empty(R, inter, dtype=torch.int8, device=x.device)
+    sc = torch.empty(R, dtype=torch.float32, device=x.device)
+    _C.check(_C.load().hymeta_silu_and_mul_int8(_p(x), _p(q), _p(sc), _p(num_rows_dev), R, inter, x.stride(0), _stream(x)),
+             "hymeta_silu_and_mul_int8")
+    return q, sc
+
+
 # Switch for A/B timing and for tests of both forms: fold the combine into the experts' down GEMM at decode sizes (see
 # moe_forward).
 MOE_FUSE_DOWN = os.environ.get("HYMETA_MOE_FUSE_DOWN", "1") != "0"
@@ -1158,9 +1172,12 @@ def moe_router_fused(x: torch.Tensor, gate_weight: torch.Tensor) -> bool:
 def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: torch.Tensor, w2: torch.Tensor, top_k: int = 1,
                 renormalize: bool = False, shared: Optional[torch.Tensor] = None,
                 local_experts: Optional[tuple] = None, out: Optional[torch.Tensor] = None,
-                gate_weight: Optional[torch.Tensor] = None, logits_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                gate_weight: Optional[torch.Tensor] = None, logits_out: Optional[torch.Tensor] = None,
+                w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Sparse MoE block: x bf16 [T,H], router_logits [T,E] (bf16 | fp32), w13 bf16 [E,2I,H], w2 bf16
-    [E,H,I]; ``shared`` bf16 [T,H] is added to the result; ``local_experts = (lo, hi)`` computes only
+    [E,H,I] -- or W8A8 experts: w13 / w2 int8 with per-output-channel ``w13_scale`` fp32 [E,2I] / ``w2_scale`` fp32 [E,H]
+    (the tokens and the activated rows are quantised per row on the way in: exact int32 sums, scales applied once);
+    ``shared`` bf16 [T,H] is added to the result; ``local_experts = (lo, hi)`` computes only
     this rank's experts (the caller all-reduces); the weight tensors may then hold just those experts
     (``[hi - lo, 2I, H]`` / ``[hi - lo, H, I]``, expert ``lo`` first: an expert-parallel rank keeps nothing else), with the
     number of experts taken from the router (``gate_weight`` rows / ``router_logits`` columns).  Returns bf16 [T,H].
@@ -1184,9 +1201,18 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
         if logits_out is not None:
             logits_out.copy_(router_logits)
     _require(x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [T, H]")
-    _require(w13.dtype == torch.bfloat16 and w13.is_contiguous() and Hw == H, "w13 must be contiguous bf16 [E, 2I, H]")
-    _require(w2.dtype == torch.bfloat16 and w2.is_contiguous() and w2.shape == (E_held, H, inter),
-             "w2 must be contiguous bf16 [E, H, I]")
+    i8 = w13.dtype == torch.int8
+    _require(w13.dtype in (torch.bfloat16, torch.int8) and w13.is_contiguous() and Hw == H,
+             "w13 must be contiguous bf16 | int8 [E, 2I, H]")
+    _require(w2.dtype == w13.dtype and w2.is_contiguous() and w2.shape == (E_held, H, inter),
+             "w2 must be contiguous [E, H, I] of w13's type")
+    if i8:
+        _dev(w13_scale, w2_scale)
+        _require(w13_scale is not None and w13_scale.dtype == torch.float32 and w13_scale.is_contiguous()
+                 and w13_scale.shape == (E_held, two_i), "w13_scale must be contiguous fp32 [E, 2I]")
+        _require(w2_scale is not None and w2_scale.dtype == torch.float32 and w2_scale.is_contiguous()
+                 and w2_scale.shape == (E_held, H), "w2_scale must be contiguous fp32 [E, H]")
+        _require(H % 128 == 0 and inter % 64 == 0, "int8 experts need H % 128 == 0 and I % 64 == 0")
     _require(fused_router or (router_logits.shape == (T, E) and router_logits.dtype in _DT and router_logits.stride(1) == 1),
              "router_logits must be [T, E] bf16 | fp32")
     dev = x.device
@@ -1230,12 +1256,18 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
     g = _C.MoeGemmArgs()
     # the kernels index the weights by the expert's number: tensors that hold the local experts only are addressed from
     # where expert 0 would lie (only experts lo .. hi - 1 are ever read)
-    w13_base = C.c_void_p(w13.data_ptr() - (lo * w13.stride(0) * 2 if compact else 0))
-    w2_base = C.c_void_p(w2.data_ptr() - (lo * w2.stride(0) * 2 if compact else 0))
-    g.x, g.weights, g.out, g.expert_offsets = _p(x), w13_base, _p(h13), _p(offsets)
+    esize = 1 if i8 else 2
+    w13_base = C.c_void_p(w13.data_ptr() - (lo * w13.stride(0) * esize if compact else 0))
+    w2_base = C.c_void_p(w2.data_ptr() - (lo * w2.stride(0) * esize if compact else 0))
+    xin = x
+    if i8:
+        xin, xs = w8a8_quantize(x)              # per token, once for all its experts
+        g.operand_dtype, g.x_scale = _C.HYMETA_I8, _p(xs)
+        g.w_scale = C.c_void_p(w13_scale.data_ptr() - (lo * two_i * 4 if compact else 0))
+    g.x, g.weights, g.out, g.expert_offsets = _p(xin), w13_base, _p(h13), _p(offsets)
     g.a_rows, g.a_rows_div, g.max_rows, g.K, g.N = _p(sorted_pair), top_k, P, H, two_i
     g.local_expert_begin, g.local_expert_end = lo, hi
-    g.x_stride_m, g.out_stride_m, g.w_stride_e = x.stride(0), h13.stride(0), w13.stride(0)
+    g.x_stride_m, g.out_stride_m, g.w_stride_e = xin.stride(0), h13.stride(0), w13.stride(0)
     _C.check(lib.hymeta_moe_gemm(C.byref(g), st), "hymeta_moe_gemm (w13)")
 
     if shared is not None:
@@ -1243,12 +1275,18 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
                  "shared must be bf16 [T, H]")
     # decode-sized batches with one choice per token and every expert local: the down GEMM writes its rows straight to
     # their tokens with the shared expert added -- no combine launch
-    fuse_combine = (MOE_FUSE_DOWN and top_k == 1 and (lo, hi) == (0, E) and bool(lib.hymeta_moe_gemm_fuses(P, hi - lo, inter, H))
+    fuse_combine = (MOE_FUSE_DOWN and top_k == 1 and (lo, hi) == (0, E)
+                    and bool(lib.hymeta_moe_gemm_fuses(P, hi - lo, inter // 2 if i8 else inter, H))
                     and (shared is None or shared.stride(0) % 8 == 0))
     # slots in use are a prefix only when lo == 0; otherwise act on all P rows (unused rows are never read)
-    hact = torch.empty(P, inter, dtype=torch.bfloat16, device=dev)
-    silu_and_mul(h13, out=hact)
     d = _C.MoeGemmArgs()
+    if i8:
+        hact, hs = silu_and_mul_int8(h13)       # activation and per-row quantisation in one launch
+        d.operand_dtype, d.x_scale = _C.HYMETA_I8, _p(hs)
+        d.w_scale = C.c_void_p(w2_scale.data_ptr() - (lo * H * 4 if compact else 0))
+    else:
+        hact = torch.empty(P, inter, dtype=torch.bfloat16, device=dev)
+        silu_and_mul(h13, out=hact)
     d.x, d.x_stride_m = _p(hact), hact.stride(0)
     y = out if fuse_combine else torch.empty(P, H, dtype=torch.bfloat16, device=dev)
     d.weights, d.out, d.expert_offsets = w2_base, _p(y), _p(offsets)
