@@ -38,9 +38,10 @@ def config_70b(layers=28, vocab=B1.VOCAB):
 
 def synthetic_checkpoint_70b(cfg, dev, quant, seed=0):
     """(name, tensor) pairs under the published names (hf_model/modeling_hymeta.py parameter names; ``mode.norm`` as the
-    checkpoint spells it), one tensor at a time on the device.  ``quant``: the attention, MLP and shared-expert linears
-    as bf16 / W8A8 (hf_model/quant_w8a8.py:121-124) / GPTQ-4 (vllm_hymeta/models/hymeta_gptq.py); the routed experts and
-    the router stay bf16, as both quantisation scripts leave them."""
+    checkpoint spells it), one tensor at a time on the device.  ``quant``: the linears as bf16 / W8A8
+    (hf_model/quant_w8a8.py:121-132: every Linear but the lm_head, i.e. the routed experts and the router too) / GPTQ-4
+    (hf_model/hymeta_gptq.py:22-35 lists the attention, MLP, shared-expert AND routed-expert projections; this tree runs
+    the first three quantised and keeps GPTQ experts out: the synthetic GPTQ checkpoint holds bf16 experts)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     hidden, inter = cfg.hidden_size, cfg.intermediate_size
@@ -88,9 +89,15 @@ def synthetic_checkpoint_70b(cfg, dev, quant, seed=0):
         if cfg.num_layer_experts[i] == 1:
             yield from mlp(p + "mlp", inter)
         else:
-            yield p + "block_sparse_moe.gate.weight", rnd(cfg.num_layer_experts[i], hidden, scale=0.5)
+            if quant == "w8a8":
+                gate = rnd(cfg.num_layer_experts[i], hidden, scale=0.5).float()
+                gs = gate.abs().amax(dim=1, keepdim=True) / 127.0
+                yield p + "block_sparse_moe.gate.weight", torch.round(gate / gs).to(torch.int8)
+                yield p + "block_sparse_moe.gate.weight_scale", gs
+            else:
+                yield p + "block_sparse_moe.gate.weight", rnd(cfg.num_layer_experts[i], hidden, scale=0.5)
             for e in range(cfg.num_layer_experts[i]):
-                yield from mlp(p + f"block_sparse_moe.experts.{e}", inter, quantise=False)
+                yield from mlp(p + f"block_sparse_moe.experts.{e}", inter, quantise=quant == "w8a8")
             yield from mlp(p + "shared_mlp", cfg.shared_intermediate_size)
 
 
@@ -156,7 +163,10 @@ def experts_hit(model, runner):
 
     def pre(mod, inputs):
         x = inputs[0].reshape(-1, inputs[0].shape[-1])
-        top = torch.nn.functional.linear(x, mod.gate_weight).float().topk(mod.top_k, dim=-1).indices.unique()
+        logits = mod.router_logits(x)
+        if logits is None:
+            logits = torch.nn.functional.linear(x, mod.gate_weight)
+        top = logits.float().topk(mod.top_k, dim=-1).indices.unique()
         if mod.local_experts is not None:
             top = top[(top >= mod.local_experts[0]) & (top < mod.local_experts[1])]
         hit.append(int(top.numel()))
@@ -184,7 +194,7 @@ def step_bytes_70b(cfg, quant, tp, batch, ctx, hit, expert_parallel=False):
     moe_layers = [i for i in range(L) if cfg.num_layer_experts[i] > 1]
     dense_w = (L - len(moe_layers)) * 3 * INTER * HIDDEN * wb / tp
     shared_w = len(moe_layers) * 3 * cfg.shared_intermediate_size * HIDDEN * wb / tp
-    expert_w = sum(hit) * 3 * INTER * HIDDEN * 2.0 / (1 if expert_parallel else tp)
+    expert_w = sum(hit) * 3 * INTER * HIDDEN * (1.0 if quant == "w8a8" else 2.0) / (1 if expert_parallel else tp)
     kvh, heads = max(1, HKV // tp), H // tp
     full = [i for i in range(L) if i in FULL_LAYERS]
     kv = batch * 2 * kvh * D * 2 * ((L - len(full)) * (min(ctx + 1, cfg.sliding_window) + M_META) + len(full) * (ctx + 1 + M_META))

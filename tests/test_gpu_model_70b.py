@@ -124,3 +124,72 @@ def test_hymeta_for_causal_lm_prefill_then_decode(engine_style):
     assert_bf16_close(logits.cpu(), ref_logits, "70B model, decode logits", rel=2e-2, frac=2.0 ** -4)
     if engine_style:
         attention.release_layers("model.")
+
+
+def _w8a8_recipe(ckpt):
+    """The checkpoint as ``hf_model/quant_w8a8.py:121-132`` would store it: every Linear but the lm_head as int8 weights
+    with one fp32 scale per output channel (``weight_scale [out, 1]``) -- the routed experts and the router included."""
+    out = {}
+    for name, t in ckpt.items():
+        is_linear = name.endswith("_proj.weight") or name.endswith("block_sparse_moe.gate.weight")
+        if not is_linear:
+            out[name] = t
+            continue
+        w = t.float()
+        scale = w.abs().amax(dim=1, keepdim=True).clamp_min(1e-8) / 127.0
+        out[name] = torch.clamp(torch.round(w / scale), -127, 127).to(torch.int8)
+        out[name + "_scale"] = scale
+    return out
+
+
+def test_w8a8_checkpoint_with_quantised_experts_and_router():
+    """A W8A8 checkpoint of the 70B family holds int8 experts and an int8 router.  The model keeps them int8 (grouped int8
+    GEMMs, the router as a W8A8 linear) and agrees with the same checkpoint whose EXPERT weights were expanded to bf16
+    -- same routing (the router is identical on both sides), so the difference is the experts' activation quantisation
+    and the bf16 rounding of the expanded weights."""
+    from vllm_hymeta.models.configuration_hymeta import HymetaConfig
+    from vllm_hymeta.models.modeling_hymeta import HymetaForCausalLM
+    from vllm_hymeta.models.moe import HymetaMoE
+
+    dev = torch.device("cuda")
+    g_ = gen(21)
+    cfg = HymetaConfig(vocab_size=512, hidden_size=512, num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=2,
+                       intermediate_size=512, shared_intermediate_size=256, num_local_experts=4, num_meta_tokens=32,
+                       sliding_window=48, max_position_embeddings=1024)
+    quantised = _w8a8_recipe(_checkpoint(g_, cfg))
+    expanded = {}
+    for name, t in quantised.items():
+        if ".experts." in name:
+            if name.endswith("weight_scale"):
+                continue
+            t = (t.float() * quantised[name + "_scale"]).to(torch.bfloat16)
+        expanded[name] = t
+
+    lens = [60, 33]
+    ids = [torch.randint(0, cfg.vocab_size, (L,), generator=g_) for L in lens]
+    bs = 16
+    per_seq = (max(lens) + bs - 1) // bs
+    bt = torch.arange(2 * per_seq, dtype=torch.int32).view(2, per_seq).to(dev)
+    slots = torch.tensor([int(bt[s, t // bs]) * bs + t % bs for s, L in enumerate(lens) for t in range(L)], device=dev)
+    outs = []
+    for ckpt in (quantised, expanded):
+        model = HymetaForCausalLM(cfg, max_num_seqs=4, device=dev)
+        loaded = model.load_weights(ckpt.items())
+        moe = [m for m in model.modules() if isinstance(m, HymetaMoE)]
+        assert len(moe) == 1 and moe[0].gate_weight.dtype == torch.int8 and moe[0].w8a8_gate is not None
+        if ckpt is quantised:
+            assert "model.layers.3.block_sparse_moe.experts.w13_weight_scale" in loaded
+            assert moe[0].w13.dtype == torch.int8 and moe[0].w13.shape == (4, 2 * cfg.intermediate_size, cfg.hidden_size)
+            assert moe[0].w13_scale.shape == (4, 2 * cfg.intermediate_size) and moe[0].w2_scale.shape == (4, cfg.hidden_size)
+        else:
+            assert moe[0].w13.dtype == torch.bfloat16 and moe[0].w13_scale is None
+        kv = [torch.zeros(2, 2 * per_seq, bs, cfg.num_key_value_heads, D, dtype=torch.bfloat16, device=dev)
+              for _ in range(cfg.num_hidden_layers)]
+        md = _md(dev, prefill_lens=lens, context_lens=[0, 0], slot_mapping=slots)
+        h = model(torch.cat(ids).to(dev), torch.cat([torch.arange(L) for L in lens]).to(dev), attn_metadata=md, kv_caches=kv,
+                  request_ids_to_seq_ids={"a": [0], "b": [1]}, finished_requests_ids=[])
+        torch.cuda.synchronize()
+        outs.append(h.float().cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert_bf16_close(outs[0], outs[1], "70B W8A8 checkpoint: int8 experts against the same experts expanded to bf16", rel=3e-2,
+                      frac=0.15)

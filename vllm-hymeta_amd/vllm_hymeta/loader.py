@@ -345,6 +345,27 @@ def stack_experts(experts: Sequence[Dict[str, torch.Tensor]], tp_size: int = 1, 
     return torch.stack(w13).contiguous(), torch.stack(w2).contiguous()
 
 
+def expert_leaf(param: str) -> Tuple[str, str]:
+    """``...experts.w13_weight_scale`` -> (``"w13"``, ``"weight_scale"``): which fused expert parameter a routed name fills and
+    which tensor of the projection it is (weight / weight_scale / qweight / qzeros / scales / g_idx)."""
+    tail = param.rsplit("experts.", 1)[-1]
+    fused, _, leaf = tail.partition("_")
+    return fused, leaf
+
+
+def stack_experts_w8a8(experts: Sequence[Dict[str, Dict[str, torch.Tensor]]]
+                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """W8A8 experts ``[{gate_proj | up_proj | down_proj: {"weight" int8 [out, in], "weight_scale" [out] or [out, 1]}}]`` (one
+    rank's pieces) -> ``w13 int8 [E, 2 I, H]`` (gate rows then up rows), ``w13_scale fp32 [E, 2 I]``, ``w2 int8 [E, H, I]``,
+    ``w2_scale fp32 [E, H]``: the layouts the grouped int8 GEMM reads."""
+    w13 = torch.stack([torch.cat([e["gate_proj"]["weight"], e["up_proj"]["weight"]], dim=0) for e in experts]).contiguous()
+    s13 = torch.stack([torch.cat([e["gate_proj"]["weight_scale"].reshape(-1), e["up_proj"]["weight_scale"].reshape(-1)])
+                       for e in experts]).float().contiguous()
+    w2 = torch.stack([e["down_proj"]["weight"] for e in experts]).contiguous()
+    s2 = torch.stack([e["down_proj"]["weight_scale"].reshape(-1) for e in experts]).float().contiguous()
+    return w13, s13, w2, s2
+
+
 def make_linear(t: Dict[str, torch.Tensor], bits: int = 4, group_size: int = 128, zero_offset: int = 1, device=None):
     """Checkpoint-format tensors (one rank's) -> ``HymetaLinear`` on ``device``."""
     from .linear import HymetaLinear

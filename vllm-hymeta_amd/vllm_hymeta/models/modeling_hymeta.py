@@ -269,8 +269,13 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
                 continue
             loaded.add(route.param)
             if route.expert_id is not None:
-                if tensor.dtype not in (torch.bfloat16, torch.float16, torch.float32):
-                    raise ValueError(f"{name}: quantised experts are not supported, expected a floating-point weight")
+                _, leaf = loader.expert_leaf(route.param)
+                if leaf in ("qweight", "qzeros", "scales", "g_idx"):
+                    raise ValueError(f"{name}: GPTQ experts are not supported (bf16 and W8A8 experts are)")
+                if leaf not in ("weight", "weight_scale"):
+                    raise ValueError(f"{name}: unexpected expert tensor {leaf!r}")
+                if leaf == "weight" and tensor.dtype not in (torch.bfloat16, torch.float16, torch.float32, torch.int8):
+                    raise ValueError(f"{name}: expert weights must be floating point or int8 (W8A8), not {tensor.dtype}")
                 layer = loader._layer_of(name)
                 if m.expert_parallel:      # whole experts, dealt to the ranks in contiguous equal shares
                     lo, hi = expert_range(_layer_experts(cfg, layer), m.tp_size, m.tp_rank)
@@ -279,8 +284,10 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
                     cut = loader.Cut()
                 else:
                     cut = row if route.shard_id == "w2" else col          # experts are cut along their intermediate size
-                piece = loader.own(loader.cut_leaf("weight", tensor, cut), dev).to(torch.bfloat16)
-                experts.setdefault(layer, {}).setdefault(route.expert_id, {})[proj_of[route.shard_id]] = piece
+                piece = loader.own(loader.cut_leaf(leaf, tensor, cut), dev)
+                if leaf == "weight" and piece.is_floating_point():
+                    piece = piece.to(torch.bfloat16)
+                experts.setdefault(layer, {}).setdefault(route.expert_id, {}).setdefault(proj_of[route.shard_id], {})[leaf] = piece
                 continue
             module, _, leaf = route.param.rpartition(".")
             if "proj" in module and "norm" not in module:
@@ -331,13 +338,22 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
             else:
                 mine = experts.pop(i)
                 local = expert_range(n_experts, m.tp_size, m.tp_rank) if m.expert_parallel else None
-                w13, w2 = loader.stack_experts([mine[e] for e in (range(*local) if local else range(n_experts))])   # this rank's
-                del mine
+                held = [mine[e] for e in (range(*local) if local else range(n_experts))]       # this rank's
+                scales = {}
+                if held[0]["gate_proj"]["weight"].dtype == torch.int8:
+                    w13, scales["w13_scale"], w2, scales["w2_scale"] = loader.stack_experts_w8a8(held)
+                else:
+                    w13, w2 = loader.stack_experts([{proj: t["weight"] for proj, t in e.items()} for e in held])
+                del mine, held
                 # the shared expert's partial sums ride in the experts' all-reduce
                 shared = mlp(f"{p}.shared_mlp", reduce_results=False) if _shared_intermediate(cfg, i) > 0 else None
-                ffn = HymetaMoE(plain[f"{p}.block_sparse_moe.gate.weight"].to(torch.bfloat16), w13, w2,
-                                top_k=cfg.num_experts_per_topk, renormalize=False, shared_mlp=shared, group=m.tp_group,
-                                local_experts=local)
+                gate = plain[f"{p}.block_sparse_moe.gate.weight"]
+                if gate.dtype == torch.int8:       # a W8A8 recipe over every Linear quantises the router as well
+                    scales["gate_scale"] = plain[f"{p}.block_sparse_moe.gate.weight_scale"].reshape(-1).float()
+                else:
+                    gate = gate.to(torch.bfloat16)
+                ffn = HymetaMoE(gate, w13, w2, top_k=cfg.num_experts_per_topk, renormalize=False, shared_mlp=shared,
+                                group=m.tp_group, local_experts=local, **scales)
             m.layers.append(HybridBlock(HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.attn_norm.weight"]), attn,
                                         HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.mlp_norm.weight"]), ffn))
         if dev.type == "cuda":

@@ -65,18 +65,43 @@ class HymetaMoE(torch.nn.Module):
 
     def __init__(self, gate_weight: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, top_k: int = 1,
                  renormalize: bool = False, shared_mlp: Optional[HymetaMLP] = None,
-                 local_experts: Optional[Tuple[int, int]] = None, group=None):
+                 local_experts: Optional[Tuple[int, int]] = None, group=None,
+                 w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None,
+                 gate_scale: Optional[torch.Tensor] = None):
+        """W8A8 experts (a compressed-tensors W8A8 checkpoint, ``hf_model/quant_w8a8.py:121-132``, quantises every Linear
+        but the lm_head: experts and router included): ``w13`` / ``w2`` int8 with ``w13_scale [E, 2I]`` / ``w2_scale [E, H]``;
+        an int8 ``gate_weight`` comes with ``gate_scale [E]`` and the router logits are then that W8A8 linear's output."""
         super().__init__()
+        self.w8a8_gate = None
+        if gate_weight.dtype == torch.int8:
+            # the W8A8 linear kernels take whole 64-column blocks: the E <= 64 router rows are padded with zero rows
+            E, H = gate_weight.shape
+            pad = torch.zeros(64, H, dtype=torch.int8, device=gate_weight.device)
+            pad[:E] = gate_weight
+            sc = torch.ones(64, dtype=torch.float32, device=gate_weight.device)
+            sc[:E] = gate_scale.reshape(-1).float()
+            self.w8a8_gate = HymetaLinear.from_w8a8(pad, sc)
         self.register_buffer("gate_weight", gate_weight)   # [E, H], replicated
         self.register_buffer("w13", w13)
         self.register_buffer("w2", w2)
+        self.register_buffer("w13_scale", w13_scale)
+        self.register_buffer("w2_scale", w2_scale)
         self.top_k, self.renormalize = top_k, renormalize
         self.shared_mlp = shared_mlp
         self.local_experts = local_experts
         self.group = group
 
+    def router_logits(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """The router's logits where the block cannot compute them itself (an int8 router); ``None``: bf16 router, run
+        inside ``moe_forward``."""
+        if self.w8a8_gate is None:
+            return None
+        return self.w8a8_gate(x)[:, :self.gate_weight.shape[0]]
+
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
-        x = hidden_states.reshape(-1, hidden_states.shape[-1])
+        # (a 2-D input is taken as it is: a norm that quantised its output for the W8A8 consumers below attached the int8
+        # rows to that very tensor object)
+        x = hidden_states if hidden_states.dim() == 2 else hidden_states.reshape(-1, hidden_states.shape[-1])
         shared = None
         if self.shared_mlp is not None:
             # the shared expert is tensor-parallel like a dense MLP; its partial sums ride in the
@@ -84,6 +109,9 @@ class HymetaMoE(torch.nn.Module):
             shared = self.shared_mlp(x)
         # the router (a replicated linear layer, reference modeling_hymeta.py:312-324) runs inside the block: in the
         # routing launch itself for decode-sized batches
-        out = hip_ops.moe_forward(x, None, self.w13, self.w2, top_k=self.top_k, renormalize=self.renormalize,
-                                  shared=shared, local_experts=self.local_experts, gate_weight=self.gate_weight)
+        logits = self.router_logits(x)
+        out = hip_ops.moe_forward(x, logits, self.w13, self.w2, top_k=self.top_k, renormalize=self.renormalize,
+                                  shared=shared, local_experts=self.local_experts,
+                                  gate_weight=self.gate_weight if logits is None else None,
+                                  w13_scale=self.w13_scale, w2_scale=self.w2_scale)
         return all_reduce_sum(out, self.group).view_as(hidden_states)
