@@ -163,8 +163,9 @@ def experts_hit(model, runner):
 
     def pre(mod, inputs):
         x = inputs[0].reshape(-1, inputs[0].shape[-1])
-        logits = mod.router_logits(x)
-        if logits is None:
+        if mod.w8a8_gate is not None:
+            logits = mod.w8a8_gate(x)[:, :mod.gate_weight.shape[0]]
+        else:
             logits = torch.nn.functional.linear(x, mod.gate_weight)
         top = logits.float().topk(mod.top_k, dim=-1).indices.unique()
         if mod.local_experts is not None:

@@ -860,6 +860,13 @@ typedef struct hymeta_moe_router_args {
   int32_t num_tokens, num_experts, top_k, renormalize, hidden;
   int32_t local_expert_begin, local_expert_end;
   int64_t x_stride_t;
+  /* The router of a W8A8 checkpoint (a recipe over every Linear quantises it too): operand_dtype = HYMETA_I8, x = the
+   * tokens' int8 rows with x_scale fp32 [num_tokens] (hymeta_w8a8_quantize), gate_weight int8 [num_experts, hidden],
+   * gate_scale fp32 [num_experts]; the logits are those of hymeta_w8a8_gemm on these operands, bit for bit.  hidden and
+   * x_stride_t multiples of 16.  HYMETA_BF16 (0): the fields are ignored. */
+  int32_t operand_dtype;
+  const float* x_scale;
+  const float* gate_scale;
 } hymeta_moe_router_args;
 
 int hymeta_moe_router(const hymeta_moe_router_args* args, hymeta_stream_t stream);

@@ -311,6 +311,43 @@ def test_moe_forward_with_w8a8_experts(T, E, top_k, renorm, with_shared, H, inte
         assert torch.equal(out, plain)          # the combine inside the down GEMM: the same bits
 
 
+@pytest.mark.parametrize("T,E,top_k", [(64, 16, 1), (5, 8, 2), (256, 16, 1)])
+def test_int8_router_in_the_routing_launch(T, E, top_k):
+    """The router of a W8A8 checkpoint is int8 too: decode-sized batches route on the tokens' int8 rows inside the routing
+    launch (integer dot products), with the logits of the W8A8 linear bit for bit; the module sends larger batches
+    through that linear."""
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta.linear import HymetaLinear
+    from vllm_hymeta.models.moe import HymetaMoE
+
+    H, inter = 512, 256
+    x, gate_w, _, _, _ = _problem(11, T, H, 64, E)
+    w13, s13, w2, s2 = _w8a8_experts(12, E, H, inter)
+    gs = gate_w.float().abs().amax(dim=1) / 127.0
+    gq = torch.round(gate_w.float() / gs[:, None]).to(torch.int8)
+    pad = torch.zeros(64, H, dtype=torch.int8)
+    pad[:E] = gq
+    sc = torch.ones(64)
+    sc[:E] = gs
+    xd = x.cuda()
+    ref_logits = HymetaLinear.from_w8a8(pad.cuda(), sc.cuda())(xd)[:, :E].contiguous()
+    logits = torch.empty(T, E, dtype=torch.bfloat16, device="cuda")
+    kw = dict(top_k=top_k, w13_scale=s13.cuda(), w2_scale=s2.cuda())
+    out = hip_ops.moe_forward(xd, None, w13.cuda(), w2.cuda(), gate_weight=gq.cuda(), gate_scale=gs.cuda(), logits_out=logits, **kw)
+    same = hip_ops.moe_forward(x.cuda(), ref_logits, w13.cuda(), w2.cuda(), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(logits, ref_logits) and torch.equal(out, same)
+    moe = HymetaMoE(gq.cuda(), w13.cuda(), w2.cuda(), top_k=top_k, w13_scale=s13.cuda(), w2_scale=s2.cuda(), gate_scale=gs.cuda())
+    assert moe.router_logits(xd) is None and torch.equal(moe(x.cuda()), out)
+    xb = randn_bf16(gen(13), 300, H).cuda()
+    big_logits = moe.router_logits(xb)
+    assert big_logits is not None and big_logits.shape == (300, E)
+    big = moe(xb)
+    ref_big = hip_ops.moe_forward(xb, big_logits, w13.cuda(), w2.cuda(), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(big, ref_big)
+
+
 def test_w8a8_experts_expert_parallel_shares():
     """A rank that holds experts [lo, hi) only (compact int8 tensors and scales) gives the bits of the full tensors with
     ``local_experts``; the shares add up to the whole block."""

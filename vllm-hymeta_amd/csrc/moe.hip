@@ -148,6 +148,10 @@ __global__ __launch_bounds__(256) void moe_scatter_kernel(hymeta_moe_route_args 
 // products, rounded to bf16 as the bf16 linear layer's output is), one thread routes them as moe_route_kernel does, and
 // the workgroup that draws the last ticket counts the pairs per expert in LDS, writes the offsets and scatters the
 // pairs.  The ticket word must be zero on entry and is zero again on exit.
+// I8: the router of a W8A8 checkpoint (int8 [E, H] with a scale per expert) against the token's int8 row: exact integer
+// dot products (v_dot4_i32_i8), scaled and rounded as the W8A8 linear kernels scale and round -- the logits that linear
+// would give, bit for bit.
+template <bool I8>
 __global__ __launch_bounds__(256) void moe_router_kernel(hymeta_moe_router_args a) {
   __shared__ float s_part[4][kMaxExperts];
   __shared__ float s_logit[kMaxExperts];
@@ -156,38 +160,59 @@ __global__ __launch_bounds__(256) void moe_router_kernel(hymeta_moe_router_args 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int t = blockIdx.x;
   const int E = a.num_experts;
-  const int chunks = a.hidden / 8;
-  const uint16_t* xrow = reinterpret_cast<const uint16_t*>(a.x) + static_cast<int64_t>(t) * a.x_stride_t;
-  const uint16_t* w = reinterpret_cast<const uint16_t*>(a.gate_weight);
+  constexpr int ES = I8 ? 1 : 2;                       // bytes per element of x and the gate weight
+  const int chunks = a.hidden * ES / 16;               // 16-byte pieces of a row
+  const char* xrow = static_cast<const char*>(a.x) + static_cast<int64_t>(t) * a.x_stride_t * ES;
+  const char* w = static_cast<const char*>(a.gate_weight);
+  const int64_t wpitch = static_cast<int64_t>(a.hidden) * ES;
 
   for (int e0 = 0; e0 < E; e0 += 16) {
     float acc[16];
+    int iacc[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f, iacc[j] = 0;
     for (int ch = tid; ch < chunks; ch += 256) {
-      const u32x4 xv = ld16g(xrow + 8 * ch);
+      const u32x4 xv = ld16g(xrow + 16 * ch);
       u32x4 wv[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) wv[j] = ld16g(w + static_cast<int64_t>(min(e0 + j, E - 1)) * a.hidden + 8 * ch);
+      for (int j = 0; j < 16; ++j) wv[j] = ld16g(w + static_cast<int64_t>(min(e0 + j, E - 1)) * wpitch + 16 * ch);
 #pragma unroll
       for (int j = 0; j < 16; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          acc[j] = __builtin_fmaf(lo_bf(xv[i]), lo_bf(wv[j][i]), acc[j]);
-          acc[j] = __builtin_fmaf(hi_bf(xv[i]), hi_bf(wv[j][i]), acc[j]);
+          if constexpr (I8) {
+            iacc[j] = __builtin_amdgcn_sdot4(static_cast<int>(xv[i]), static_cast<int>(wv[j][i]), iacc[j], false);
+          } else {
+            acc[j] = __builtin_fmaf(lo_bf(xv[i]), lo_bf(wv[j][i]), acc[j]);
+            acc[j] = __builtin_fmaf(hi_bf(xv[i]), hi_bf(wv[j][i]), acc[j]);
+          }
         }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      float v = acc[j];
+      if constexpr (I8) {
+        int v = iacc[j];
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0 && e0 + j < E) s_part[wave][e0 + j] = v;
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && e0 + j < E) s_part[wave][e0 + j] = __int_as_float(v);
+      } else {
+        float v = acc[j];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && e0 + j < E) s_part[wave][e0 + j] = v;
+      }
     }
   }
   __syncthreads();
   if (tid < E) {
-    const float v = bf16_round(((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid]);
+    float v;
+    if constexpr (I8) {
+      const int sum = __float_as_int(s_part[0][tid]) + __float_as_int(s_part[1][tid]) + __float_as_int(s_part[2][tid]) +
+                      __float_as_int(s_part[3][tid]);
+      v = bf16_round(w8a8_scaled(sum, a.x_scale[t], a.gate_scale[tid], 0.f));
+    } else {
+      v = bf16_round(((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid]);
+    }
     s_logit[tid] = v;
     if (a.logits_out != nullptr) reinterpret_cast<uint16_t*>(a.logits_out)[static_cast<int64_t>(t) * E + tid] = f2bf(v);
   }
@@ -785,7 +810,11 @@ extern "C" int hymeta_moe_router(const hymeta_moe_router_args* args, hymeta_stre
   const hymeta_moe_router_args& a = *args;
   if (a.num_tokens < 0 || a.num_experts <= 0 || a.top_k <= 0 || a.hidden <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.num_experts > kMaxExperts || a.top_k > 2 || a.top_k > a.num_experts) return HYMETA_ERR_UNSUPPORTED;
-  if (a.num_tokens == 0 || a.num_tokens > HYMETA_MOE_ROUTER_MAX_TOKENS || a.hidden % 8 != 0 || a.x_stride_t % 8 != 0)
+  if (a.operand_dtype != HYMETA_BF16 && a.operand_dtype != HYMETA_I8) return HYMETA_ERR_UNSUPPORTED;
+  const bool i8 = a.operand_dtype == HYMETA_I8;
+  if (i8 && (!a.x_scale || !a.gate_scale)) return HYMETA_ERR_INVALID_ARG;
+  const int per16 = i8 ? 16 : 8;       // elements of a 16-byte piece
+  if (a.num_tokens == 0 || a.num_tokens > HYMETA_MOE_ROUTER_MAX_TOKENS || a.hidden % per16 != 0 || a.x_stride_t % per16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
   if (a.local_expert_begin < 0 || a.local_expert_end > a.num_experts || a.local_expert_begin > a.local_expert_end)
     return HYMETA_ERR_INVALID_ARG;
@@ -793,7 +822,8 @@ extern "C" int hymeta_moe_router(const hymeta_moe_router_args* args, hymeta_stre
     return HYMETA_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.gate_weight)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
   hipStream_t s = begin_launches(stream);
-  hipLaunchKernelGGL(moe_router_kernel, dim3(a.num_tokens), dim3(256), 0, s, a);
+  if (i8) hipLaunchKernelGGL(moe_router_kernel<true>, dim3(a.num_tokens), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(moe_router_kernel<false>, dim3(a.num_tokens), dim3(256), 0, s, a);
   return launch_status();
 }
 

@@ -242,6 +242,7 @@ class MoeRouterArgs(_Args):
         ("num_tokens", _i32), ("num_experts", _i32), ("top_k", _i32), ("renormalize", _i32), ("hidden", _i32),
         ("local_expert_begin", _i32), ("local_expert_end", _i32),
         ("x_stride_t", _i64),
+        ("operand_dtype", _i32), ("x_scale", _ptr), ("gate_scale", _ptr),
     ]
 
 

@@ -1164,16 +1164,18 @@ MOE_FUSE_DOWN = os.environ.get("HYMETA_MOE_FUSE_DOWN", "1") != "0"
 
 def moe_router_fused(x: torch.Tensor, gate_weight: torch.Tensor) -> bool:
     """Whether ``moe_forward`` routes this batch with the one-launch router (linear layer + routing)."""
-    return (x.is_cuda and x.dtype == torch.bfloat16 and gate_weight.dtype == torch.bfloat16 and gate_weight.is_contiguous()
-            and 0 < x.shape[0] <= _C.MOE_ROUTER_MAX_TOKENS and x.shape[1] % 8 == 0 and x.stride(0) % 8 == 0
-            and gate_weight.shape[0] <= 64)
+    per16 = 16 if gate_weight.dtype == torch.int8 else 8      # an int8 router reads the tokens' int8 rows
+    return (x.is_cuda and x.dtype == torch.bfloat16 and gate_weight.dtype in (torch.bfloat16, torch.int8)
+            and gate_weight.is_contiguous() and 0 < x.shape[0] <= _C.MOE_ROUTER_MAX_TOKENS and x.shape[1] % per16 == 0
+            and x.stride(0) % 8 == 0 and gate_weight.shape[0] <= 64)
 
 
 def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: torch.Tensor, w2: torch.Tensor, top_k: int = 1,
                 renormalize: bool = False, shared: Optional[torch.Tensor] = None,
                 local_experts: Optional[tuple] = None, out: Optional[torch.Tensor] = None,
                 gate_weight: Optional[torch.Tensor] = None, logits_out: Optional[torch.Tensor] = None,
-                w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None,
+                gate_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Sparse MoE block: x bf16 [T,H], router_logits [T,E] (bf16 | fp32), w13 bf16 [E,2I,H], w2 bf16
     [E,H,I] -- or W8A8 experts: w13 / w2 int8 with per-output-channel ``w13_scale`` fp32 [E,2I] / ``w2_scale`` fp32 [E,H]
     (the tokens and the activated rows are quantised per row on the way in: exact int32 sums, scales applied once);
@@ -1183,8 +1185,9 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
     number of experts taken from the router (``gate_weight`` rows / ``router_logits`` columns).  Returns bf16 [T,H].
     With ``router_logits=None`` and ``gate_weight`` bf16 [E,H] the block computes the logits itself: decode-sized batches
     in the routing launch (``moe_router_fused``; ``logits_out`` bf16 [T,E] then receives them), larger ones through the
-    linear layer."""
-    _dev(x, router_logits, w13, w2, shared, out, gate_weight)
+    linear layer.  An int8 ``gate_weight`` with ``gate_scale`` fp32 [E] (the router of a W8A8 checkpoint) is routed in
+    that launch too, on the tokens' int8 rows; larger batches must come with ``router_logits``."""
+    _dev(x, router_logits, w13, w2, shared, out, gate_weight, gate_scale)
     T, H = x.shape
     E_held, two_i, Hw = w13.shape
     inter = two_i // 2
@@ -1195,6 +1198,10 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
     compact = E_held != E                   # only the local experts are held: slot 0 = expert lo
     _require(E_held == E or E_held == hi - lo, "w13 / w2 must hold every expert or exactly the local ones")
     fused_router = router_logits is None and T > 0 and moe_router_fused(x, gate_weight)
+    if gate_weight is not None and gate_weight.dtype == torch.int8 and router_logits is None:
+        _require(fused_router, "an int8 router above the one-launch router's batch size needs router_logits")
+        _require(gate_scale is not None and gate_scale.dtype == torch.float32 and gate_scale.is_contiguous()
+                 and gate_scale.numel() == E, "gate_scale must be contiguous fp32 [E]")
     if router_logits is None and not fused_router:
         _require(gate_weight.shape == (E, H), "gate_weight must be [E, H]")
         router_logits = torch.nn.functional.linear(x, gate_weight)
@@ -1234,12 +1241,17 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
                  "logits_out must be contiguous bf16 [T, E]")
         r = _C.MoeRouterArgs()
         r.x, r.gate_weight, r.logits_out = _p(x), _p(gate_weight), _p(logits_out)
+        r.x_stride_t = x.stride(0)
+        if gate_weight.dtype == torch.int8:
+            xq_r, xs_r = w8a8_quantize(x)       # (the rows a quantising norm attached, or one launch; the experts reuse them)
+            setattr(x, INT8_ROWS_ATTR, (xq_r, xs_r))
+            r.x, r.x_stride_t = _p(xq_r), xq_r.stride(0)
+            r.operand_dtype, r.x_scale, r.gate_scale = _C.HYMETA_I8, _p(xs_r), _p(gate_scale)
         r.topk_ids, r.topk_weights, r.expert_offsets = _p(ids), _p(wts), _p(offsets)
         r.sorted_pair, r.pair_pos = _p(sorted_pair), _p(pair_pos)
         r.ticket = _p(_workspace(dev, 64, "moe_router"))
         r.num_tokens, r.num_experts, r.top_k, r.renormalize, r.hidden = T, E, top_k, int(bool(renormalize)), H
         r.local_expert_begin, r.local_expert_end = lo, hi
-        r.x_stride_t = x.stride(0)
         _C.check(lib.hymeta_moe_router(C.byref(r), st), "hymeta_moe_router")
     else:
         r = _C.MoeRouteArgs()

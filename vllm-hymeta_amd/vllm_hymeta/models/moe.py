@@ -86,15 +86,16 @@ class HymetaMoE(torch.nn.Module):
         self.register_buffer("w2", w2)
         self.register_buffer("w13_scale", w13_scale)
         self.register_buffer("w2_scale", w2_scale)
+        self.register_buffer("gate_scale", None if gate_scale is None else gate_scale.reshape(-1).float().contiguous())
         self.top_k, self.renormalize = top_k, renormalize
         self.shared_mlp = shared_mlp
         self.local_experts = local_experts
         self.group = group
 
     def router_logits(self, x: torch.Tensor) -> Optional[torch.Tensor]:
-        """The router's logits where the block cannot compute them itself (an int8 router); ``None``: bf16 router, run
-        inside ``moe_forward``."""
-        if self.w8a8_gate is None:
+        """The router's logits where the block cannot compute them itself (an int8 router above the batch size of the
+        one-launch router: the padded W8A8 linear); ``None``: run inside ``moe_forward``."""
+        if self.w8a8_gate is None or hip_ops.moe_router_fused(x, self.gate_weight):
             return None
         return self.w8a8_gate(x)[:, :self.gate_weight.shape[0]]
 
@@ -112,6 +113,6 @@ class HymetaMoE(torch.nn.Module):
         logits = self.router_logits(x)
         out = hip_ops.moe_forward(x, logits, self.w13, self.w2, top_k=self.top_k, renormalize=self.renormalize,
                                   shared=shared, local_experts=self.local_experts,
-                                  gate_weight=self.gate_weight if logits is None else None,
+                                  gate_weight=self.gate_weight if logits is None else None, gate_scale=self.gate_scale,
                                   w13_scale=self.w13_scale, w2_scale=self.w2_scale)
         return all_reduce_sum(out, self.group).view_as(hidden_states)
