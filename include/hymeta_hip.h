@@ -913,6 +913,41 @@ int hymeta_moe_gemm(const hymeta_moe_gemm_args* args, hymeta_stream_t stream);
  * pass K / 2 for int8 operands, the choice goes by the bytes of a row). */
 int hymeta_moe_gemm_fuses(int32_t max_rows, int32_t experts, int32_t K, int32_t N);
 
+/* GPTQ experts (hf_model/hymeta_gptq.py:30-32 lists the routed experts' projections among the quantised modules; the
+ * reference runs them through vLLM's quantised fused_moe, third party: parity unpinned).  The tensors of one projection
+ * stacked over the experts, each expert's as hymeta_gptq_gemm takes them: qweight int32 [experts, K / pack, N], qzeros
+ * int32 [experts, K / group, N / pack], scales fp16 | bf16 [experts, K / group, N], contiguous; pointers address expert 0
+ * (a rank that holds experts [lo, hi) only passes its base minus lo experts, as for hymeta_moe_gemm).  Rows, a_rows,
+ * row_scale, offsets: as hymeta_moe_gemm.  The kernel walks an expert's rows in tiles of 16 or 32 and re-reads the
+ * expert's weights per tile: meant for decode-sized batches; for prefill-sized ones hymeta_moe_gptq_expand + the bf16
+ * hymeta_moe_gemm.  bits 4 | 8, group 32 | 64 | 128, K % group == 0, N % 64 == 0. */
+typedef struct hymeta_moe_gptq_gemm_args {
+  uint32_t struct_size;     /* sizeof(this struct) as the caller compiled it; see "Versioning" above */
+  const void* x;               /* bf16 rows of K */
+  const int32_t* qweight;
+  const int32_t* qzeros;
+  const void* scales;
+  void* out;                   /* bf16 [slots, N] */
+  const int32_t* expert_offsets;   /* [experts + 1], device */
+  const int32_t* a_rows;       /* source row of slot s = a_rows[s] / a_rows_div, or NULL: s */
+  const int32_t* scale_rows;   /* index into row_scale per slot, or NULL: s */
+  const float* row_scale;      /* or NULL */
+  int32_t a_rows_div;
+  int32_t max_rows;
+  int32_t K, N;
+  int32_t bits, group_size, scales_dtype, zero_offset;
+  int32_t local_expert_begin, local_expert_end;
+  int64_t x_stride_m, out_stride_m;
+} hymeta_moe_gptq_gemm_args;
+
+int hymeta_moe_gptq_gemm(const hymeta_moe_gptq_gemm_args* args, hymeta_stream_t stream);
+
+/* `experts` stacked GPTQ matrices (layouts above, starting at the pointers given) -> bf16 W^T [experts, N, K], the
+ * layout of the bf16 expert stacks: one launch.  K % (32 * (32 / bits)) == 0. */
+int hymeta_moe_gptq_expand(const int32_t* qweight, const int32_t* qzeros, const void* scales, void* out, int32_t experts,
+                           int32_t K, int32_t N, int32_t bits, int32_t group_size, int32_t scales_dtype, int32_t zero_offset,
+                           hymeta_stream_t stream);
+
 /* num_rows_dev: optional device count of the rows in use (e.g. expert_offsets + E); NULL: num_rows. */
 int hymeta_silu_and_mul(const void* in, void* out, const int32_t* num_rows_dev, int32_t num_rows,
                         int32_t inter, int64_t in_stride, int64_t out_stride, hymeta_stream_t stream);

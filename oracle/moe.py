@@ -95,3 +95,33 @@ def moe_w8a8_ref(x: torch.Tensor, router_logits: torch.Tensor, w13: torch.Tensor
     if shared is not None:
         out = (out.float() + shared.float()).to(x.dtype)
     return out
+
+
+def moe_gptq_ref(x: torch.Tensor, router_logits: torch.Tensor, w13, w2, bits: int = 4, group_size: int = 128, top_k: int = 1,
+                 renormalize: bool = False, shared: Optional[torch.Tensor] = None,
+                 local_experts: Optional[Tuple[int, int]] = None, zero_offset: int = 1) -> torch.Tensor:
+    """The block with GPTQ experts (``hf_model/hymeta_gptq.py:30-32`` lists the routed experts' projections among the
+    quantised modules; vLLM runs them through its quantised ``fused_moe``, third party: parity unpinned).  ``w13`` /
+    ``w2``: per-expert lists of ``(qweight, qzeros, scales)`` standing for ``[2I, H]`` / ``[H, I]`` weights; the arithmetic
+    is ``moe_ref``'s on the exactly de-quantised weights ``s (q - z)``."""
+    from .quant import gptq_dequant_ref
+
+    d13 = torch.stack([gptq_dequant_ref(*t, bits, group_size, zero_offset).t() for t in w13])      # [E, 2I, H] fp64
+    d2 = torch.stack([gptq_dequant_ref(*t, bits, group_size, zero_offset).t() for t in w2])
+    T, H = x.shape
+    ids, w = moe_route_ref(router_logits, top_k, renormalize)
+    out = torch.zeros(T, H, dtype=torch.float64)
+    lo, hi = local_experts if local_experts is not None else (0, d13.shape[0])
+    for t in range(T):
+        for j in range(top_k):
+            e = int(ids[t, j])
+            if not lo <= e < hi:
+                continue
+            h = (x[t].double() @ d13[e].t()).to(x.dtype)
+            a = silu_and_mul_ref(h)
+            y = (float(w[t, j]) * (a.double() @ d2[e].t())).to(x.dtype)
+            out[t] = (out[t] + y.double()).to(x.dtype).double() if j else y.double()
+    out = out.to(x.dtype)
+    if shared is not None:
+        out = (out.float() + shared.float()).to(x.dtype)
+    return out

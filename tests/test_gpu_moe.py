@@ -373,6 +373,78 @@ def test_w8a8_experts_expert_parallel_shares():
     assert torch.equal(total.to(torch.bfloat16), full.cpu())      # top-1: every token's row comes from exactly one share
 
 
+def _gptq_experts(seed, E, K, N, bits, group, scales_dtype=torch.float16):
+    """Per-expert GPTQ tensors of [N, K] weights of about unit-variance rows: (list for the oracle, stacked for the kernels)."""
+    from oracle.quant import gptq_pack_ref
+    from vllm_hymeta import hip_ops
+
+    g_ = gen(seed)
+    per = []
+    for _ in range(E):
+        wi = torch.randint(0, 2 ** bits, (K, N), generator=g_)
+        z = torch.randint(1, 2 ** bits, (K // group, N), generator=g_)
+        sc = ((torch.rand(K // group, N, generator=g_) * 0.5 + 0.75) * (3.4 / 2 ** bits) * K ** -0.5).to(scales_dtype)
+        qw, qz = gptq_pack_ref(wi, z, bits)
+        per.append((qw, qz, sc))
+    stack = hip_ops.GptqExperts(torch.stack([p[0] for p in per]).cuda(), torch.stack([p[1] for p in per]).cuda(),
+                                torch.stack([p[2] for p in per]).cuda(), bits, group)
+    return per, stack
+
+
+@pytest.mark.parametrize("T,E,top_k,with_shared,H,inter,bits,group", [
+    (1, 16, 1, False, 256, 128, 4, 128),       # one decode token
+    (64, 16, 1, True, 512, 384, 4, 128),       # decode batch, 16-row tiles, waves with uneven group counts (3 groups on 4 waves)
+    (64, 4, 2, False, 256, 256, 8, 64),        # 8-bit, group 64, two choices: 32-row tiles walked inside the workgroup
+    (120, 4, 1, True, 256, 128, 4, 32),        # group 32; 30 rows per expert on average: still the fused kernel
+    (400, 4, 1, True, 512, 256, 4, 128),       # prefill-sized: experts expanded to bf16, tiled grouped GEMM
+])
+def test_moe_forward_with_gptq_experts(T, E, top_k, with_shared, H, inter, bits, group):
+    """Experts as a GPTQ checkpoint holds them: decode-sized batches through the fused de-quantising grouped GEMM,
+    prefill-sized ones through the one-launch expansion and the bf16 tiled kernel, against the CPU restatement."""
+    from oracle.moe import moe_gptq_ref
+    from vllm_hymeta import hip_ops
+
+    x, gate_w, _, _, logits = _problem(15, T, H, 64, E)
+    p13, s13 = _gptq_experts(16, E, H, 2 * inter, bits, group)
+    p2, s2 = _gptq_experts(17, E, inter, H, bits, group, torch.bfloat16 if bits == 8 else torch.float16)
+    shared = randn_bf16(gen(18), T, H) if with_shared else None
+    ref = moe_gptq_ref(x, logits, p13, p2, bits, group, top_k, False, shared)
+    out = hip_ops.moe_forward(x.cuda(), logits.cuda(), s13, s2, top_k=top_k, shared=None if shared is None else shared.cuda())
+    again = hip_ops.moe_forward(x.cuda(), logits.cuda(), s13, s2, top_k=top_k, shared=None if shared is None else shared.cuda())
+    torch.cuda.synchronize()
+    assert_bf16_close(out.cpu(), ref, f"gptq moe T={T} E={E} k={top_k} {bits}-bit", rel=8e-3)
+    assert torch.equal(out, again)
+
+
+def test_gptq_experts_expert_parallel_and_the_expansion():
+    """Compact stacks of a rank's experts give the bits of the full stacks with ``local_experts`` (both regimes); the
+    one-launch expansion is the dense expansion of every expert."""
+    from oracle.moe import moe_gptq_ref
+    from vllm_hymeta import hip_ops
+
+    E, H, inter = 8, 512, 256
+    p13, s13 = _gptq_experts(19, E, H, 2 * inter, 4, 128)
+    p2, s2 = _gptq_experts(20, E, inter, H, 4, 128)
+    dense = torch.stack([hip_ops.gptq_dequant(s13.qweight[e], s13.qzeros[e], s13.scales[e], 4, 128, transposed=True) for e in range(E)])
+    assert torch.equal(hip_ops.moe_gptq_expand(s13), dense)
+    cut = lambda w, lo, hi: w._replace(qweight=w.qweight[lo:hi].contiguous(), qzeros=w.qzeros[lo:hi].contiguous(),
+                                       scales=w.scales[lo:hi].contiguous())
+    for T in (64, 600):
+        x, gate_w, _, _, logits = _problem(21 + T, T, H, 64, E)
+        xd, ld = x.cuda(), logits.cuda()
+        total = torch.zeros(T, H)
+        for lo, hi in ((0, 4), (4, 8)):
+            whole = hip_ops.moe_forward(xd, ld, s13, s2, local_experts=(lo, hi))
+            held = hip_ops.moe_forward(xd, ld, cut(s13, lo, hi), cut(s2, lo, hi), local_experts=(lo, hi))
+            torch.cuda.synchronize()
+            assert torch.equal(whole, held)
+            assert_bf16_close(whole.cpu(), moe_gptq_ref(x, logits, p13, p2, local_experts=(lo, hi)), f"gptq EP share {lo} T={T}", rel=8e-3)
+            total += whole.float().cpu()
+        full = hip_ops.moe_forward(xd, ld, s13, s2)
+        torch.cuda.synchronize()
+        assert torch.equal(total.to(torch.bfloat16), full.cpu())
+
+
 def test_moe_rejects_unsupported():
     from vllm_hymeta import hip_ops
     from vllm_hymeta._C import HymetaError

@@ -262,6 +262,18 @@ class MoeGemmArgs(_Args):
     ]
 
 
+class MoeGptqGemmArgs(_Args):
+    _fields_ = [
+        _SIZE,
+        ("x", _ptr), ("qweight", _ptr), ("qzeros", _ptr), ("scales", _ptr), ("out", _ptr), ("expert_offsets", _ptr),
+        ("a_rows", _ptr), ("scale_rows", _ptr), ("row_scale", _ptr),
+        ("a_rows_div", _i32), ("max_rows", _i32), ("K", _i32), ("N", _i32),
+        ("bits", _i32), ("group_size", _i32), ("scales_dtype", _i32), ("zero_offset", _i32),
+        ("local_expert_begin", _i32), ("local_expert_end", _i32),
+        ("x_stride_m", _i64), ("out_stride_m", _i64),
+    ]
+
+
 class MoeCombineArgs(_Args):
     _fields_ = [
         _SIZE,
@@ -330,6 +342,8 @@ _SIGNATURES = {
     "hymeta_moe_gemm_fuses": (C.c_int, [_i32, _i32, _i32, _i32]),
     "hymeta_moe_gemm": (C.c_int, [C.POINTER(MoeGemmArgs), _ptr]),
     "hymeta_silu_and_mul": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),
+    "hymeta_moe_gptq_gemm": (C.c_int, [C.POINTER(MoeGptqGemmArgs), _ptr]),
+    "hymeta_moe_gptq_expand": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "hymeta_silu_and_mul_int8": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i64, _ptr]),
     "hymeta_moe_combine": (C.c_int, [C.POINTER(MoeCombineArgs), _ptr]),
     "hymeta_w8a8_quantize": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i64, _ptr]),
@@ -355,6 +369,7 @@ STRUCTS = {
     "hymeta_moe_route_args": MoeRouteArgs,
     "hymeta_moe_router_args": MoeRouterArgs,
     "hymeta_moe_gemm_args": MoeGemmArgs,
+    "hymeta_moe_gptq_gemm_args": MoeGptqGemmArgs,
     "hymeta_moe_combine_args": MoeCombineArgs,
 }
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional
+from typing import NamedTuple, Optional
 
 import torch
 
@@ -1157,6 +1157,43 @@ def silu_and_mul_int8(x: torch.Tensor, num_rows_dev: Optional[torch.Tensor] = No
     return q, sc
 
 
+class GptqExperts(NamedTuple):
+    """One projection of GPTQ experts, stacked: ``qweight`` int32 [E, K / pack, N], ``qzeros`` int32 [E, K / group, N / pack],
+    ``scales`` fp16 | bf16 [E, K / group, N] (each expert's tensors as ``gptq_gemm`` takes them), contiguous."""
+    qweight: torch.Tensor
+    qzeros: torch.Tensor
+    scales: torch.Tensor
+    bits: int = 4
+    group_size: int = 128
+    zero_offset: int = 1
+
+    @property
+    def shape(self):
+        """(E, N, K): the shape of the bf16 stack this stands for."""
+        return (self.qweight.shape[0], self.qweight.shape[2], self.qweight.shape[1] * (32 // self.bits))
+
+
+# Rows per local expert (on average) up to which GPTQ experts run the fused de-quantising grouped GEMM; above, the local
+# experts are expanded to bf16 once per call and the tiled bf16 grouped GEMM runs on the expansion (the fused kernel
+# re-reads an expert's weights per 32-row tile).
+MOE_GPTQ_FUSED_ROWS_PER_EXPERT = 32
+
+
+def moe_gptq_expand(w: GptqExperts) -> torch.Tensor:
+    """GPTQ expert stack -> bf16 [E, N, K] (one launch), in a grow-only workspace of the device and stream."""
+    E, N, K = w.shape
+    pack = 32 // w.bits
+    _require(w.qweight.dtype == torch.int32 and w.qweight.is_contiguous() and w.qzeros.is_contiguous() and w.scales.is_contiguous(),
+             "GPTQ expert tensors must be contiguous")
+    _require(N % 64 == 0 and K % (32 * pack) == 0, "expansion needs N % 64 == 0 and K % (32 * pack) == 0")
+    ws = _workspace(w.qweight.device, E * N * K * 2, f"moe_gptq_expand_{N}x{K}")
+    out = ws[: E * N * K * 2].view(torch.bfloat16).view(E, N, K)
+    sd = _C.HYMETA_F16 if w.scales.dtype == torch.float16 else _C.HYMETA_BF16
+    _C.check(_C.load().hymeta_moe_gptq_expand(_p(w.qweight), _p(w.qzeros), _p(w.scales), _p(out), E, K, N, w.bits, w.group_size,
+                                              sd, w.zero_offset, _stream(w.qweight)), "hymeta_moe_gptq_expand")
+    return out
+
+
 # Switch for A/B timing and for tests of both forms: fold the combine into the experts' down GEMM at decode sizes (see
 # moe_forward).
 MOE_FUSE_DOWN = os.environ.get("HYMETA_MOE_FUSE_DOWN", "1") != "0"
@@ -1186,8 +1223,25 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
     With ``router_logits=None`` and ``gate_weight`` bf16 [E,H] the block computes the logits itself: decode-sized batches
     in the routing launch (``moe_router_fused``; ``logits_out`` bf16 [T,E] then receives them), larger ones through the
     linear layer.  An int8 ``gate_weight`` with ``gate_scale`` fp32 [E] (the router of a W8A8 checkpoint) is routed in
-    that launch too, on the tokens' int8 rows; larger batches must come with ``router_logits``."""
-    _dev(x, router_logits, w13, w2, shared, out, gate_weight, gate_scale)
+    that launch too, on the tokens' int8 rows; larger batches must come with ``router_logits``.  GPTQ experts: ``w13`` /
+    ``w2`` as ``GptqExperts`` stacks -- decode-sized batches run the fused de-quantising grouped GEMM, larger ones expand
+    the local experts to bf16 once per call."""
+    gptq = isinstance(w13, GptqExperts)
+    if gptq:
+        _require(isinstance(w2, GptqExperts), "w13 and w2 must both be GPTQ stacks")
+        n_local = (local_experts[1] - local_experts[0]) if local_experts is not None else w13.shape[0]
+        if x.shape[0] * top_k > MOE_GPTQ_FUSED_ROWS_PER_EXPERT * max(n_local, 1):
+            held = w13.shape[0]
+            total = gate_weight.shape[0] if gate_weight is not None else router_logits.shape[1]
+            if held == total and local_experts is not None and tuple(local_experts) != (0, total):
+                lo_, hi_ = local_experts      # expand the rank's experts only
+                w13 = w13._replace(qweight=w13.qweight[lo_:hi_], qzeros=w13.qzeros[lo_:hi_], scales=w13.scales[lo_:hi_])
+                w2 = w2._replace(qweight=w2.qweight[lo_:hi_], qzeros=w2.qzeros[lo_:hi_], scales=w2.scales[lo_:hi_])
+            return moe_forward(x, router_logits, moe_gptq_expand(w13), moe_gptq_expand(w2), top_k, renormalize, shared,
+                               local_experts, out, gate_weight, logits_out)
+        _dev(x, router_logits, w13.qweight, w2.qweight, shared, out, gate_weight, gate_scale)
+    else:
+        _dev(x, router_logits, w13, w2, shared, out, gate_weight, gate_scale)
     T, H = x.shape
     E_held, two_i, Hw = w13.shape
     inter = two_i // 2
@@ -1208,11 +1262,22 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
         if logits_out is not None:
             logits_out.copy_(router_logits)
     _require(x.dtype == torch.bfloat16 and x.stride(1) == 1, "x must be row-contiguous bf16 [T, H]")
-    i8 = w13.dtype == torch.int8
-    _require(w13.dtype in (torch.bfloat16, torch.int8) and w13.is_contiguous() and Hw == H,
-             "w13 must be contiguous bf16 | int8 [E, 2I, H]")
-    _require(w2.dtype == w13.dtype and w2.is_contiguous() and w2.shape == (E_held, H, inter),
-             "w2 must be contiguous [E, H, I] of w13's type")
+    i8 = not gptq and w13.dtype == torch.int8
+    if gptq:
+        _require(Hw == H and tuple(w2.shape) == (E_held, H, inter), "GPTQ stacks must stand for w13 [E, 2I, H] and w2 [E, H, I]")
+        for w in (w13, w2):
+            pk = 32 // w.bits
+            _require(w.qweight.dtype == torch.int32 and w.qweight.is_contiguous() and w.qzeros.dtype == torch.int32
+                     and w.qzeros.is_contiguous() and w.scales.dtype in (torch.float16, torch.bfloat16) and w.scales.is_contiguous(),
+                     "GPTQ expert tensors must be contiguous int32 / int32 / fp16 | bf16")
+            _require(tuple(w.qzeros.shape) == (E_held, w.shape[2] // w.group_size, w.shape[1] // pk)
+                     and tuple(w.scales.shape) == (E_held, w.shape[2] // w.group_size, w.shape[1]),
+                     "qzeros / scales must be [E, K / group, N / pack] / [E, K / group, N]")
+    else:
+        _require(w13.dtype in (torch.bfloat16, torch.int8) and w13.is_contiguous() and Hw == H,
+                 "w13 must be contiguous bf16 | int8 [E, 2I, H]")
+        _require(w2.dtype == w13.dtype and w2.is_contiguous() and w2.shape == (E_held, H, inter),
+                 "w2 must be contiguous [E, H, I] of w13's type")
     if i8:
         _dev(w13_scale, w2_scale)
         _require(w13_scale is not None and w13_scale.dtype == torch.float32 and w13_scale.is_contiguous()
@@ -1265,6 +1330,43 @@ def moe_forward(x: torch.Tensor, router_logits: Optional[torch.Tensor], w13: tor
         _C.check(lib.hymeta_moe_route(C.byref(r), st), "hymeta_moe_route")
 
     h13 = torch.empty(P, two_i, dtype=torch.bfloat16, device=dev)
+    if gptq:
+        if shared is not None:
+            _require(shared.shape == (T, H) and shared.dtype == torch.bfloat16 and shared.stride(1) == 1,
+                     "shared must be bf16 [T, H]")
+
+        def gptq_gemm_args(w: GptqExperts, xin, xout, K_, N_):
+            q = _C.MoeGptqGemmArgs()
+            back = lo if compact else 0           # tensors that hold the local experts only: address expert 0
+            per_q, per_z, per_s = w.qweight.stride(0) * 4, w.qzeros.stride(0) * 4, w.scales.stride(0) * 2
+            q.qweight = C.c_void_p(w.qweight.data_ptr() - back * per_q)
+            q.qzeros = C.c_void_p(w.qzeros.data_ptr() - back * per_z)
+            q.scales = C.c_void_p(w.scales.data_ptr() - back * per_s)
+            q.x, q.out, q.expert_offsets = _p(xin), _p(xout), _p(offsets)
+            q.max_rows, q.K, q.N = P, K_, N_
+            q.bits, q.group_size, q.zero_offset = w.bits, w.group_size, w.zero_offset
+            q.scales_dtype = _C.HYMETA_F16 if w.scales.dtype == torch.float16 else _C.HYMETA_BF16
+            q.local_expert_begin, q.local_expert_end = lo, hi
+            q.x_stride_m, q.out_stride_m = xin.stride(0), xout.stride(0)
+            return q
+
+        q13 = gptq_gemm_args(w13, x, h13, H, two_i)
+        q13.a_rows, q13.a_rows_div = _p(sorted_pair), top_k
+        _C.check(lib.hymeta_moe_gptq_gemm(C.byref(q13), st), "hymeta_moe_gptq_gemm (w13)")
+        hact = torch.empty(P, inter, dtype=torch.bfloat16, device=dev)
+        silu_and_mul(h13, out=hact)
+        y = torch.empty(P, H, dtype=torch.bfloat16, device=dev)
+        q2 = gptq_gemm_args(w2, hact, y, inter, H)
+        q2.a_rows_div, q2.scale_rows, q2.row_scale = 1, _p(sorted_pair), _p(wts)
+        _C.check(lib.hymeta_moe_gptq_gemm(C.byref(q2), st), "hymeta_moe_gptq_gemm (w2)")
+        c = _C.MoeCombineArgs()
+        c.y, c.shared, c.out, c.pair_pos, c.topk_weights = _p(y), _p(shared), _p(out), _p(pair_pos), _p(wts)
+        c.num_tokens, c.hidden, c.top_k = T, H, top_k
+        c.y_stride_m, c.out_stride_m = y.stride(0), out.stride(0)
+        if shared is not None:
+            c.shared_stride_m = shared.stride(0)
+        _C.check(lib.hymeta_moe_combine(C.byref(c), st), "hymeta_moe_combine")
+        return out
     g = _C.MoeGemmArgs()
     # the kernels index the weights by the expert's number: tensors that hold the local experts only are addressed from
     # where expert 0 would lie (only experts lo .. hi - 1 are ever read)
