@@ -40,8 +40,8 @@ def synthetic_checkpoint_70b(cfg, dev, quant, seed=0):
     """(name, tensor) pairs under the published names (hf_model/modeling_hymeta.py parameter names; ``mode.norm`` as the
     checkpoint spells it), one tensor at a time on the device.  ``quant``: the linears as bf16 / W8A8
     (hf_model/quant_w8a8.py:121-132: every Linear but the lm_head, i.e. the routed experts and the router too) / GPTQ-4
-    (hf_model/hymeta_gptq.py:22-35 lists the attention, MLP, shared-expert AND routed-expert projections; this tree runs
-    the first three quantised and keeps GPTQ experts out: the synthetic GPTQ checkpoint holds bf16 experts)."""
+    (hf_model/hymeta_gptq.py:22-35: the attention, MLP, shared-expert and routed-expert projections; the router stays
+    floating point)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     hidden, inter = cfg.hidden_size, cfg.intermediate_size
@@ -60,8 +60,15 @@ def synthetic_checkpoint_70b(cfg, dev, quant, seed=0):
             yield prefix + ".weight_scale", (torch.rand(out_f, 1, device=dev, generator=g) * (2.0 / 127) * in_f ** -0.5).float()
         else:
             yield prefix + ".qweight", torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // 8, out_f), dtype=torch.int32, device=dev, generator=g)
-            yield prefix + ".qzeros", torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // B1.GROUP, out_f // 8), dtype=torch.int32, device=dev, generator=g)
-            yield prefix + ".scales", (torch.rand(in_f // B1.GROUP, out_f, device=dev, generator=g) * (0.25 * in_f ** -0.5)).to(torch.float16)
+            # zero points 7 or 8 with equal odds (stored as 6 / 7): around them the random nibbles (mean 7.5) give
+            # zero-mean weights.  With a mean of -0.5 steps per weight a linear amplifies the common component of its input
+            # 6-fold, the hidden states of all sequences end up parallel and the router sends every token to one expert
+            coin = torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // B1.GROUP, out_f // 8), dtype=torch.int32, device=dev, generator=g)
+            yield prefix + ".qzeros", (coin & 0x11111111) + 0x66666666
+            # nibbles around the zero point have a standard deviation of 4.6: scales of 0.217 / sqrt(in) on average keep
+            # the variance of the activations, as the bf16 and W8A8 weights of this checkpoint do
+            yield prefix + ".scales", ((torch.rand(in_f // B1.GROUP, out_f, device=dev, generator=g) * 0.5 + 0.75)
+                                       * (0.217 * in_f ** -0.5)).to(torch.float16)
             yield prefix + ".g_idx", (torch.arange(in_f, dtype=torch.int32, device=dev) // B1.GROUP)
 
     def mlp(prefix, size, quantise=True):
@@ -97,7 +104,7 @@ def synthetic_checkpoint_70b(cfg, dev, quant, seed=0):
             else:
                 yield p + "block_sparse_moe.gate.weight", rnd(cfg.num_layer_experts[i], hidden, scale=0.5)
             for e in range(cfg.num_layer_experts[i]):
-                yield from mlp(p + f"block_sparse_moe.experts.{e}", inter, quantise=quant == "w8a8")
+                yield from mlp(p + f"block_sparse_moe.experts.{e}", inter)
             yield from mlp(p + "shared_mlp", cfg.shared_intermediate_size)
 
 
@@ -195,7 +202,7 @@ def step_bytes_70b(cfg, quant, tp, batch, ctx, hit, expert_parallel=False):
     moe_layers = [i for i in range(L) if cfg.num_layer_experts[i] > 1]
     dense_w = (L - len(moe_layers)) * 3 * INTER * HIDDEN * wb / tp
     shared_w = len(moe_layers) * 3 * cfg.shared_intermediate_size * HIDDEN * wb / tp
-    expert_w = sum(hit) * 3 * INTER * HIDDEN * (1.0 if quant == "w8a8" else 2.0) / (1 if expert_parallel else tp)
+    expert_w = sum(hit) * 3 * INTER * HIDDEN * wb / (1 if expert_parallel else tp)
     kvh, heads = max(1, HKV // tp), H // tp
     full = [i for i in range(L) if i in FULL_LAYERS]
     kv = batch * 2 * kvh * D * 2 * ((L - len(full)) * (min(ctx + 1, cfg.sliding_window) + M_META) + len(full) * (ctx + 1 + M_META))

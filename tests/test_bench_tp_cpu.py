@@ -59,11 +59,11 @@ def test_step_bytes_of_the_published_geometry():
     assert parts["kv_rows"] == 64 * 2 * 128 * 2 * (24 * (4096 + 128) + 4 * (32769 + 128))
     assert parts["gla_states"] == 28 * 64 * 2 * 7 * 128 * 128 * 2 and total == sum(parts.values())
     assert parts["lm_head_and_logits"] == 152064 // 4 * 3584 * 2 + 2 * 64 * (152064 // 4) * 4
-    # a W8A8 checkpoint holds int8 experts too; the synthetic GPTQ one keeps bf16 experts
+    # the quantised checkpoints hold quantised experts too
     _, p8 = step_bytes_70b(cfg, "w8a8", 4, 64, 32768, [16] * 21)
     assert p8["routed_experts"] * 2 == parts["routed_experts"] and p8["dense_mlp"] * 2 == parts["dense_mlp"]
     _, p4 = step_bytes_70b(cfg, "gptq4", 4, 64, 32768, [16] * 21)
-    assert p4["routed_experts"] == parts["routed_experts"]
+    assert p4["routed_experts"] * p8["dense_mlp"] == p8["routed_experts"] * p4["dense_mlp"] and p4["routed_experts"] < p8["routed_experts"]
 
 
 def _free_port():

@@ -193,3 +193,73 @@ def test_w8a8_checkpoint_with_quantised_experts_and_router():
     assert torch.isfinite(outs[0]).all()
     assert_bf16_close(outs[0], outs[1], "70B W8A8 checkpoint: int8 experts against the same experts expanded to bf16", rel=3e-2,
                       frac=0.15)
+
+
+def _gptq_recipe(ckpt, g_, bits=4, group=128):
+    """The checkpoint as gptqmodel stores it with the module list of ``hf_model/hymeta_gptq.py:22-35``: attention, MLP,
+    shared-expert and routed-expert projections as ``qweight / qzeros / scales / g_idx`` (round-to-nearest here; the
+    recipe's error compensation does not change the format); the router stays floating point.  Also returns the same
+    checkpoint with every quantised projection expanded to the bf16 weight it stands for."""
+    from oracle.quant import gptq_dequant_ref, gptq_pack_ref
+    quantised, expanded = {}, {}
+    for name, t in ckpt.items():
+        if not name.endswith("_proj.weight"):
+            quantised[name] = expanded[name] = t
+            continue
+        w = t.float().t().contiguous()                      # [K, N]
+        K, N = w.shape
+        wg = w.view(K // group, group, N)
+        lo, hi = wg.amin(dim=1), wg.amax(dim=1)
+        scale = ((hi - lo).clamp_min(1e-6) / (2 ** bits - 1)).to(torch.float16)
+        zero = torch.clamp(torch.round(-lo / scale.float()), 1, 2 ** bits - 1).long()
+        q = torch.clamp(torch.round(wg / scale.float()[:, None, :]) + zero[:, None, :], 0, 2 ** bits - 1).long().view(K, N)
+        qw, qz = gptq_pack_ref(q, zero, bits)
+        base = name[: -len("weight")]
+        quantised[base + "qweight"], quantised[base + "qzeros"], quantised[base + "scales"] = qw, qz, scale
+        quantised[base + "g_idx"] = (torch.arange(K, dtype=torch.int32) // group)
+        expanded[name] = gptq_dequant_ref(qw, qz, scale, bits, group).t().to(torch.bfloat16).contiguous()
+    return quantised, expanded
+
+
+def test_gptq_checkpoint_with_quantised_experts():
+    """A GPTQ checkpoint of the 70B family holds GPTQ experts.  The model keeps them packed (fused de-quantising grouped
+    GEMM on decode-sized steps, expansion per call on prefill-sized ones) and agrees with the bf16 model built from the
+    weights the packed tensors stand for."""
+    from vllm_hymeta.models.configuration_hymeta import HymetaConfig
+    from vllm_hymeta.models.modeling_hymeta import HymetaForCausalLM
+    from vllm_hymeta.models.moe import HymetaMoE
+    from vllm_hymeta import hip_ops
+
+    dev = torch.device("cuda")
+    g_ = gen(31)
+    cfg = HymetaConfig(vocab_size=512, hidden_size=512, num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=2,
+                       intermediate_size=512, shared_intermediate_size=256, num_local_experts=4, num_meta_tokens=32,
+                       sliding_window=48, max_position_embeddings=1024)
+    quantised, expanded = _gptq_recipe(_checkpoint(g_, cfg), g_)
+    bs = 16
+    outs = {}
+    for lens in ([60, 33], [150, 160]):          # 93 pairs on 4 experts: the fused kernel; 310: the expansion
+        ids = [torch.randint(0, cfg.vocab_size, (L,), generator=g_) for L in lens]
+        per_seq = (max(lens) + bs - 1) // bs
+        bt = torch.arange(2 * per_seq, dtype=torch.int32).view(2, per_seq).to(dev)
+        slots = torch.tensor([int(bt[s, t // bs]) * bs + t % bs for s, L in enumerate(lens) for t in range(L)], device=dev)
+        for kind, ckpt in (("gptq", quantised), ("bf16", expanded)):
+            model = HymetaForCausalLM(cfg, max_num_seqs=4, device=dev,
+                                      quant={"bits": 4, "group_size": 128, "zero_offset": 1} if kind == "gptq" else None)
+            loaded = model.load_weights(ckpt.items())
+            moe = [m for m in model.modules() if isinstance(m, HymetaMoE)]
+            assert len(moe) == 1
+            if kind == "gptq":
+                assert "model.layers.3.block_sparse_moe.experts.w13_qweight" in loaded
+                assert isinstance(moe[0].w13, hip_ops.GptqExperts) and tuple(moe[0].w13.shape) == (4, 2 * cfg.intermediate_size, cfg.hidden_size)
+                assert tuple(moe[0].w2.shape) == (4, cfg.hidden_size, cfg.intermediate_size)
+            kv = [torch.zeros(2, 2 * per_seq, bs, cfg.num_key_value_heads, D, dtype=torch.bfloat16, device=dev)
+                  for _ in range(cfg.num_hidden_layers)]
+            md = _md(dev, prefill_lens=lens, context_lens=[0, 0], slot_mapping=slots)
+            h = model(torch.cat(ids).to(dev), torch.cat([torch.arange(L) for L in lens]).to(dev), attn_metadata=md, kv_caches=kv,
+                      request_ids_to_seq_ids={"a": [0], "b": [1]}, finished_requests_ids=[])
+            torch.cuda.synchronize()
+            outs[kind] = h.float().cpu()
+        assert torch.isfinite(outs["gptq"]).all()
+        assert_bf16_close(outs["gptq"], outs["bf16"], f"70B GPTQ checkpoint, {sum(lens)} tokens: packed against expanded weights",
+                          rel=2e-2, frac=0.1)

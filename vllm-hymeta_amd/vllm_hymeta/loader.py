@@ -366,6 +366,23 @@ def stack_experts_w8a8(experts: Sequence[Dict[str, Dict[str, torch.Tensor]]]
     return w13, s13, w2, s2
 
 
+def stack_experts_gptq(experts: Sequence[Dict[str, Dict[str, torch.Tensor]]], bits: int = 4, group_size: int = 128,
+                       zero_offset: int = 1):
+    """GPTQ experts ``[{gate_proj | up_proj | down_proj: {"qweight", "qzeros", "scales"}}]`` (one rank's pieces, cut on packing
+    and group boundaries) -> two ``hip_ops.GptqExperts`` stacks standing for ``w13 [E, 2 I, H]`` (gate columns then up
+    columns of every packed row) and ``w2 [E, H, I]``."""
+    from .hip_ops import GptqExperts
+
+    fused = [concat_out_features([e["gate_proj"], e["up_proj"]]) for e in experts]
+    down = [e["down_proj"] for e in experts]
+
+    def stack(parts):
+        return GptqExperts(*(torch.stack([p[leaf] for p in parts]).contiguous() for leaf in ("qweight", "qzeros", "scales")),
+                           bits, group_size, zero_offset)
+
+    return stack(fused), stack(down)
+
+
 def make_linear(t: Dict[str, torch.Tensor], bits: int = 4, group_size: int = 128, zero_offset: int = 1, device=None):
     """Checkpoint-format tensors (one rank's) -> ``HymetaLinear`` on ``device``."""
     from .linear import HymetaLinear

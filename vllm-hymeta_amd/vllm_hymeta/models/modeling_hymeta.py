@@ -270,9 +270,7 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
             loaded.add(route.param)
             if route.expert_id is not None:
                 _, leaf = loader.expert_leaf(route.param)
-                if leaf in ("qweight", "qzeros", "scales", "g_idx"):
-                    raise ValueError(f"{name}: GPTQ experts are not supported (bf16 and W8A8 experts are)")
-                if leaf not in ("weight", "weight_scale"):
+                if leaf not in ("weight", "weight_scale", "qweight", "qzeros", "scales", "g_idx"):
                     raise ValueError(f"{name}: unexpected expert tensor {leaf!r}")
                 if leaf == "weight" and tensor.dtype not in (torch.bfloat16, torch.float16, torch.float32, torch.int8):
                     raise ValueError(f"{name}: expert weights must be floating point or int8 (W8A8), not {tensor.dtype}")
@@ -284,7 +282,10 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
                     cut = loader.Cut()
                 else:
                     cut = row if route.shard_id == "w2" else col          # experts are cut along their intermediate size
-                piece = loader.own(loader.cut_leaf(leaf, tensor, cut), dev)
+                piece = loader.cut_leaf(leaf, tensor, cut, q["bits"], q["group_size"])
+                if piece is None:          # g_idx: checked (act-order is refused), not kept
+                    continue
+                piece = loader.own(piece, dev)
                 if leaf == "weight" and piece.is_floating_point():
                     piece = piece.to(torch.bfloat16)
                 experts.setdefault(layer, {}).setdefault(route.expert_id, {}).setdefault(proj_of[route.shard_id], {})[leaf] = piece
@@ -340,7 +341,9 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
                 local = expert_range(n_experts, m.tp_size, m.tp_rank) if m.expert_parallel else None
                 held = [mine[e] for e in (range(*local) if local else range(n_experts))]       # this rank's
                 scales = {}
-                if held[0]["gate_proj"]["weight"].dtype == torch.int8:
+                if "qweight" in held[0]["gate_proj"]:
+                    w13, w2 = loader.stack_experts_gptq(held, q["bits"], q["group_size"], q["zero_offset"])
+                elif held[0]["gate_proj"]["weight"].dtype == torch.int8:
                     w13, scales["w13_scale"], w2, scales["w2_scale"] = loader.stack_experts_w8a8(held)
                 else:
                     w13, w2 = loader.stack_experts([{proj: t["weight"] for proj, t in e.items()} for e in held])

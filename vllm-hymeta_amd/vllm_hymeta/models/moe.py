@@ -70,7 +70,8 @@ class HymetaMoE(torch.nn.Module):
                  gate_scale: Optional[torch.Tensor] = None):
         """W8A8 experts (a compressed-tensors W8A8 checkpoint, ``hf_model/quant_w8a8.py:121-132``, quantises every Linear
         but the lm_head: experts and router included): ``w13`` / ``w2`` int8 with ``w13_scale [E, 2I]`` / ``w2_scale [E, H]``;
-        an int8 ``gate_weight`` comes with ``gate_scale [E]`` and the router logits are then that W8A8 linear's output."""
+        an int8 ``gate_weight`` comes with ``gate_scale [E]`` and the router logits are then that W8A8 linear's output.
+        GPTQ experts (``hf_model/hymeta_gptq.py:30-32``): ``w13`` / ``w2`` as ``hip_ops.GptqExperts`` stacks."""
         super().__init__()
         self.w8a8_gate = None
         if gate_weight.dtype == torch.int8:
@@ -82,8 +83,16 @@ class HymetaMoE(torch.nn.Module):
             sc[:E] = gate_scale.reshape(-1).float()
             self.w8a8_gate = HymetaLinear.from_w8a8(pad, sc)
         self.register_buffer("gate_weight", gate_weight)   # [E, H], replicated
-        self.register_buffer("w13", w13)
-        self.register_buffer("w2", w2)
+        self._gptq = None
+        if isinstance(w13, hip_ops.GptqExperts):
+            # the stacks' tensors are the buffers; ``w13`` / ``w2`` (properties below) put them together again
+            self._gptq = {"w13": w13[3:], "w2": w2[3:]}
+            for name, w in (("w13", w13), ("w2", w2)):
+                for leaf, t in zip(("qweight", "qzeros", "scales"), w[:3]):
+                    self.register_buffer(f"{name}_{leaf}", t)
+        else:
+            self.register_buffer("_w13", w13)
+            self.register_buffer("_w2", w2)
         self.register_buffer("w13_scale", w13_scale)
         self.register_buffer("w2_scale", w2_scale)
         self.register_buffer("gate_scale", None if gate_scale is None else gate_scale.reshape(-1).float().contiguous())
@@ -91,6 +100,21 @@ class HymetaMoE(torch.nn.Module):
         self.shared_mlp = shared_mlp
         self.local_experts = local_experts
         self.group = group
+
+    def _stack(self, name: str):
+        if self._gptq is None:
+            return getattr(self, "_" + name)
+        return hip_ops.GptqExperts(getattr(self, name + "_qweight"), getattr(self, name + "_qzeros"), getattr(self, name + "_scales"),
+                                   *self._gptq[name])
+
+    @property
+    def w13(self):
+        """bf16 | int8 ``[E, 2I, H]``, or the ``GptqExperts`` stack standing for it."""
+        return self._stack("w13")
+
+    @property
+    def w2(self):
+        return self._stack("w2")
 
     def router_logits(self, x: torch.Tensor) -> Optional[torch.Tensor]:
         """The router's logits where the block cannot compute them itself (an int8 router above the batch size of the
