@@ -213,9 +213,14 @@ def test_exchange_takes_a_k_sliced_linear_straight_from_its_partial_sums(kind):
 D = 128
 
 
-@pytest.mark.parametrize("expert_parallel", [False, True])
-def test_two_tensor_parallel_ranks_on_one_gpu_equal_the_unsharded_model(expert_parallel):
-    """``expert_parallel``: the routed experts dealt whole to the ranks (2 of the 4 each, only those held) instead of
+@pytest.mark.parametrize("expert_parallel,fmt", [(False, "bf16"), (True, "bf16"), (False, "w8a8"), (True, "w8a8"), (False, "gptq4"),
+                                                 (True, "gptq4")])
+def test_two_tensor_parallel_ranks_on_one_gpu_equal_the_unsharded_model(expert_parallel, fmt):
+    """``fmt``: the checkpoint as bf16, as the W8A8 recipe stores it (int8 linears, experts and router) or as the GPTQ
+    recipe does (packed linears and experts): the quantised formats are cut per rank on their own boundaries (scales with
+    the output rows, packed words and groups with the input rows) and are compared with the unsharded model of the same
+    checkpoint.
+    ``expert_parallel``: the routed experts dealt whole to the ranks (2 of the 4 each, only those held) instead of
     every expert cut along its intermediate size -- the reference's ``--enable-expert-parallel``; either way the layer's
     one all-reduce sums the ranks.
     Configs with tensor parallelism, collectives included, on one GPU: two ranks of HymetaForCausalLM live in one
@@ -243,7 +248,15 @@ def test_two_tensor_parallel_ranks_on_one_gpu_equal_the_unsharded_model(expert_p
     ckpt = _checkpoint(g_, cfg)
     lens = [75, 40]
     ids = [torch.randint(0, cfg.vocab_size, (L + 1,), generator=g_) for L in lens]
-    refs = [hymeta_model_ref(x, ckpt, cfg) for x in ids]
+    refs = [hymeta_model_ref(x, ckpt, cfg) for x in ids] if fmt == "bf16" else None
+    quant = None
+    if fmt == "w8a8":
+        from test_gpu_model_70b import _w8a8_recipe
+        ckpt = _w8a8_recipe(ckpt)
+    elif fmt == "gptq4":
+        from test_gpu_model_70b import _gptq_recipe
+        ckpt, _ = _gptq_recipe(ckpt, g_)
+        quant = {"bits": 4, "group_size": 128, "zero_offset": 1}
     bs = 16
     per_seq = (max(lens) + 1 + bs - 1) // bs
     bt_cpu = torch.randperm(2 * per_seq + 1, generator=g_)[: 2 * per_seq].to(torch.int32).view(2, per_seq)
@@ -254,7 +267,7 @@ def test_two_tensor_parallel_ranks_on_one_gpu_equal_the_unsharded_model(expert_p
     def run_rank(group, out):
         """One rank: build, load, prefill, decode.  ``group`` None = the unsharded model."""
         kvh = cfg.num_key_value_heads // (group.size if group is not None else 1)
-        model = HymetaForCausalLM(cfg, max_num_seqs=4, tp_group=group, device=dev, expert_parallel=expert_parallel)
+        model = HymetaForCausalLM(cfg, max_num_seqs=4, tp_group=group, device=dev, expert_parallel=expert_parallel, quant=quant)
         model.load_weights(ckpt.items())
         if group is not None:
             from vllm_hymeta.models.moe import HymetaMoE
@@ -309,6 +322,11 @@ def test_two_tensor_parallel_ranks_on_one_gpu_equal_the_unsharded_model(expert_p
 
     for key in ("h_pre", "h_dec"):
         assert torch.equal(outs[0][key], outs[1][key]), f"{key}: the two ranks differ"
+    if fmt != "bf16":
+        # (W8A8: a rank quantises the slice of an activated row that it holds, with the slice's own scale)
+        assert_bf16_close(outs[0]["h_pre"], full["h_pre"].float(), f"TP=2 {fmt} model against the unsharded one, prefill", rel=3e-2, frac=0.15)
+        assert_bf16_close(outs[0]["h_dec"], full["h_dec"].float(), f"TP=2 {fmt} model against the unsharded one, decode", rel=3e-2, frac=0.15)
+        return
     ref_pre = torch.cat([r[0][:L] for r, L in zip(refs, lens)])
     ref_dec = torch.stack([r[0][L] for r, L in zip(refs, lens)])
     assert_bf16_close(outs[0]["h_pre"], ref_pre, "TP=2 model, prefill hidden states", rel=2e-2, frac=2.0 ** -4)
