@@ -339,25 +339,39 @@ def tp_main(args):
     note(rank, f"all-reduce path: {all_reduce_path}" + ("" if all_reduce_path != "rccl" else f" ({why})"))
 
     batch, ctx, total = args.batch, args.ctx if args.ctx_given else 32768, args.warmup + args.steps
-    note(rank, f"{world} ranks: tp{tp} x {replicas}; building the model")
-    model, cfg = build_model_70b(dev, args.quant, batch, tp_group, args.tp_layers, expert_parallel=args.ep)
-    runner = B1.DecodeRunner(model, batch, ctx, total + 8, dev, seed=plan["batch_seed"])
-    runner.sampler = VocabParallelGreedy(model, tp_group, plan["rank_in_group"], shard_tp, batch, dev, ranks_in_exchange=tp)
-    hit = experts_hit(model, runner)
-    note(rank, f"model built ({torch.cuda.memory_allocated(dev) / 2 ** 30:.1f} GiB allocated), experts hit {hit}")
-    if args.tp_eager:
-        for _ in range(2):
-            runner.eager_step()
-        stepper = EagerRunner(runner)
-    else:
-        runner.capture(before_capture=settle, capture_error_mode="thread_local")
-        stepper = runner
-    torch.cuda.synchronize()
-    note(rank, "step ready; timing")
-    elapsed, gpu_ms = B1.timed_steps(stepper, args.warmup, args.steps, dist=dist)
-    t = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, gpu_ms = float(t[0]), float(t[1])
+
+    def measure(quant):
+        """Build the rank's model from the synthetic checkpoint of one weight format, capture its step, time it: every
+        rank makes the same calls (the step holds collectives).  The model is gone when this returns."""
+        note(rank, f"{world} ranks: tp{tp} x {replicas}; building the {quant} model")
+        model, cfg_ = build_model_70b(dev, quant, batch, tp_group, args.tp_layers, expert_parallel=args.ep)
+        runner = B1.DecodeRunner(model, batch, ctx, total + 8, dev, seed=plan["batch_seed"])
+        runner.sampler = VocabParallelGreedy(model, tp_group, plan["rank_in_group"], shard_tp, batch, dev, ranks_in_exchange=tp)
+        hit_ = experts_hit(model, runner)
+        note(rank, f"model built ({torch.cuda.memory_allocated(dev) / 2 ** 30:.1f} GiB allocated), experts hit {hit_}")
+        if args.tp_eager:
+            for _ in range(2):
+                runner.eager_step()
+            stepper = EagerRunner(runner)
+        else:
+            runner.capture(before_capture=settle, capture_error_mode="thread_local")
+            stepper = runner
+        torch.cuda.synchronize()
+        note(rank, "step ready; timing")
+        elapsed_, gpu_ms_ = B1.timed_steps(stepper, args.warmup, args.steps, dist=dist)
+        t_ = torch.tensor([elapsed_, gpu_ms_], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        del stepper, runner, model
+        from vllm_hymeta.models import attention
+        attention.release_layers("model.")        # the registry of attention layers holds the model's KV caches
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        note(rank, f"model released ({torch.cuda.memory_allocated(dev) / 2 ** 30:.1f} GiB still allocated)")
+        return float(t_[0]), float(t_[1]), hit_, cfg_
+
+    elapsed, gpu_ms, hit, cfg = measure(args.quant)
     note(rank, f"timed: {gpu_ms:.3f} ms/step; timing the collectives alone")
     coll_ms = collectives_alone(cfg, batch, tp_group, dev)
     c = torch.tensor([coll_ms], dtype=torch.float64, device=dev)
@@ -428,6 +442,20 @@ def tp_main(args):
             "avg_launch_ms": round(gpu_ms, 5),
         },
     }
+    # the same step from the quantised checkpoints (experts and, for W8A8, the router quantised as the recipes do)
+    if args.quant == "bf16" and not args.no_side:
+        line["model_decode"] = {"bf16": {"ms_per_step": line["ms_per_step"], "tokens_per_s": line["value"], "hbm_frac": line["roofline"]["frac"]}}
+        for q in ("gptq4", "w8a8"):
+            try:
+                el, ms, hit_q, _ = measure(q)
+                nb, _ = step_bytes_70b(cfg, q, shard_tp, batch, ctx, hit_q, expert_parallel=args.ep and shard_tp > 1)
+                line["model_decode"][q] = {"ms_per_step": round(el / args.steps * 1e3, 4),
+                                           "tokens_per_s": round(replicas * batch * args.steps / el, 1),
+                                           "hbm_frac": round(nb / (ms * 1e-3) / 1e9 / B1.HBM_PEAK_GBS, 4),
+                                           "algorithmic_bytes_per_launch": nb, "experts_hit_per_mixture_layer": hit_q}
+            except Exception as exc:      # the headline line stands on its own
+                line["model_decode"][q] = {"error": f"{type(exc).__name__}: {exc}"}
+                break
     if rank == 0:
         print(json.dumps(line), flush=True)
     parallel.disable_one_shot_all_reduce(tp_group)
