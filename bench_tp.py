@@ -363,7 +363,8 @@ def tp_main(args):
         dist.all_reduce(t_, op=dist.ReduceOp.MAX)
         del stepper, runner, model
         from vllm_hymeta.models import attention
-        attention.release_layers("model.")        # the registry of attention layers holds the model's KV caches
+        for name in list(attention.registered_layers()):      # the registry of attention layers holds the model's KV caches
+            attention.release_layers(name)
         import gc
         gc.collect()
         torch.cuda.synchronize()
