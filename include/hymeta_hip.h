@@ -943,7 +943,7 @@ typedef struct hymeta_moe_gptq_gemm_args {
 int hymeta_moe_gptq_gemm(const hymeta_moe_gptq_gemm_args* args, hymeta_stream_t stream);
 
 /* `experts` stacked GPTQ matrices (layouts above, starting at the pointers given) -> bf16 W^T [experts, N, K], the
- * layout of the bf16 expert stacks: one launch.  K % (32 * (32 / bits)) == 0. */
+ * layout of the bf16 expert stacks: one launch.  K % (16 * (32 / bits)) == 0. */
 int hymeta_moe_gptq_expand(const int32_t* qweight, const int32_t* qzeros, const void* scales, void* out, int32_t experts,
                            int32_t K, int32_t N, int32_t bits, int32_t group_size, int32_t scales_dtype, int32_t zero_offset,
                            hymeta_stream_t stream);

@@ -238,7 +238,7 @@ def test_gptq_checkpoint_with_quantised_experts():
     quantised, expanded = _gptq_recipe(_checkpoint(g_, cfg), g_)
     bs = 16
     outs = {}
-    for lens in ([60, 33], [150, 160]):          # 93 pairs on 4 experts: the fused kernel; 310: the expansion
+    for lens in ([60, 33], [400, 420]):          # 93 pairs on 4 experts: the fused kernel; 820: the expansion
         ids = [torch.randint(0, cfg.vocab_size, (L,), generator=g_) for L in lens]
         per_seq = (max(lens) + bs - 1) // bs
         bt = torch.arange(2 * per_seq, dtype=torch.int32).view(2, per_seq).to(dev)

@@ -395,8 +395,9 @@ def _gptq_experts(seed, E, K, N, bits, group, scales_dtype=torch.float16):
     (1, 16, 1, False, 256, 128, 4, 128),       # one decode token
     (64, 16, 1, True, 512, 384, 4, 128),       # decode batch, 16-row tiles, waves with uneven group counts (3 groups on 4 waves)
     (64, 4, 2, False, 256, 256, 8, 64),        # 8-bit, group 64, two choices: 32-row tiles walked inside the workgroup
-    (120, 4, 1, True, 256, 128, 4, 32),        # group 32; 30 rows per expert on average: still the fused kernel
-    (400, 4, 1, True, 512, 256, 4, 128),       # prefill-sized: experts expanded to bf16, tiled grouped GEMM
+    (400, 4, 1, True, 256, 128, 4, 32),        # group 32; 100 rows per expert on average: still the fused kernel
+    (800, 4, 1, True, 512, 256, 4, 128),       # prefill-sized: experts expanded to bf16, tiled grouped GEMM
+    (800, 4, 1, False, 512, 384, 4, 128),      # the same with a down projection whose K is three groups (no multiple of 256)
 ])
 def test_moe_forward_with_gptq_experts(T, E, top_k, with_shared, H, inter, bits, group):
     """Experts as a GPTQ checkpoint holds them: decode-sized batches through the fused de-quantising grouped GEMM,
@@ -429,7 +430,7 @@ def test_gptq_experts_expert_parallel_and_the_expansion():
     assert torch.equal(hip_ops.moe_gptq_expand(s13), dense)
     cut = lambda w, lo, hi: w._replace(qweight=w.qweight[lo:hi].contiguous(), qzeros=w.qzeros[lo:hi].contiguous(),
                                        scales=w.scales[lo:hi].contiguous())
-    for T in (64, 600):
+    for T in (64, 1400):      # both regimes: the fused kernel, and the expansion for the shares and for the whole
         x, gate_w, _, _, logits = _problem(21 + T, T, H, 64, E)
         xd, ld = x.cuda(), logits.cuda()
         total = torch.zeros(T, H)

@@ -230,15 +230,16 @@ __global__ __launch_bounds__(256) void moe_gptq_gemm_kernel(hymeta_moe_gptq_gemm
 }
 
 // Every local expert's matrix expanded to bf16 W^T [N, K] (the layout of the bf16 expert stacks) in one launch, for
-// prefill-sized batches: the tiled bf16 grouped GEMM then runs on the expansion.  grid = (N / 64, K / (32 PACK), experts);
-// a workgroup expands 64 columns x 32 packed rows of one expert through an LDS tile [column][k] and stores whole
-// 32 PACK-element runs of one output row.
+// prefill-sized batches: the tiled bf16 grouped GEMM then runs on the expansion.  grid = (N / 64, K / (16 PACK), experts);
+// a workgroup expands 64 columns x 16 packed rows of one expert (128 k at 4 bits: a tensor-parallel shard's K is a whole
+// number of groups, not of 256) through an LDS tile [column][k] and stores whole 16 PACK-element runs of one output row.
 template <int BITS>
 __global__ __launch_bounds__(256) void moe_gptq_expand_kernel(const int32_t* __restrict__ qweight, const int32_t* __restrict__ qzeros,
                                                               const void* __restrict__ scales, uint16_t* __restrict__ out, int K,
                                                               int N, int group_size, int scales_dtype, int zero_offset) {
   constexpr int PACK = 32 / BITS;
-  constexpr int TK = 32 * PACK;
+  constexpr int TKP = 16;                       // packed rows of a tile
+  constexpr int TK = TKP * PACK;
   constexpr int PITCH = TK * 2 + 16;
   __shared__ __attribute__((aligned(16))) unsigned char tile[64 * PITCH];
   const int e = blockIdx.z;
@@ -247,11 +248,11 @@ __global__ __launch_bounds__(256) void moe_gptq_expand_kernel(const int32_t* __r
   qzeros += static_cast<int64_t>(e) * G * (N / PACK);
   const uint16_t* sc16 = reinterpret_cast<const uint16_t*>(scales) + static_cast<int64_t>(e) * G * N;
   out += static_cast<int64_t>(e) * N * K;
-  const int n0 = blockIdx.x * 64, kp0 = blockIdx.y * 32;
+  const int n0 = blockIdx.x * 64, kp0 = blockIdx.y * TKP;
   const int lane_n = threadIdx.x & 63, sub = threadIdx.x >> 6;
   const int n = n0 + lane_n;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < TKP / 4; ++i) {
     const int kp = kp0 + sub + 4 * i;
     const int g = kp * PACK / group_size;
     const uint32_t qw = static_cast<uint32_t>(qweight[static_cast<int64_t>(kp) * N + n]);
@@ -337,8 +338,8 @@ extern "C" int hymeta_moe_gptq_expand(const int32_t* qweight, const int32_t* qze
   if (experts == 0) return HYMETA_OK;
   if (!qweight || !qzeros || !scales || !out) return HYMETA_ERR_INVALID_ARG;
   const int pack = 32 / bits;
-  if (K % (32 * pack) != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
-  const dim3 grid(static_cast<unsigned>(N / 64), static_cast<unsigned>(K / (32 * pack)), static_cast<unsigned>(experts));
+  if (K % (16 * pack) != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+  const dim3 grid(static_cast<unsigned>(N / 64), static_cast<unsigned>(K / (16 * pack)), static_cast<unsigned>(experts));
   if (grid.y > 65535u || grid.z > 65535u) return HYMETA_ERR_UNSUPPORTED;
   hipStream_t s = begin_launches(stream);
   uint16_t* o = static_cast<uint16_t*>(out);

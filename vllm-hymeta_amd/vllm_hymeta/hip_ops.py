@@ -1175,8 +1175,9 @@ class GptqExperts(NamedTuple):
 
 # Rows per local expert (on average) up to which GPTQ experts run the fused de-quantising grouped GEMM; above, the local
 # experts are expanded to bf16 once per call and the tiled bf16 grouped GEMM runs on the expansion (the fused kernel
-# re-reads an expert's weights per 32-row tile).
-MOE_GPTQ_FUSED_ROWS_PER_EXPERT = 32
+# re-reads an expert's weights per 32-row tile).  Measured on the 70B TP=4 shapes (16 experts, us per block, fused /
+# expanded): 1024 tokens 466 / 796, 2048: 777 / 943, 4096: 1373 / 1164, 8192: 2569 / 1557.
+MOE_GPTQ_FUSED_ROWS_PER_EXPERT = int(os.environ.get("HYMETA_MOE_GPTQ_FUSED_ROWS", "160"))
 
 
 def moe_gptq_expand(w: GptqExperts) -> torch.Tensor:
@@ -1185,7 +1186,7 @@ def moe_gptq_expand(w: GptqExperts) -> torch.Tensor:
     pack = 32 // w.bits
     _require(w.qweight.dtype == torch.int32 and w.qweight.is_contiguous() and w.qzeros.is_contiguous() and w.scales.is_contiguous(),
              "GPTQ expert tensors must be contiguous")
-    _require(N % 64 == 0 and K % (32 * pack) == 0, "expansion needs N % 64 == 0 and K % (32 * pack) == 0")
+    _require(N % 64 == 0 and K % (16 * pack) == 0, "expansion needs N % 64 == 0 and K % (16 * pack) == 0")
     ws = _workspace(w.qweight.device, E * N * K * 2, f"moe_gptq_expand_{N}x{K}")
     out = ws[: E * N * K * 2].view(torch.bfloat16).view(E, N, K)
     sd = _C.HYMETA_F16 if w.scales.dtype == torch.float16 else _C.HYMETA_BF16
