@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import json
 import os
+import time
 import sys
 
 import torch
@@ -213,6 +214,70 @@ def step_bytes_70b(cfg, quant, tp, batch, ctx, hit, expert_parallel=False):
     return int(sum(parts.values())), {k: int(v) for k, v in parts.items()}
 
 
+class MixedChunkStep:
+    """One serving step of chunked prefill beside a decode batch (the engine's mixed step): a ``chunk``-token piece of a
+    prompt that already has ``ctx`` tokens cached, and one token each of ``n_decode`` sequences at ``ctx`` tokens, through
+    the whole rank (eager launches: the engine does not capture prefill steps)."""
+
+    def __init__(self, model, chunk, ctx, n_decode, dev):
+        from vllm_hymeta.attention.meta_attention import MetaAttentionMetadata
+
+        self.model = model
+        m = model.model
+        per_seq = (ctx + chunk + B1.BLOCK - 1) // B1.BLOCK
+        nseq = 1 + n_decode
+        self.kv = [torch.randn(2, nseq * per_seq, B1.BLOCK, m.shard.num_kv_heads, B1.D, device=dev, dtype=torch.bfloat16)
+                   for _ in m.attn_layers]
+        bt = torch.arange(nseq * per_seq, dtype=torch.int32, device=dev).view(nseq, per_seq)
+        g = torch.Generator(device="cpu")
+        g.manual_seed(11)
+        T = chunk + n_decode
+        self.ids = torch.randint(0, m.config.vocab_size, (T,), generator=g).to(dev)
+        self.pos = torch.cat([torch.arange(ctx, ctx + chunk), torch.full((n_decode,), ctx)]).to(dev)
+        slots = torch.cat([bt[0, 0] * B1.BLOCK + torch.arange(ctx, ctx + chunk, device=dev),
+                           bt[1:, 0] * B1.BLOCK + ctx]).long()
+        qlens = [chunk] + [1] * n_decode
+        seq_lens = [ctx + chunk] + [ctx + 1] * n_decode
+        cu = lambda xs: torch.tensor([0] + list(torch.tensor(xs).cumsum(0)), dtype=torch.int32, device=dev)
+        self.md = MetaAttentionMetadata(
+            num_prefills=1, num_prefill_tokens=chunk, num_decode_tokens=n_decode, slot_mapping=slots,
+            multi_modal_placeholder_index_maps=None, enable_kv_scales_calculation=False, seq_lens=seq_lens,
+            seq_lens_tensor=torch.tensor(seq_lens, dtype=torch.int32, device=dev), max_prefill_seq_len=ctx + chunk,
+            max_decode_seq_len=ctx + 1 if n_decode else 0,
+            context_lens_tensor=torch.tensor([ctx] + [ctx] * n_decode, dtype=torch.int32, device=dev), block_tables=bt,
+            use_cuda_graph=False, max_query_len=chunk, max_decode_query_len=1, query_start_loc=cu(qlens), seq_start_loc=cu(seq_lens))
+        cache, idx = model.get_seqlen_agnostic_capture_inputs(nseq)
+        idx.copy_(torch.arange(nseq, dtype=idx.dtype, device=dev))
+        self.capture_inputs = (cache, idx)
+
+    def step(self):
+        return self.model(self.ids, self.pos, attn_metadata=self.md, kv_caches=self.kv,
+                          seqlen_agnostic_capture_inputs=self.capture_inputs)
+
+
+def time_mixed_chunks(model, ctx, dev, dist_=None):
+    """ms per mixed step (max over ranks) for the chunk sizes of the serving configurations: 2048 and 8192 prompt tokens
+    beside 32 decode rows at ``ctx`` cached tokens."""
+    out = {}
+    for chunk in (2048, 8192):
+        stepper = MixedChunkStep(model, chunk, ctx - chunk, 32, dev)
+        stepper.step()
+        torch.cuda.synchronize()
+        if dist_ is not None:
+            dist_.barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            stepper.step()
+        torch.cuda.synchronize()
+        ms = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], dtype=torch.float64, device=dev)
+        if dist_ is not None:
+            dist_.all_reduce(ms, op=dist_.ReduceOp.MAX)
+        out[str(chunk)] = {"ms_per_step": round(float(ms[0]), 3), "prompt_tokens_per_s": round(chunk / float(ms[0]) * 1e3, 1)}
+        del stepper
+        torch.cuda.empty_cache()
+    return out
+
+
 def settle():
     """Called right before a stream capture.  What used to take the process down here: the process group's watchdog
     thread polls the end events of the eager collectives it still holds, those events sit on the group's communication
@@ -340,6 +405,8 @@ def tp_main(args):
 
     batch, ctx, total = args.batch, args.ctx if args.ctx_given else 32768, args.warmup + args.steps
 
+    mixed = {}        # chunked-prefill steps per weight format, filled by measure()
+
     def measure(quant):
         """Build the rank's model from the synthetic checkpoint of one weight format, capture its step, time it: every
         rank makes the same calls (the step holds collectives).  The model is gone when this returns."""
@@ -361,7 +428,14 @@ def tp_main(args):
         elapsed_, gpu_ms_ = B1.timed_steps(stepper, args.warmup, args.steps, dist=dist)
         t_ = torch.tensor([elapsed_, gpu_ms_], dtype=torch.float64, device=dev)
         dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-        del stepper, runner, model
+        del stepper, runner
+        torch.cuda.empty_cache()
+        if not args.no_side and not args.no_prefill:
+            try:
+                mixed[quant] = time_mixed_chunks(model, ctx, dev, dist)
+            except Exception as exc:
+                mixed[quant] = {"error": f"{type(exc).__name__}: {exc}"}
+        del model
         from vllm_hymeta.models import attention
         for name in list(attention.registered_layers()):      # the registry of attention layers holds the model's KV caches
             attention.release_layers(name)
@@ -457,6 +531,11 @@ def tp_main(args):
             except Exception as exc:      # the headline line stands on its own
                 line["model_decode"][q] = {"error": f"{type(exc).__name__}: {exc}"}
                 break
+    if mixed:
+        line["chunked_prefill"] = {
+            "step": "one chunk of a prompt with the rest of the context cached + 32 decode rows at that context, whole rank, "
+                    "eager launches, all-reduces included; ms = max over ranks",
+            "ctx": ctx, "by_format": mixed}
     if rank == 0:
         print(json.dumps(line), flush=True)
     parallel.disable_one_shot_all_reduce(tp_group)
