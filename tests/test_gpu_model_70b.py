@@ -263,3 +263,78 @@ def test_gptq_checkpoint_with_quantised_experts():
         assert torch.isfinite(outs["gptq"]).all()
         assert_bf16_close(outs["gptq"], outs["bf16"], f"70B GPTQ checkpoint, {sum(lens)} tokens: packed against expanded weights",
                           rel=2e-2, frac=0.1)
+
+
+@pytest.mark.parametrize("stages", [2, 3])
+def test_pipeline_stages_equal_the_whole_model(stages):
+    """The reference's 8-GPU recipe is TP4 x PP2: the model cut into pipeline stages (here all in one process, the
+    hand-off carried by the test).  The meta rows pass from stage to stage once, at load time; every serving step hands
+    ``IntermediateTensors`` on; prefill and decode of two sequences give the whole model's hidden states and logits bit
+    for bit (the hand-off sum is the one the next block's fused add + norm forms)."""
+    from vllm_hymeta import _compat
+    from vllm_hymeta.models.configuration_hymeta import HymetaConfig
+    from vllm_hymeta.models.modeling_hymeta import HymetaForCausalLM
+
+    dev = torch.device("cuda")
+    g_ = gen(41)
+    cfg = HymetaConfig(vocab_size=512, hidden_size=512, num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=2,
+                       intermediate_size=512, shared_intermediate_size=256, num_local_experts=4, num_meta_tokens=32,
+                       sliding_window=48, max_position_embeddings=1024)
+    ckpt = _checkpoint(g_, cfg)
+    whole = HymetaForCausalLM(cfg, max_num_seqs=4, device=dev)
+    whole.load_weights(ckpt.items())
+    pipe = [HymetaForCausalLM(cfg, max_num_seqs=4, device=dev, pp_rank=r, pp_size=stages) for r in range(stages)]
+    rows = None
+    for st in pipe:
+        st.load_weights(ckpt.items())
+        if st.model.pp_rank > 0:
+            assert not st.model.has_meta_cache
+            with pytest.raises(RuntimeError, match="meta caches are empty"):
+                st(None, torch.zeros(1, dtype=torch.long, device=dev), attn_metadata=object(),
+                   intermediate_tensors=st.make_empty_intermediate_tensors(1, torch.bfloat16, dev))
+            st.model.prepare_meta_caches(rows)
+        rows = st.model.meta_hidden_out
+        assert st.model.has_meta_cache and rows.shape == (cfg.num_meta_tokens, cfg.hidden_size)
+    with pytest.raises(RuntimeError, match="stage before it"):
+        HymetaForCausalLM(cfg, max_num_seqs=4, device=dev, pp_rank=1, pp_size=2).model.prepare_meta_caches()
+
+    lens = [75, 40]
+    ids = [torch.randint(0, cfg.vocab_size, (L + 1,), generator=g_) for L in lens]
+    bs = 16
+    per_seq = (max(lens) + 1 + bs - 1) // bs
+    bt = torch.randperm(2 * per_seq + 1, generator=g_)[: 2 * per_seq].to(torch.int32).view(2, per_seq).to(dev)
+    slot = lambda s_, t: int(bt[s_, t // bs]) * bs + t % bs
+    run = dict(request_ids_to_seq_ids={"a": [0], "b": [1]}, finished_requests_ids=[])
+
+    def caches(model):
+        return [torch.zeros(2, 2 * per_seq + 1, bs, cfg.num_key_value_heads, D, dtype=torch.bfloat16, device=dev)
+                for _ in model.model.attn_layers]
+
+    kv_whole, kv_pipe = caches(whole), [caches(st) for st in pipe]
+
+    def through_pipe(ids_, pos_, md_):
+        x = None
+        for st, kv in zip(pipe, kv_pipe):
+            x = st(ids_ if st.model.is_first_stage else None, pos_, intermediate_tensors=x, attn_metadata=md_, kv_caches=kv, **run)
+            if not st.model.is_last_stage:
+                assert isinstance(x, _compat.IntermediateTensors) and not bool(x["residual"].any())
+        return x
+
+    pre_ids = torch.cat([x[:L] for x, L in zip(ids, lens)]).to(dev)
+    pre_pos = torch.cat([torch.arange(L) for L in lens]).to(dev)
+    pre_slots = torch.tensor([slot(s_, t) for s_, L in enumerate(lens) for t in range(L)], device=dev)
+    md = _md(dev, prefill_lens=lens, context_lens=[0, 0], slot_mapping=pre_slots)
+    h_whole = whole(pre_ids, pre_pos, attn_metadata=md, kv_caches=kv_whole, **run)
+    h_pipe = through_pipe(pre_ids, pre_pos, md)
+    torch.cuda.synchronize()
+    assert torch.equal(h_whole, h_pipe)
+
+    dec_ids = torch.stack([x[L] for x, L in zip(ids, lens)]).to(dev)
+    dec_pos = torch.tensor(lens, device=dev)
+    dec_slots = torch.tensor([slot(s_, L) for s_, L in enumerate(lens)], device=dev)
+    md = _md(dev, decode_seq_lens=[L + 1 for L in lens], block_tables=bt, slot_mapping=dec_slots)
+    d_whole = whole(dec_ids, dec_pos, attn_metadata=md, kv_caches=kv_whole, **run)
+    d_pipe = through_pipe(dec_ids, dec_pos, md)
+    torch.cuda.synchronize()
+    assert torch.equal(d_whole, d_pipe)
+    assert torch.equal(whole.compute_logits(d_whole), pipe[-1].compute_logits(d_pipe))

@@ -102,6 +102,58 @@ def test_70b_checkpoint_loads_per_rank(tp, monkeypatch):
                 assert moe.shared_mlp.gate_up_proj.weight.shape == (2 * 256 // tp, 512) and not moe.shared_mlp.reduce_results
 
 
+def test_pipeline_stage_layer_ranges():
+    """vLLM's partition rule: equal shares, the remainder one each to the stages counted back from the second to last."""
+    from vllm_hymeta.models.modeling_hymeta import pp_layer_range
+
+    assert [pp_layer_range(28, r, 2) for r in range(2)] == [(0, 14), (14, 28)]
+    assert [pp_layer_range(28, r, 4) for r in range(4)] == [(0, 7), (7, 14), (14, 21), (21, 28)]
+    assert [pp_layer_range(30, r, 4) for r in range(4)] == [(0, 7), (7, 15), (15, 23), (23, 30)]
+    assert [pp_layer_range(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    assert pp_layer_range(28, 0, 1) == (0, 28)
+    for L, n in ((28, 3), (31, 8), (7, 7)):
+        spans = [pp_layer_range(L, r, n) for r in range(n)]
+        assert spans[0][0] == 0 and spans[-1][1] == L and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    with pytest.raises(ValueError):
+        pp_layer_range(28, 2, 2)
+
+
+def test_70b_checkpoint_loads_per_pipeline_stage():
+    """A stage keeps its own layers (caches and attention layers sized to them, registered under their global names), the
+    first one the embedding and the meta tokens, the last one the final norm and the lm_head."""
+    from vllm_hymeta.models import modeling_hymeta as mod
+    from vllm_hymeta.models.configuration_hymeta import HymetaConfig
+
+    cfg = HymetaConfig(vocab_size=512, hidden_size=512, num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=2,
+                       intermediate_size=512, shared_intermediate_size=256, num_local_experts=4, num_meta_tokens=32,
+                       sliding_window=48, max_position_embeddings=1024)
+    ckpt = ckpt_70b(gen(1), cfg)
+    whole = mod.HymetaForCausalLM(cfg, max_num_seqs=3, device="cpu")
+    whole.load_weights(ckpt.items())
+    loaded_all = set()
+    for rank in range(2):
+        model = mod.HymetaForCausalLM(cfg, max_num_seqs=3, device="cpu", pp_rank=rank, pp_size=2)
+        loaded = model.load_weights(ckpt.items())
+        loaded_all |= loaded
+        m = model.model
+        assert (m.start_layer, m.end_layer) == ((0, 2), (2, 4))[rank] and len(m.layers) == 2 and len(m.attn_layers) == 2
+        assert m.cache_shape[0] == 2 and m.meta_fattn_cache_shape[0] == 2
+        assert [a.layer_name.split("model.")[-1] for a in m.attn_layers] == [f"layers.{i}.attn.vanilla_attn.attn" for i in
+                                                                             range(m.start_layer, m.end_layer)]
+        assert (m.embeddings is not None) == (rank == 0) and (m.meta_tokens is not None) == (rank == 0)
+        assert (m.norm is not None) == (rank == 1) and (model.lm_head is not None) == (rank == 1)
+        assert all(not (f"layers.{i}." in name) for name in loaded for i in range(4) if not m.start_layer <= i < m.end_layer)
+        for j, layer in enumerate(m.layers):      # the stage's layer j is the whole model's layer start + j
+            ref = whole.model.layers[m.start_layer + j]
+            assert torch.equal(layer.attn.out_proj.weight, ref.attn.out_proj.weight)
+            assert type(layer.mlp) is type(ref.mlp)
+        assert torch.equal(m.lower_bounds, whole.model.lower_bounds)
+        assert callable(model.make_empty_intermediate_tensors)
+        empty = model.make_empty_intermediate_tensors(5, torch.bfloat16, "cpu")
+        assert empty["hidden_states"].shape == (5, 512) and empty["residual"].shape == (5, 512)
+    assert "lm_head.weight" in loaded_all and "model.embeddings.weight" in loaded_all
+
+
 def test_whole_model_restatements_run():
     from oracle.model import glaswa_model_ref, hymeta_model_ref
     from vllm_hymeta.model_for_7B.configuration_gla_swa import GLAswaConfig

@@ -55,8 +55,10 @@ def test_model_classes_carry_the_vllm_interfaces():
     for cls in (HymetaForCausalLM, GLAswaForCausalLM):
         for mixin in (_compat.HasInnerState, _compat.IsHybrid, _compat.SupportsV0Only):
             assert issubclass(cls, mixin)
-        # pipeline parallelism is not implemented, and the classes do not claim it (vLLM checks ``supports_pp``)
-        assert not issubclass(cls, _compat.SupportsPP) and not hasattr(cls, "make_empty_intermediate_tensors")
+    # the 70B class has pipeline stages and says so (vLLM checks ``supports_pp`` and ``make_empty_intermediate_tensors``);
+    # the 7B class has none and does not claim any
+    assert issubclass(HymetaForCausalLM, _compat.SupportsPP)
+    assert not issubclass(GLAswaForCausalLM, _compat.SupportsPP) and not hasattr(GLAswaForCausalLM, "make_empty_intermediate_tensors")
 
 
 def test_70b_built_from_vllm_config_registers_and_binds(fresh_registry):
@@ -135,9 +137,13 @@ def test_7b_built_from_vllm_config_registers_sliding_window_layers(fresh_registr
 def test_unsupported_engine_settings_are_refused(fresh_registry):
     from vllm_hymeta.models.modeling_hymeta import HymetaForCausalLM
 
+    from vllm_hymeta.model_for_7B.modeling_gla_swa import GLAswaForCausalLM
+
     cfg = _cfg70()
     with pytest.raises(NotImplementedError, match="pipeline"):
-        HymetaForCausalLM(vllm_config=vllm_config_like(cfg, pp=2))
+        GLAswaForCausalLM(vllm_config=vllm_config_like(_cfg7(), pp=2))
+    with pytest.raises(RuntimeError, match="pipeline_parallel_rank"):
+        HymetaForCausalLM(vllm_config=vllm_config_like(cfg, pp=2))      # no vLLM pipeline group and no rank given
     with pytest.raises(NotImplementedError, match="desc_act"):
         HymetaForCausalLM(vllm_config=vllm_config_like(cfg, quant_config=SimpleNamespace(weight_bits=4, group_size=128, desc_act=True)))
     with pytest.raises(RuntimeError, match="tensor_parallel_size"):

@@ -84,6 +84,9 @@ class ModelBuildArgs:
     cache_config: Any
     prefix: str
     expert_parallel: bool = False      # ``--enable-expert-parallel`` (``parallel_config.enable_expert_parallel``)
+    pp_rank: int = 0                   # this process's pipeline stage
+    pp_size: int = 1
+    pp_group: Any = None               # torch.distributed group of the stages (rank in it = stage), or None
 
 
 def quant_args(quant_config) -> Optional[Dict[str, int]]:
@@ -113,19 +116,39 @@ def tensor_parallel_group(tp_size: int):
     raise RuntimeError(f"tensor_parallel_size={tp_size} needs an initialised torch.distributed world of that size")
 
 
-def model_build_args(vllm_config, prefix: str = "") -> ModelBuildArgs:
+def pipeline_parallel_stage(parallel_config, pp_size: int):
+    """(stage of this process, group of the stages): vLLM's pipeline group under vLLM; otherwise the duck-typed
+    ``parallel_config.pipeline_parallel_rank`` / ``.pipeline_parallel_group`` (tests, launchers of their own)."""
+    if HAVE_VLLM:  # pragma: no cover - only where vLLM is installed
+        from vllm.distributed import get_pp_group
+        g = get_pp_group()
+        return int(g.rank_in_group), g.device_group
+    rank = getattr(parallel_config, "pipeline_parallel_rank", None)
+    if rank is None:
+        raise RuntimeError(f"pipeline_parallel_size={pp_size} without vLLM needs parallel_config.pipeline_parallel_rank")
+    return int(rank), getattr(parallel_config, "pipeline_parallel_group", None)
+
+
+def model_build_args(vllm_config, prefix: str = "", pipeline: bool = False) -> ModelBuildArgs:
+    """``pipeline``: the calling model class has pipeline stages; a ``pipeline_parallel_size`` above 1 is refused for
+    one that has not."""
     mc = vllm_config.model_config
     config = mc.hf_config
     if isinstance(getattr(mc, "max_model_len", None), int):
         config.max_model_len = mc.max_model_len                      # reference :1401-1402
     pc = getattr(vllm_config, "parallel_config", None)
     tp = int(getattr(pc, "tensor_parallel_size", 1) or 1)
-    if int(getattr(pc, "pipeline_parallel_size", 1) or 1) > 1:
-        raise NotImplementedError("pipeline parallelism is not implemented by the HIP model classes; use tensor parallelism "
-                                  "(TP 1, 2 or 4) and replicas")
+    pp = int(getattr(pc, "pipeline_parallel_size", 1) or 1)
+    pp_rank, pp_group = 0, None
+    if pp > 1:
+        if not pipeline:
+            raise NotImplementedError("pipeline parallelism is not implemented by this model class; use tensor "
+                                      "parallelism and replicas")
+        pp_rank, pp_group = pipeline_parallel_stage(pc, pp)
     device = getattr(getattr(vllm_config, "device_config", None), "device", None) or "cuda"
     return ModelBuildArgs(config=config, max_num_seqs=int(vllm_config.scheduler_config.max_num_seqs),
                           quant=quant_args(getattr(vllm_config, "quant_config", None)),
                           tp_group=tensor_parallel_group(tp), device=device,
                           cache_config=getattr(vllm_config, "cache_config", None), prefix=prefix,
-                          expert_parallel=bool(getattr(pc, "enable_expert_parallel", False)))
+                          expert_parallel=bool(getattr(pc, "enable_expert_parallel", False)),
+                          pp_rank=pp_rank, pp_size=pp, pp_group=pp_group)

@@ -16,9 +16,12 @@ What differs in mechanism:
 * a new sequence's state slot is seeded from the meta state by the prefill kernel
   (``context_lens == 0``), not zeroed on the host (``_clear_prefill_cache``, ``:1202-1227``);
 * tensors are ingested in checkpoint format and cut for the rank by ``vllm_hymeta.loader``.
-Pipeline parallelism is not implemented: the classes do not declare ``SupportsPP`` (vLLM then refuses a
-``pipeline_parallel_size`` above 1 by itself, and ``_compat.model_build_args`` refuses it when the model is built).
-The reference's 8-GPU recipe is TP4 x PP2 (``readme.md:113-114``); here 8 GPUs run as two TP4 replicas.
+Pipeline parallelism (the reference's 8-GPU recipe is TP4 x PP2, ``readme.md:113-114``; ``:1103-1110, 1132,
+1190-1193, 1281-1296, 1356-1364, 1471-1486``): a stage holds a contiguous range of layers (vLLM's partition rule), the
+first one the embedding and the meta tokens, the last one the final norm and the lm_head; a stage hands the next
+``IntermediateTensors`` with ``hidden_states`` = the residual stream and ``residual`` = zeros, as the reference does.
+Because the meta tokens run at load time here, the stages also hand their meta rows on once, when the weights are loaded
+(``prepare_meta_caches``): over the pipeline group when it is a torch.distributed group, or through the caller.
 """
 
 from __future__ import annotations
@@ -28,11 +31,12 @@ from typing import Dict, Iterable, List, Optional, Set, Tuple
 import torch
 
 from .. import loader
-from .._compat import HasInnerState, IsHybrid, SupportsV0Only, model_build_args
+from .._compat import HasInnerState, IntermediateTensors, IsHybrid, SupportsPP, SupportsV0Only, model_build_args
 from ..linear import HymetaLinear, LinearColumns
 from ..lm_head import LmHeadMixin, lm_head_logits
 from ..model_for_7B.window_attention import rope_cos_sin_cache
-from ..parallel import exchange_enabled, raise_on_exchange_timeout, shard_heads, tp_rank_and_size
+from ..parallel import (exchange_enabled, raise_on_exchange_timeout, recv_from_stage, send_to_stage, shard_heads,
+                        tp_rank_and_size)
 from .attention import MetaAttention, bind_kv_cache, current_attn_metadata, forward_context, standalone_prefix
 from .block import HybridBlock, HymetaRMSNorm
 from .hybrid_attention import HLinearAttention, IntraHybridAttention, MetaFlashAttention
@@ -63,9 +67,23 @@ def _layer_window(config, layer_idx: int) -> Optional[int]:
     raise ValueError(f"{type(w)} is not supported.")
 
 
+def pp_layer_range(num_layers: int, pp_rank: int, pp_size: int) -> Tuple[int, int]:
+    """Layers ``[start, end)`` of one pipeline stage: equal shares, the remainder one each to the stages counted back from
+    the second to last (vLLM's ``get_pp_indices``, which the reference's ``make_layers`` call uses, ``:1132``): the last
+    stage, which also holds the lm_head, is the last to get an extra layer."""
+    if not 0 <= pp_rank < pp_size:
+        raise ValueError(f"pipeline rank {pp_rank} outside a pipeline of {pp_size} stages")
+    parts = [num_layers // pp_size] * pp_size
+    for i in range(2, num_layers % pp_size + 2):
+        parts[-i if i <= pp_size else -1] += 1
+    start = sum(parts[:pp_rank])
+    return start, start + parts[pp_rank]
+
+
 class HymetaModel(torch.nn.Module):
     def __init__(self, config, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda",
-                 cache_config=None, prefix: Optional[str] = None, expert_parallel: bool = False):
+                 cache_config=None, prefix: Optional[str] = None, expert_parallel: bool = False,
+                 pp_rank: int = 0, pp_size: int = 1, pp_group=None):
         """``expert_parallel`` (``--enable-expert-parallel`` of the reference's serving commands, ``readme.md:115,167``):
         the routed experts of a mixture layer are dealt whole to the ranks of the tensor-parallel group (16 / tp each)
         instead of every expert being cut along its intermediate size; every rank still sees every token, computes the
@@ -82,12 +100,17 @@ class HymetaModel(torch.nn.Module):
         self.tp_group = tp_group
         self.tp_rank, self.tp_size = tp_rank_and_size(tp_group)
         self.expert_parallel = bool(expert_parallel) and self.tp_size > 1
+        # pipeline stage: layers [start_layer, end_layer); pp_group: the torch.distributed group of the stages (rank =
+        # stage) over which the meta rows travel at load time, or None when the caller carries them
+        self.pp_rank, self.pp_size, self.pp_group = int(pp_rank), int(pp_size), pp_group
+        self.start_layer, self.end_layer = pp_layer_range(config.num_hidden_layers, self.pp_rank, self.pp_size)
+        self.is_first_stage, self.is_last_stage = self.pp_rank == 0, self.pp_rank == self.pp_size - 1
         self.quant = dict(bits=4, group_size=128, zero_offset=1)
         self.quant.update(quant or {})
         self.use_lower_bound = config.use_lower_bound
         self.num_meta_tokens = config.num_meta_tokens
         self.shard = shard_heads(config.num_attention_heads, config.num_key_value_heads, self.tp_size, self.tp_rank)
-        L, D = config.num_hidden_layers, config.head_dim
+        L, D = self.end_layer - self.start_layer, config.head_dim      # the caches hold the stage's own layers
         self.cache_shape = (L, max_num_seqs, self.shard.num_heads, D, D)
         self.meta_linear_cache_shape = (L, self.shard.num_heads, D, D)
         self.meta_fattn_cache_shape = (L, 2, self.num_meta_tokens, self.shard.num_kv_heads, D)
@@ -104,12 +127,13 @@ class HymetaModel(torch.nn.Module):
             MetaAttention(self.shard.num_heads, D, D ** -0.5, self.shard.num_kv_heads, cache_config=cache_config,
                           per_layer_sliding_window=_layer_window(config, i) or None,
                           prefix=f"{self.prefix}.layers.{i}.attn.vanilla_attn.attn", num_meta_tokens=self.num_meta_tokens)
-            for i in range(L)])
+            for i in range(self.start_layer, self.end_layer)])
         self.embeddings: Optional[torch.Tensor] = None
         self.layers = torch.nn.ModuleList()
         self.norm: Optional[HymetaRMSNorm] = None
         self.lower_bounds: Optional[torch.Tensor] = None     # [L, hidden] fp32 AFTER softmax/cumsum (:1309-1311)
         self.meta_tokens: Optional[torch.Tensor] = None      # [M, hidden] bf16
+        self.meta_hidden_out: Optional[torch.Tensor] = None  # the meta rows after this stage's layers (for the next stage)
         self.has_meta_cache = False
 
     def get_input_embeddings(self, input_ids: torch.Tensor) -> torch.Tensor:
@@ -119,19 +143,37 @@ class HymetaModel(torch.nn.Module):
         return self.lower_bounds[layer_idx % 7] if self.use_lower_bound else None
 
     @torch.no_grad()
-    def prepare_meta_caches(self) -> None:
-        """The meta tokens' pass through every layer: fills ``meta_linear_cache`` and
-        ``meta_fattn_cache`` of each layer; the rows' own outputs only feed the next layer."""
+    def prepare_meta_caches(self, meta_hidden: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """The meta tokens' pass through the stage's layers: fills ``meta_linear_cache`` and ``meta_fattn_cache`` of each
+        layer; the rows' own outputs only feed the next layer.  A stage other than the first starts from the rows the
+        stage before it produced (``meta_hidden``; with a torch.distributed pipeline group they are received from that
+        stage, and sent on to the next); returns the rows after this stage's layers (also kept as ``meta_hidden_out``)."""
         if self.num_meta_tokens == 0:
             self.has_meta_cache = True
-            return
+            return None
+        import torch.distributed as dist
+        over_group = self.pp_size > 1 and self.pp_group is not None and dist.is_available() and dist.is_initialized()
+        if self.is_first_stage:
+            h = self.meta_tokens
+        else:
+            if meta_hidden is None and over_group:
+                like = torch.empty(self.num_meta_tokens, self.config.hidden_size, dtype=torch.bfloat16, device=self.device)
+                meta_hidden = recv_from_stage(like, self.pp_group, self.pp_rank - 1)
+            if meta_hidden is None:
+                raise RuntimeError("a pipeline stage after the first needs the meta rows of the stage before it: pass "
+                                   "prepare_meta_caches(previous_stage.meta_hidden_out), or build the stages over a "
+                                   "torch.distributed pipeline group")
+            h = meta_hidden.to(self.device, torch.bfloat16)
         _, meta_linear, meta_fattn = self.hymeta_cache.cache
-        h = self.meta_tokens
-        for i, layer in enumerate(self.layers):
-            lb = self._lower_bound(i)
-            h, _ = layer(h, attn_fn=lambda x, i=i, layer=layer, lb=lb: layer.attn.prepare_meta_state(
-                x, meta_linear[i], meta_fattn[i], lb))
+        for j, layer in enumerate(self.layers):
+            lb = self._lower_bound(self.start_layer + j)
+            h, _ = layer(h, attn_fn=lambda x, j=j, layer=layer, lb=lb: layer.attn.prepare_meta_state(
+                x, meta_linear[j], meta_fattn[j], lb))
+        self.meta_hidden_out = h
+        if not self.is_last_stage and over_group:
+            send_to_stage(h, self.pp_group, self.pp_rank + 1)
         self.has_meta_cache = True
+        return h
 
     def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor, intermediate_tensors=None,
                 inputs_embeds: Optional[torch.Tensor] = None, attn_metadata=None,
@@ -145,42 +187,63 @@ class HymetaModel(torch.nn.Module):
                 bind_kv_cache(layer, kv)
         if attn_metadata is not None:
             with forward_context(attn_metadata):
-                return self._forward(input_ids, positions, inputs_embeds, attn_metadata, **kwargs)
+                return self._forward(input_ids, positions, inputs_embeds, attn_metadata, intermediate_tensors, **kwargs)
         attn_metadata = current_attn_metadata()
         if attn_metadata is None:
             return None
-        return self._forward(input_ids, positions, inputs_embeds, attn_metadata, **kwargs)
+        return self._forward(input_ids, positions, inputs_embeds, attn_metadata, intermediate_tensors, **kwargs)
 
-    def _forward(self, input_ids, positions, inputs_embeds, attn_metadata, **kwargs) -> torch.Tensor:
-        if input_ids is not None and inputs_embeds is not None:
-            raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
-        if input_ids is None and inputs_embeds is None:
-            raise ValueError("You have to specify either input_ids or inputs_embeds")
+    def _forward(self, input_ids, positions, inputs_embeds, attn_metadata, intermediate_tensors=None, **kwargs):
+        if self.is_first_stage:
+            if input_ids is not None and inputs_embeds is not None:
+                raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+            if input_ids is None and inputs_embeds is None:
+                raise ValueError("You have to specify either input_ids or inputs_embeds")
+        elif intermediate_tensors is None:
+            raise ValueError("a pipeline stage after the first needs the intermediate_tensors of the stage before it")
         if not self.has_meta_cache:
             raise RuntimeError("meta caches are empty: load_weights() / prepare_meta_caches() must run before forward()")
         kwargs.setdefault("request_ids_to_seq_ids", {})
         kwargs.setdefault("finished_requests_ids", [])
         params = HymetaCacheParams(*self.hymeta_cache.current_run_tensors(**kwargs))
-        hidden_states = self.get_input_embeddings(input_ids) if inputs_embeds is None else inputs_embeds
+        if self.is_first_stage:
+            hidden_states = self.get_input_embeddings(input_ids) if inputs_embeds is None else inputs_embeds
+        else:
+            hidden_states = intermediate_tensors["hidden_states"]      # the residual stream ("residual" arrives as zeros)
         residual = None      # the residual stream travels beside the blocks' outputs (fused add + norm)
-        for i, layer in enumerate(self.layers):
-            c = params.at_layer_idx(i)
+        for j, layer in enumerate(self.layers):
+            c = params.at_layer_idx(j)
             hidden_states, residual = layer(hidden_states, carry_residual=True, residual=residual, positions=positions,
                                             kv_cache=None, hymeta_cache=c.hymeta_cache,
                                             meta_linear_cache=c.meta_linear_cache, meta_fattn_cache=c.meta_fattn_cache,
                                             state_indices_tensor=c.state_indices_tensor, attn_metadata=attn_metadata,
-                                            lower_bound=self._lower_bound(i))
+                                            lower_bound=self._lower_bound(self.start_layer + j))
+        if not self.is_last_stage:
+            # the next stage starts as the model does: from the residual stream itself.  The sum is the one the next
+            # block's fused add + norm would have formed (K slices in order, one bf16 rounding, + residual, one rounding)
+            if not isinstance(hidden_states, torch.Tensor):
+                hidden_states = hidden_states.tensor()
+            if residual is not None:
+                hidden_states = hidden_states + residual
+            return IntermediateTensors({"hidden_states": hidden_states, "residual": torch.zeros_like(hidden_states)})
         return self.norm(hidden_states, residual)[0] if residual is not None else self.norm(hidden_states)
 
+    def make_empty_intermediate_tensors(self, batch_size: int, dtype: torch.dtype, device) -> IntermediateTensors:
+        """Reference ``:1471-1486``."""
+        shape = (batch_size, self.config.hidden_size)
+        return IntermediateTensors({"hidden_states": torch.zeros(shape, dtype=dtype, device=device),
+                                    "residual": torch.zeros(shape, dtype=dtype, device=device)})
 
-class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, SupportsV0Only):
+
+class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, SupportsPP, SupportsV0Only):
     packed_modules_mapping = {
         "qkv_proj": ["q_proj", "k_proj", "v_proj"],
         "gate_up_proj": ["gate_proj", "up_proj"],
     }
 
     def __init__(self, config=None, max_num_seqs: int = 256, quant: Optional[dict] = None, tp_group=None, device="cuda",
-                 *, vllm_config=None, prefix: Optional[str] = None, expert_parallel: bool = False):
+                 *, vllm_config=None, prefix: Optional[str] = None, expert_parallel: bool = False,
+                 pp_rank: int = 0, pp_size: int = 1, pp_group=None):
         """vLLM constructs the class as ``HymetaForCausalLM(vllm_config=..., prefix=...)`` (reference ``:1386-1411``):
         the HF config, ``scheduler_config.max_num_seqs`` (state slots), the quantisation parameters, the
         tensor-parallel group and the cache config are read from ``vllm_config``.  The keyword form
@@ -189,10 +252,11 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
         super().__init__()
         cache_config = None
         if vllm_config is not None:
-            args = model_build_args(vllm_config, prefix or "")
+            args = model_build_args(vllm_config, prefix or "", pipeline=True)
             config, max_num_seqs, quant, tp_group, device, cache_config = (
                 args.config, args.max_num_seqs, args.quant, args.tp_group, args.device, args.cache_config)
             expert_parallel = bool(getattr(args, "expert_parallel", False))
+            pp_rank, pp_size, pp_group = args.pp_rank, args.pp_size, args.pp_group
             model_prefix = f"{prefix}.model" if prefix else "model"          # maybe_prefix(prefix, "model"), :1410
         else:
             if config is None:
@@ -204,9 +268,11 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
             config.sliding_window = None
         self.unpadded_vocab_size = config.vocab_size
         self.model = HymetaModel(config, max_num_seqs=max_num_seqs, quant=quant, tp_group=tp_group, device=device,
-                                 cache_config=cache_config, prefix=model_prefix, expert_parallel=expert_parallel)
-        self.lm_head = None             # [vocab, hidden]; reads as fp32 (:1429), see lm_head.py
+                                 cache_config=cache_config, prefix=model_prefix, expert_parallel=expert_parallel,
+                                 pp_rank=pp_rank, pp_size=pp_size, pp_group=pp_group)
+        self.lm_head = None             # [vocab, hidden]; reads as fp32 (:1429), see lm_head.py; the last stage's only
         self.kv_cache = [torch.tensor([]) for _ in range(config.num_hidden_layers)]
+        self.make_empty_intermediate_tensors = self.model.make_empty_intermediate_tensors
 
     def copy_inputs_before_cuda_graphs(self, input_buffers, **kwargs):
         """The engine calls this on the host before every replay of a captured step: also the place where a timeout of
@@ -267,6 +333,15 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
             route = loader.route_70b(name, cfg.num_hidden_layers)
             if route is None:
                 continue
+            # a pipeline stage keeps its own layers; the embedding and the meta tokens belong to the first stage, the final
+            # norm and the lm_head to the last (the reference skips them with is_pp_missing_parameter, :1538-1651)
+            layer_of = loader._layer_of(route.param)
+            if layer_of is not None and not m.start_layer <= layer_of < m.end_layer:
+                continue
+            if route.param in ("model.embeddings.weight", "model.meta_tokens") and not m.is_first_stage:
+                continue
+            if route.param in ("model.norm.weight", "lm_head.weight") and not m.is_last_stage:
+                continue
             loaded.add(route.param)
             if route.expert_id is not None:
                 _, leaf = loader.expert_leaf(route.param)
@@ -310,16 +385,18 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
             gate_up = loader.concat_out_features([lin(f"{prefix}.gate_up_proj", 0), lin(f"{prefix}.gate_up_proj", 1)])
             return HymetaMLP(make(gate_up), make(lin(f"{prefix}.down_proj")), tp_group=m.tp_group, reduce_results=reduce_results)
 
-        m.embeddings = plain["model.embeddings.weight"].to(torch.bfloat16)
-        m.norm = HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain["model.norm.weight"])
-        self.lm_head = plain["lm_head.weight"]
+        if m.is_first_stage:
+            m.embeddings = plain["model.embeddings.weight"].to(torch.bfloat16)
+        if m.is_last_stage:
+            m.norm = HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain["model.norm.weight"])
+            self.lm_head = plain["lm_head.weight"]
         if m.use_lower_bound:
             lb = plain["model.lower_bounds"].float().softmax(0)
             m.lower_bounds = (lb.cumsum(0) - lb[0]).contiguous()
-        if m.num_meta_tokens > 0:
+        if m.num_meta_tokens > 0 and m.is_first_stage:
             m.meta_tokens = plain["model.meta_tokens"].to(torch.bfloat16).contiguous()
         m.layers = torch.nn.ModuleList()
-        for i in range(cfg.num_hidden_layers):
+        for i in range(m.start_layer, m.end_layer):
             p = f"model.layers.{i}"
 
             # both branches project the same normed input: one linear for the six projections (the softmax branch's
@@ -328,7 +405,8 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
                                                     for branch in ("vanilla_attn", "linear_attn") for s in ("q", "k", "v")]))
             width = (sh.num_heads + 2 * sh.num_kv_heads) * cfg.head_dim
             vanilla = MetaFlashAttention(cfg.hidden_size, H, KVH, LinearColumns(both, 0, width), m.cos_sin_cache,
-                                         _layer_window(cfg, i), num_meta_tokens=m.num_meta_tokens, shard=sh, attn=m.attn_layers[i])
+                                         _layer_window(cfg, i), num_meta_tokens=m.num_meta_tokens, shard=sh,
+                                         attn=m.attn_layers[i - m.start_layer])
             linear = HLinearAttention(cfg.hidden_size, H, KVH, LinearColumns(both, width, 2 * width), i,
                                       num_meta_tokens=m.num_meta_tokens, shard=sh)
             attn = IntraHybridAttention(vanilla, linear, make(lin(f"{p}.attn.out_proj")), plain[f"{p}.attn.norm1.weight"],
@@ -359,6 +437,8 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
                                 group=m.tp_group, local_experts=local, **scales)
             m.layers.append(HybridBlock(HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.attn_norm.weight"]), attn,
                                         HymetaRMSNorm(cfg.hidden_size, cfg.norm_eps, plain[f"{p}.mlp_norm.weight"]), ffn))
-        if dev.type == "cuda":
+        # the meta tokens' pass: a later stage of a pipeline without a torch.distributed group waits for its caller to
+        # bring the rows of the stage before it (prepare_meta_caches(previous.meta_hidden_out))
+        if dev.type == "cuda" and (m.is_first_stage or m.pp_group is not None or m.num_meta_tokens == 0):
             m.prepare_meta_caches()
         return loaded

@@ -482,3 +482,22 @@ def tp_rank_and_size(group: Optional[dist.ProcessGroup] = None) -> Tuple[int, in
             return EMULATED_TP
         return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
+
+
+def send_to_stage(t: torch.Tensor, group: dist.ProcessGroup, dst: int) -> None:
+    """One tensor to rank ``dst`` of ``group`` (a pipeline hand-off).  A gloo group gets a host copy: its transfers of
+    device tensors between processes that share a GPU can hang."""
+    if dist.get_backend(group) == "gloo":
+        t = t.detach().to("cpu")           # synchronous copy
+    dist.send(t.contiguous(), group=group, group_dst=dst)
+
+
+def recv_from_stage(like: torch.Tensor, group: dist.ProcessGroup, src: int) -> torch.Tensor:
+    """The counterpart of ``send_to_stage``: a tensor of ``like``'s shape, dtype and device from rank ``src``."""
+    if dist.get_backend(group) == "gloo":
+        host = torch.empty(like.shape, dtype=like.dtype, device="cpu")
+        dist.recv(host, group=group, group_src=src)
+        return host.to(like.device)
+    out = torch.empty_like(like)
+    dist.recv(out, group=group, group_src=src)
+    return out
