@@ -172,3 +172,70 @@ def test_glaswa_for_causal_lm_gptq_checkpoint():
     torch.cuda.synchronize()
     assert_bf16_close(torch.cat([h_pre, h_dec]).cpu(), ref_h, "7B model from a GPTQ checkpoint, hidden states", rel=2e-2, frac=2.0 ** -4)
     assert_bf16_close(logits.cpu(), ref_logits[L:], "7B model from a GPTQ checkpoint, logits", rel=2e-2, frac=2.0 ** -4)
+
+
+@pytest.mark.parametrize("stages", [2, 3])
+def test_pipeline_stages_equal_the_whole_model(stages):
+    """The model cut into pipeline stages (all in one process, the hand-off carried by the test): every step hands
+    ``IntermediateTensors`` (``hidden_states`` = the residual stream, ``residual`` = zeros, as the reference's stages
+    do) to the next stage; prefill and decode of two sequences give the whole model's hidden states and logits bit for
+    bit.  With three stages of four layers the last stage holds one sliding-window layer and no linear-attention state."""
+    from vllm_hymeta import _compat
+    from vllm_hymeta.model_for_7B.configuration_gla_swa import GLAswaConfig
+    from vllm_hymeta.model_for_7B.modeling_gla_swa import GLAswaForCausalLM
+
+    dev = torch.device("cuda")
+    g_ = gen(43)
+    cfg = GLAswaConfig(vocab_size=512, hidden_size=512, num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=2,
+                       intermediate_size=1024, sliding_window=48, max_position_embeddings=1024)
+    ckpt = _checkpoint(g_, cfg)
+    whole = GLAswaForCausalLM(cfg, max_num_seqs=4, device=dev)
+    whole.load_weights(ckpt.items())
+    pipe = [GLAswaForCausalLM(cfg, max_num_seqs=4, device=dev, pp_rank=r, pp_size=stages) for r in range(stages)]
+    for st in pipe:
+        st.load_weights(ckpt.items())
+    assert sum(len(st.model.layers) for st in pipe) == 4 and sum(st.model.cache_shape[0] for st in pipe) == 2
+    assert [st.lm_head is not None for st in pipe] == [False] * (stages - 1) + [True]
+
+    lens = [75, 40]
+    ids = [torch.randint(0, cfg.vocab_size, (L + 1,), generator=g_) for L in lens]
+    bs = 16
+    per_seq = (max(lens) + 1 + bs - 1) // bs
+    bt = torch.randperm(2 * per_seq + 1, generator=g_)[: 2 * per_seq].to(torch.int32).view(2, per_seq).to(dev)
+    slot = lambda s_, t: int(bt[s_, t // bs]) * bs + t % bs
+    run = dict(request_ids_to_seq_ids={"a": [0], "b": [1]}, finished_requests_ids=[])
+
+    def caches(model):
+        return [torch.zeros(2, 2 * per_seq + 1, bs, cfg.num_key_value_heads, D, dtype=torch.bfloat16, device=dev)
+                for _ in model.model.attn_layers]
+
+    kv_whole, kv_pipe = caches(whole), [caches(st) for st in pipe]
+
+    def through_pipe(ids_, pos_, md_):
+        x = None
+        for st, kv in zip(pipe, kv_pipe):
+            x = st(ids_ if st.model.is_first_stage else None, pos_, intermediate_tensors=x, attn_metadata=md_, kv_caches=kv, **run)
+            if not st.model.is_last_stage:
+                assert isinstance(x, _compat.IntermediateTensors) and not bool(x["residual"].any())
+        return x
+
+    pre_ids = torch.cat([x[:L] for x, L in zip(ids, lens)]).to(dev)
+    pre_pos = torch.cat([torch.arange(L) for L in lens]).to(dev)
+    pre_slots = torch.tensor([slot(s_, t) for s_, L in enumerate(lens) for t in range(L)], device=dev)
+    md = _md(dev, prefill_lens=lens, context_lens=[0, 0], slot_mapping=pre_slots)
+    h_whole = whole(pre_ids, pre_pos, attn_metadata=md, kv_caches=kv_whole, **run)
+    h_pipe = through_pipe(pre_ids, pre_pos, md)
+    torch.cuda.synchronize()
+    assert torch.equal(h_whole, h_pipe)
+
+    dec_ids = torch.stack([x[L] for x, L in zip(ids, lens)]).to(dev)
+    dec_pos = torch.tensor(lens, device=dev)
+    dec_slots = torch.tensor([slot(s_, L) for s_, L in enumerate(lens)], device=dev)
+    md = _md(dev, decode_seq_lens=[L + 1 for L in lens], block_tables=bt, slot_mapping=dec_slots)
+    d_whole = whole(dec_ids, dec_pos, attn_metadata=md, kv_caches=kv_whole, **run)
+    d_pipe = through_pipe(dec_ids, dec_pos, md)
+    torch.cuda.synchronize()
+    assert torch.equal(d_whole, d_pipe)
+    assert torch.equal(whole.compute_logits(d_whole), pipe[-1].compute_logits(d_pipe))
+    with pytest.raises(ValueError, match="stage before it"):
+        pipe[1](None, dec_pos, attn_metadata=md, kv_caches=kv_pipe[1], **run)

@@ -154,6 +154,38 @@ def test_70b_checkpoint_loads_per_pipeline_stage():
     assert "lm_head.weight" in loaded_all and "model.embeddings.weight" in loaded_all
 
 
+def test_7b_checkpoint_loads_per_pipeline_stage():
+    """A stage of the 7B class keeps its own layers (state cache and sliding-window attention layers sized to them,
+    registered under their global names), the first one the embedding, the last one the final norm and the lm_head."""
+    from vllm_hymeta.model_for_7B import modeling_gla_swa as mod
+    from vllm_hymeta.model_for_7B.configuration_gla_swa import GLAswaConfig
+
+    cfg = GLAswaConfig(vocab_size=512, hidden_size=512, num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=2,
+                       intermediate_size=1024, sliding_window=48, max_position_embeddings=1024)
+    ckpt = ckpt_7b(gen(0), cfg)
+    whole = mod.GLAswaForCausalLM(cfg, max_num_seqs=3, device="cpu")
+    whole.load_weights(ckpt.items())
+    loaded_all = set()
+    for rank, (lo, hi) in enumerate(((0, 1), (1, 3), (3, 4))):                  # vLLM's partition of 4 layers over 3 stages
+        model = mod.GLAswaForCausalLM(cfg, max_num_seqs=3, device="cpu", pp_rank=rank, pp_size=3)
+        loaded = model.load_weights(ckpt.items())
+        loaded_all |= loaded
+        m = model.model
+        assert (m.start_layer, m.end_layer) == (lo, hi) and len(m.layers) == hi - lo
+        assert list(m.attn_layers.keys()) == [str(i) for i in range(lo, hi) if i in cfg.attn_layers]
+        assert all(a.layer_name.endswith(f"model.layers.{i}.attn.attn") for i, a in m.attn_layers.items())
+        assert m.cache_shape[0] == sum(1 for i in range(lo, hi) if i not in cfg.attn_layers)
+        assert len(model.kv_cache) == len(m.attn_layers)
+        assert (m.embeddings is not None) == (rank == 0)
+        assert (m.norm is not None) == (rank == 2) and (model.lm_head is not None) == (rank == 2)
+        assert all(not (f"layers.{i}." in name) for name in loaded for i in range(4) if not lo <= i < hi)
+        for j, layer in enumerate(m.layers):
+            assert torch.equal(layer.attn.o_proj.weight, whole.model.layers[lo + j].attn.o_proj.weight)
+        empty = model.make_empty_intermediate_tensors(5, torch.bfloat16, "cpu")
+        assert empty["hidden_states"].shape == (5, 512) and empty["residual"].shape == (5, 512)
+    assert loaded_all == whole.load_weights(ckpt.items())
+
+
 def test_whole_model_restatements_run():
     from oracle.model import glaswa_model_ref, hymeta_model_ref
     from vllm_hymeta.model_for_7B.configuration_gla_swa import GLAswaConfig

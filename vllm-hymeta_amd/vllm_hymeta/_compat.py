@@ -129,9 +129,7 @@ def pipeline_parallel_stage(parallel_config, pp_size: int):
     return int(rank), getattr(parallel_config, "pipeline_parallel_group", None)
 
 
-def model_build_args(vllm_config, prefix: str = "", pipeline: bool = False) -> ModelBuildArgs:
-    """``pipeline``: the calling model class has pipeline stages; a ``pipeline_parallel_size`` above 1 is refused for
-    one that has not."""
+def model_build_args(vllm_config, prefix: str = "") -> ModelBuildArgs:
     mc = vllm_config.model_config
     config = mc.hf_config
     if isinstance(getattr(mc, "max_model_len", None), int):
@@ -141,9 +139,6 @@ def model_build_args(vllm_config, prefix: str = "", pipeline: bool = False) -> M
     pp = int(getattr(pc, "pipeline_parallel_size", 1) or 1)
     pp_rank, pp_group = 0, None
     if pp > 1:
-        if not pipeline:
-            raise NotImplementedError("pipeline parallelism is not implemented by this model class; use tensor "
-                                      "parallelism and replicas")
         pp_rank, pp_group = pipeline_parallel_stage(pc, pp)
     device = getattr(getattr(vllm_config, "device_config", None), "device", None) or "cuda"
     return ModelBuildArgs(config=config, max_num_seqs=int(vllm_config.scheduler_config.max_num_seqs),

@@ -252,7 +252,7 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
         super().__init__()
         cache_config = None
         if vllm_config is not None:
-            args = model_build_args(vllm_config, prefix or "", pipeline=True)
+            args = model_build_args(vllm_config, prefix or "")
             config, max_num_seqs, quant, tp_group, device, cache_config = (
                 args.config, args.max_num_seqs, args.quant, args.tp_group, args.device, args.cache_config)
             expert_parallel = bool(getattr(args, "expert_parallel", False))
@@ -272,7 +272,6 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
                                  pp_rank=pp_rank, pp_size=pp_size, pp_group=pp_group)
         self.lm_head = None             # [vocab, hidden]; reads as fp32 (:1429), see lm_head.py; the last stage's only
         self.kv_cache = [torch.tensor([]) for _ in range(config.num_hidden_layers)]
-        self.make_empty_intermediate_tensors = self.model.make_empty_intermediate_tensors
 
     def copy_inputs_before_cuda_graphs(self, input_buffers, **kwargs):
         """The engine calls this on the host before every replay of a captured step: also the place where a timeout of
@@ -292,6 +291,9 @@ class HymetaForCausalLM(LmHeadMixin, torch.nn.Module, HasInnerState, IsHybrid, S
         if tp_group is not None and exchange_enabled(tp_group) and not torch.cuda.is_current_stream_capturing():
             raise_on_exchange_timeout(tp_group)      # eager steps: the check a replayed step gets from the hook above
         return self.model(input_ids, positions, intermediate_tensors, inputs_embeds, **kwargs)
+
+    def make_empty_intermediate_tensors(self, batch_size: int, dtype: torch.dtype, device) -> IntermediateTensors:
+        return self.model.make_empty_intermediate_tensors(batch_size, dtype, device)
 
     def compute_logits(self, hidden_states: torch.Tensor, sampling_metadata=None) -> torch.Tensor:
         """fp32 logits of the rows the sampler asks for (vLLM's ``LogitsProcessor`` prunes the hidden states to
