@@ -637,7 +637,8 @@ int hymeta_gptq_dequant_nk(const int32_t* qweight, const int32_t* qzeros, const 
                            int32_t zero_offset, hymeta_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * bf16 linear for decode-sized batches (M <= 128; 65 to 128 rows need K % 64 == 0, K >= 256 and split_k == 0):
+ * bf16 linear for decode-sized batches (M <= 128; 65 to 128 rows need K % 64 == 0, K >= 256 and split_k == 0;
+ * 129 to 256 rows: the shapes for which hymeta_bf16_gemm_takes says so, with a workspace and split_k == 0):
  * out = bf16(x W^T + bias), fp32 accumulation,
  * one rounding; W [N, K] as torch stores a Linear weight.  Replaces the un-quantised linear
  * method (F.linear through vLLM's ColumnParallelLinear / RowParallelLinear, third party) at the
@@ -665,6 +666,13 @@ typedef struct hymeta_bf16_gemm_args {
 int hymeta_bf16_gemm_split_k(int32_t M, int32_t K, int32_t N);
 size_t hymeta_bf16_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream);
+/* 1 when hymeta_bf16_gemm (split_k 0, workspace of hymeta_bf16_gemm_workspace_bytes(M, N, 0)) -- or, with silu_mul
+ * set, hymeta_bf16_gemm_silu_mul (N counts the gate and the up rows) -- takes the shape, 0 when it would answer
+ * HYMETA_ERR_UNSUPPORTED and the caller runs a library GEMM: every covered shape up to 128 rows; from 129 to 256
+ * rows what the 129..256-row streaming kernel cuts into at least 128 workgroups (tiles of 112 to 160 columns; K
+ * slices of at least 512 bytes for narrow matrices).  No counterpart in the reference (its linears are vLLM's):
+ * a question of the host-side dispatch. */
+int hymeta_bf16_gemm_takes(int32_t M, int32_t K, int32_t N, int32_t silu_mul);
 
 /* Logits of a bf16 lm_head: out fp32 [M, N] (out_stride_m in fp32 elements, a multiple of 4) = x weight^T (+ bias)
  * with fp32 accumulation and no rounding of the result; workspace and split_k unused.  M <= 128, K a multiple of 64 and

@@ -163,6 +163,14 @@ extern "C" size_t hymeta_bf16_gemm_workspace_bytes(int32_t M, int32_t N, int32_t
   return counters + static_cast<size_t>(split_k) * M * N * sizeof(float);
 }
 
+extern "C" int hymeta_bf16_gemm_takes(int32_t M, int32_t K, int32_t N, int32_t silu_mul) {
+  if (M <= 0 || K <= 0 || N <= 0 || M > 256 || K % 32 != 0 || N % kCols != 0 || K > (1 << 28)) return 0;
+  StreamPlan plan;
+  if (silu_mul) return stream_gemm_plan_gated(M, K * 2, N, &plan) ? 1 : 0;
+  if (M <= 64) return 1;
+  return stream_gemm_plan(M, K * 2, N, true, &plan) ? 1 : 0;
+}
+
 static int bf16_gemm_impl(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream, hymeta_gemm_partials* deferred) {
   if (!hymeta::args_ok(args)) return HYMETA_ERR_INVALID_ARG;
   if (deferred != nullptr) *deferred = hymeta::make_args<hymeta_gemm_partials>();
@@ -170,7 +178,7 @@ static int bf16_gemm_impl(const hymeta_bf16_gemm_args* args, hymeta_stream_t str
   if (a.M < 0 || a.K <= 0 || a.N <= 0) return HYMETA_ERR_INVALID_ARG;
   if (a.M == 0) return HYMETA_OK;
   if (!a.x || !a.weight || !a.out) return HYMETA_ERR_INVALID_ARG;
-  if (a.M > 128 || a.K % 32 != 0 || a.N % kCols != 0) return HYMETA_ERR_UNSUPPORTED;
+  if (a.M > 256 || a.K % 32 != 0 || a.N % kCols != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((a.x_stride_m | a.w_stride_n | a.out_stride_m) % 8 != 0) return HYMETA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.weight) | reinterpret_cast<uintptr_t>(a.out) |
        reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.workspace)) % 16 != 0)
@@ -195,7 +203,7 @@ static int bf16_gemm_impl(const hymeta_bf16_gemm_args* args, hymeta_stream_t str
       return stream_gemm_launch<false>(sa, plan, begin_launches(stream), deferred != nullptr);
     }
   }
-  if (a.M > 64) return HYMETA_ERR_UNSUPPORTED;      // 65 to 128 rows: the streaming kernel only
+  if (a.M > 64) return HYMETA_ERR_UNSUPPORTED;      // 65 to 256 rows: the streaming kernels only
   const int ksteps = a.K / 32;
   int splits = a.split_k > 0 ? a.split_k : (a.workspace != nullptr ? hymeta_bf16_gemm_split_k(a.M, a.K, a.N) : 1);
   if (splits > ksteps) splits = ksteps;
@@ -241,7 +249,7 @@ extern "C" int hymeta_bf16_gemm_f32out(const hymeta_bf16_gemm_args* args, hymeta
        reinterpret_cast<uintptr_t>(a.bias)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
   StreamPlan plan;
-  if (a.K > (1 << 28) || !stream_gemm_plan(a.M, a.K * 2, a.N, false, &plan) || plan.splits != 1) return HYMETA_ERR_UNSUPPORTED;
+  if (a.K > (1 << 28) || !stream_gemm_plan(a.M, a.K * 2, a.N, false, &plan) || plan.splits != 1 || plan.tall) return HYMETA_ERR_UNSUPPORTED;
   StreamArgs sa = {};
   sa.x = static_cast<const char*>(a.x), sa.w = static_cast<const char*>(a.weight);
   sa.bias = static_cast<const uint16_t*>(a.bias), sa.out = static_cast<uint16_t*>(a.out);

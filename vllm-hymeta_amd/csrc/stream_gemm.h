@@ -28,9 +28,10 @@ struct StreamPlan {
   int tiles, chunks;   // chunks: 512-byte pieces of a weight row
   int splits;          // K slices per tile (1: the workgroup writes the tile itself)
   int ring;      // pairs of k-steps each wave keeps in flight (2 or 4)
+  int tall;      // 1: the plan of the 129..256-row kernel (tall_gemm.hip): nf = fragments of the widest TILE (8..10)
 };
 
-// Whether the streaming kernel takes the shape (M <= 128 rows, K a multiple of 128 bytes and at least 512, N of 64 columns), and how
+// Whether a streaming kernel takes the shape (M <= 128 rows: the decode-sized kernel; 129..256 rows: the tall one; K a multiple of 128 bytes and at least 512, N of 64 columns), and how
 // it is cut (one workgroup per compute unit where the shape allows).  Without a workspace every workgroup owns whole tiles (no slabs).
 bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* plan);
 // Gated form (see StreamArgs::gated): N counts the gate and the up rows together and must be a multiple of 128.
@@ -42,6 +43,11 @@ size_t stream_gemm_workspace_bound(int M, int N);
 // defer_reduce: with K slices, stop after the slabs are written (the caller hands them to a consumer that sums them).
 template <bool I8>
 int stream_gemm_launch(StreamArgs args, const StreamPlan& plan, hipStream_t stream, bool defer_reduce = false);
+
+// The 129..256-row kernel (tall_gemm.hip); stream_gemm_plan / stream_gemm_launch route to these two.
+bool tall_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* plan);
+template <bool I8>
+int tall_gemm_launch(const StreamArgs& args, const StreamPlan& plan, hipStream_t stream);
 
 // ---- the 4-bit GPTQ form (stream_gptq.hip): group size 128, K a multiple of 256, N of 128 ----
 struct StreamGptqArgs {

@@ -368,6 +368,8 @@ static int tune(const char* name) {
 }
 
 bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* p) {
+  p->tall = 0;
+  if (tall_gemm_plan(M, K_bytes, N, have_workspace, p)) return true;
   if (M <= 0 || M > 128 || K_bytes % 128 != 0 || K_bytes < kChunkBytes || N % 64 != 0) return false;
   static const int nf_forced = tune("HYMETA_STREAM_NF"), splits_forced = tune("HYMETA_STREAM_SPLITS");
   static const int ring_forced = tune("HYMETA_STREAM_RING"), want_forced = tune("HYMETA_STREAM_WGS");
@@ -426,6 +428,15 @@ size_t stream_gemm_workspace_bound(int M, int N) {
 template <bool I8>
 int stream_gemm_launch(StreamArgs a, const StreamPlan& p, hipStream_t s, bool defer_reduce) {
   a.tiles = p.tiles, a.chunks = p.chunks, a.splits = p.splits;
+  if (p.tall) {
+    if (a.gated && (p.splits != 1 || a.bias != nullptr)) return HYMETA_ERR_INVALID_ARG;
+    if (a.out_f32) return HYMETA_ERR_UNSUPPORTED;
+    const int rc = tall_gemm_launch<I8>(a, p, s);
+    if (rc != HYMETA_OK || a.splits == 1 || defer_reduce) return rc;
+    const int64_t threads = static_cast<int64_t>(a.M) * (a.N / 4);
+    hipLaunchKernelGGL(stream_gemm_reduce_kernel<I8>, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, s, a);
+    return launch_status();
+  }
   if (a.k_bytes <= 0 || (a.k_bytes + kChunkBytes - 1) / kChunkBytes != p.chunks) return HYMETA_ERR_INVALID_ARG;
   if (a.gated && (p.splits != 1 || a.bias != nullptr || a.N % 128 != 0)) return HYMETA_ERR_INVALID_ARG;
   if (a.out_f32 && (p.splits != 1 || a.gated)) return HYMETA_ERR_INVALID_ARG;

@@ -334,6 +334,7 @@ _SIGNATURES = {
     "hymeta_rope_neox_partials": (C.c_int, [C.POINTER(RopeArgs), C.POINTER(GemmPartials), _ptr]),
     "hymeta_add_rmsnorm_int8": (C.c_int, [C.POINTER(AddRmsNormArgs), C.POINTER(GemmPartials), _ptr, _ptr, _ptr]),
     "hymeta_bf16_gemm_split_k": (C.c_int, [_i32, _i32, _i32]),
+    "hymeta_bf16_gemm_takes": (C.c_int, [_i32, _i32, _i32, _i32]),
     "hymeta_bf16_gemm_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "hymeta_w8a8_gemm": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),
     "hymeta_w8a8_gemm_silu_mul": (C.c_int, [C.POINTER(W8A8GemmArgs), _ptr]),

@@ -893,6 +893,7 @@ def gptq_dequant(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tens
 
 
 BF16_GEMM_MAX_ROWS = 128      # 65 to 128 rows: the streaming kernel only (K a multiple of 64, at least 256)
+BF16_GEMM_TALL_ROWS = 256     # 129 to 256 rows: the shapes the library says it takes (hymeta_bf16_gemm_takes)
 
 
 def bf16_gemm_preferred(x: torch.Tensor, weight: torch.Tensor) -> bool:
@@ -903,17 +904,23 @@ def bf16_gemm_preferred(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 
 def bf16_gemm_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
-    """Shapes the decode-sized bf16 linear kernel takes."""
-    return (x.dim() == 2 and 0 < x.shape[0] <= BF16_GEMM_MAX_ROWS and x.is_cuda and x.dtype == torch.bfloat16
+    """Shapes the bf16 linear kernels take: decode-sized batches, and from 129 to 256 rows what the library's
+    129..256-row kernel covers (``hymeta_bf16_gemm_takes``)."""
+    if not (x.dim() == 2 and 0 < x.shape[0] <= BF16_GEMM_TALL_ROWS and x.is_cuda and x.dtype == torch.bfloat16
             and weight.dtype == torch.bfloat16 and x.stride(1) == 1 and weight.stride(1) == 1
             and weight.shape[1] % 32 == 0 and weight.shape[0] % 64 == 0
             and (x.shape[0] <= 64 or (weight.shape[1] % 64 == 0 and weight.shape[1] >= 256))
-            and x.stride(0) % 8 == 0 and weight.stride(0) % 8 == 0)
+            and x.stride(0) % 8 == 0 and weight.stride(0) % 8 == 0):
+        return False
+    if x.shape[0] <= BF16_GEMM_MAX_ROWS:
+        return True
+    return bool(_C.load().hymeta_bf16_gemm_takes(x.shape[0], weight.shape[1], weight.shape[0], 0))
 
 
 def bf16_gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
               out: Optional[torch.Tensor] = None, split_k: int = 0, defer: bool = False):
-    """x bf16 [M <= 128, K] @ weight bf16 [N, K]^T (+ bias bf16 [N]) -> bf16 [M, N]; ``split_k`` 0: library's choice.
+    """x bf16 [M, K] @ weight bf16 [N, K]^T (+ bias bf16 [N]) -> bf16 [M, N] for the shapes of ``bf16_gemm_supported``;
+    ``split_k`` 0: library's choice.
     ``defer``: when the library cuts K into slices, return their ``PartialSums`` instead of summing them."""
     _dev(x, weight, bias, out)
     M, K = x.shape
@@ -1051,16 +1058,20 @@ def gemm_silu_mul_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     """Shapes the gate/up projection with the activation in its epilogue takes: decode-sized batches of a bf16
     ``[2 I, K]`` weight (gate rows, then up rows), any batch of an int8 one."""
     esize = 1 if weight.dtype == torch.int8 else 2
-    rows = BF16_GEMM_MAX_ROWS if weight.dtype == torch.bfloat16 else 1 << 30      # int8: the tiled kernel above the streaming rows
-    return (x.dim() == 2 and 0 < x.shape[0] <= rows and x.is_cuda and x.dtype == torch.bfloat16
+    rows = BF16_GEMM_TALL_ROWS if weight.dtype == torch.bfloat16 else 1 << 30      # int8: the tiled kernel above the streaming rows
+    if not (x.dim() == 2 and 0 < x.shape[0] <= rows and x.is_cuda and x.dtype == torch.bfloat16
             and weight.dtype in (torch.bfloat16, torch.int8) and x.stride(1) == 1 and weight.is_contiguous()
             and (weight.shape[1] * esize) % 128 == 0 and weight.shape[1] * esize >= 512 and weight.shape[0] % 128 == 0
-            and x.stride(0) % 8 == 0)
+            and x.stride(0) % 8 == 0):
+        return False
+    if weight.dtype == torch.bfloat16 and x.shape[0] > BF16_GEMM_MAX_ROWS:
+        return bool(_C.load().hymeta_bf16_gemm_takes(x.shape[0], weight.shape[1], weight.shape[0], 1))
+    return True
 
 
 def gemm_silu_mul(x: torch.Tensor, weight: torch.Tensor, w_scale: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``silu(x gate^T) * (x up^T)`` in one launch: x bf16 [M, K]; weight [2 I, K] bf16 (M <= 128), or int8 with ``w_scale``
+    """``silu(x gate^T) * (x up^T)`` in one launch: x bf16 [M, K]; weight [2 I, K] bf16 (M <= 128, wide ones to 256), or int8 with ``w_scale``
     fp32 [2 I] (dynamic per-token int8 activations; any M) -> bf16 [M, I].  Bit for bit the linear followed by
     ``silu_and_mul``."""
     _dev(x, weight, w_scale, out)

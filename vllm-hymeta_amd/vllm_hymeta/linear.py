@@ -1,5 +1,5 @@
 """Linear layers of the attention blocks: bf16 or one of the fused dequant-GEMMs (GPTQ 4/8-bit, W8A8).
-Decode-sized batches (up to 128 rows; GPTQ up to 64) always run on this package's weight-streaming kernels; prefill-sized
+Decode-sized batches (up to 128 rows, int8 up to 256; GPTQ up to 64) always run on this package's weight-streaming kernels; prefill-sized
 batches of bf16 / expanded GPTQ / int8 weights go to the library GEMM.  Stands where the reference puts vLLM's
 ``QKVParallelLinear`` / ``RowParallelLinear`` / ``ReplicatedLinear`` with a ``quant_config``
 (``vllm_hymeta/model_for_7B/gla_attention.py:147-176``): a tensor-parallel shard is simply a
@@ -17,24 +17,28 @@ from . import hip_ops
 # Rows above which a GPTQ linear expands its weights and calls the library GEMM (measured on the 7B
 # projection shapes: the fused kernel wins up to a few hundred rows, the library from there on).
 GPTQ_EXPAND_ROWS = 256
-# Rows above which a W8A8 linear puts the library int8 GEMM between its own quantisation and
-# scaling kernels: the streaming int8 kernel covers up to 128 rows (one pass over the weights); both
+# Rows above which a W8A8 linear may put the library int8 GEMM between its own quantisation and
+# scaling kernels: the streaming int8 kernels cover up to 256 rows (one pass over the weights); both
 # paths give the same bits (exact int32 sums).
-W8A8_LIBRARY_ROWS = 128
+W8A8_LIBRARY_ROWS = 256
+W8A8_STREAM_ROWS = 128       # the decode-sized kernel: any K of whole 128-byte lines, N of whole 64-column groups
 
 
 def w8a8_use_library(rows: int, in_features: int, out_features: int) -> bool:
-    """Above the streaming kernel's rows a W8A8 linear is either ONE tiled int8-MFMA launch with the scales in its
+    """Above the streaming kernels' rows a W8A8 linear is either ONE tiled int8-MFMA launch with the scales in its
     epilogue (``hymeta_w8a8_gemm``: K in whole 128-deep steps, N in whole 128-column tiles) or quantise -> library int8
     GEMM -> scale (three launches, the int32 sums through memory); both give the same bits.  The tiled kernel takes the
     shapes where it was measured ahead (7B shapes, us, tiled / library): gate_up 70 / 72 at 129 rows, 68 / 101 at 256,
-    331 / 412 at 2048, 4400 / 5568 at 32768; qkv 67 / 71 at 2048, 601 / 736 at 32768; o 51 / 57 and 481 / 594; the deep
+    331 / 412 at 2048, 4400 / 5568 at 32768 (up to 256 rows the streaming kernel has since taken over: 59 at 256, the
+    down projection 48 against 118); qkv 67 / 71 at 2048, 601 / 736 at 32768; o 51 / 57 and 481 / 594; the deep
     narrow down projection (K = 5.3 N: few tiles, long K loops) 587 / 683 at 8192 and level at 32768 -- and leaves the
     rest to the library (qkv / o below 1024 rows, down below 4096: 210 / 189 at 2048)."""
-    if rows <= W8A8_LIBRARY_ROWS:
+    if rows <= W8A8_STREAM_ROWS:
         return False
     if in_features % 128 != 0 or out_features % 128 != 0:
         return True
+    if rows <= W8A8_LIBRARY_ROWS:
+        return False
     if out_features >= 16384:
         return False
     if in_features >= 4 * out_features:
