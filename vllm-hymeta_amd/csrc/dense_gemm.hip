@@ -249,7 +249,7 @@ extern "C" int hymeta_bf16_gemm_f32out(const hymeta_bf16_gemm_args* args, hymeta
        reinterpret_cast<uintptr_t>(a.bias)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
   StreamPlan plan;
-  if (a.K > (1 << 28) || !stream_gemm_plan(a.M, a.K * 2, a.N, false, &plan) || plan.splits != 1 || plan.tall) return HYMETA_ERR_UNSUPPORTED;
+  if (a.K > (1 << 28) || !stream_gemm_plan(a.M, a.K * 2, a.N, false, &plan, false) || plan.splits != 1) return HYMETA_ERR_UNSUPPORTED;
   StreamArgs sa = {};
   sa.x = static_cast<const char*>(a.x), sa.w = static_cast<const char*>(a.weight);
   sa.bias = static_cast<const uint16_t*>(a.bias), sa.out = static_cast<uint16_t*>(a.out);

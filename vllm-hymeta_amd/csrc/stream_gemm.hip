@@ -367,9 +367,9 @@ static int tune(const char* name) {
   return e == nullptr ? 0 : atoi(e);
 }
 
-bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* p) {
+bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* p, bool allow_tall) {
   p->tall = 0;
-  if (tall_gemm_plan(M, K_bytes, N, have_workspace, p)) return true;
+  if (allow_tall && tall_gemm_plan(M, K_bytes, N, have_workspace, p)) return true;
   if (M <= 0 || M > 128 || K_bytes % 128 != 0 || K_bytes < kChunkBytes || N % 64 != 0) return false;
   static const int nf_forced = tune("HYMETA_STREAM_NF"), splits_forced = tune("HYMETA_STREAM_SPLITS");
   static const int ring_forced = tune("HYMETA_STREAM_RING"), want_forced = tune("HYMETA_STREAM_WGS");

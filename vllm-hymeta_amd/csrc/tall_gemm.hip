@@ -47,14 +47,11 @@ __device__ __forceinline__ typename Acc<I8>::type mma(const u32x4& a, const u32x
 // 16 bytes per lane from global memory into LDS at (wave-uniform) dst + 16 lane.  Written as an asm statement, with
 // the waits for it counted by hand (wait_loads_then_barrier): the compiler books such a load on the LDS counter as
 // well, and while one is in flight -- here: always -- every wait for a fragment read becomes a wait for ALL of them.
-template <bool NT>
+// (The non-temporal hint on the weight requests, which the decode-sized kernel's register loads gain from, was measured
+// here too: level on whole-K tiles, 3 to 5 us slower per launch on the K-sliced 7B shapes.)
 __device__ __forceinline__ void glds16(const char* src, char* dst) {
   const uint32_t lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)dst));
-  if constexpr (NT) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lds), "v"(src) : "memory");
-  } else {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(src) : "memory");
-  }
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(src) : "memory");
 }
 
 template <int N>
@@ -130,9 +127,9 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
   auto request = [&](int q, int g) {
     if (q >= kReq) return;
     if (q < kXInstr) {
-      glds16<false>(src[q] + pair_off(g + 1), xbuf + ((g + 1) & 1) * kXBuf + dst[q]);
+      glds16(src[q] + pair_off(g + 1), xbuf + ((g + 1) & 1) * kXBuf + dst[q]);
     } else {
-      glds16<true>(src[q] + pair_off(g + 2), wbuf + ((g + 2) % kWRing) * kWSlot + dst[q]);
+      glds16(src[q] + pair_off(g + 2), wbuf + ((g + 2) % kWRing) * kWSlot + dst[q]);
     }
   };
   // every wave: until all but its newest weight requests have landed, then until every wave's have -- at which point
@@ -320,7 +317,8 @@ int launch_tall(const StreamArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// HYMETA_TALL_MIN_ROWS: rows from which the tall kernel is planned (default 129; tuning and tests).
+// HYMETA_TALL_MIN_ROWS: rows from which the tall kernel is planned (default 129: at 128 rows the decode-sized kernel
+// is level for int8 and 5 % ahead for bf16 on the 7B step; above 256 turns this kernel off).
 static int tall_min_rows() {
   static const int v = [] {
     const char* e = getenv("HYMETA_TALL_MIN_ROWS");
