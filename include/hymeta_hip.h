@@ -666,17 +666,19 @@ typedef struct hymeta_bf16_gemm_args {
 int hymeta_bf16_gemm_split_k(int32_t M, int32_t K, int32_t N);
 size_t hymeta_bf16_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int hymeta_bf16_gemm(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream);
-/* 1 when hymeta_bf16_gemm (split_k 0, workspace of hymeta_bf16_gemm_workspace_bytes(M, N, 0)) -- or, with silu_mul
- * set, hymeta_bf16_gemm_silu_mul (N counts the gate and the up rows) -- takes the shape, 0 when it would answer
+/* 1 when the entry point named by `form` -- 0: hymeta_bf16_gemm (split_k 0, workspace of
+ * hymeta_bf16_gemm_workspace_bytes(M, N, 0)); 1: hymeta_bf16_gemm_silu_mul (N counts the gate and the up rows);
+ * 2: hymeta_bf16_gemm_f32out -- takes the shape, 0 when it would answer
  * HYMETA_ERR_UNSUPPORTED and the caller runs a library GEMM: every covered shape up to 128 rows; from 129 to 256
  * rows what the 129..256-row streaming kernel cuts into at least 128 workgroups (tiles of 112 to 160 columns; K
  * slices of at least 512 bytes for narrow matrices).  No counterpart in the reference (its linears are vLLM's):
  * a question of the host-side dispatch. */
-int hymeta_bf16_gemm_takes(int32_t M, int32_t K, int32_t N, int32_t silu_mul);
+int hymeta_bf16_gemm_takes(int32_t M, int32_t K, int32_t N, int32_t form);
 
 /* Logits of a bf16 lm_head: out fp32 [M, N] (out_stride_m in fp32 elements, a multiple of 4) = x weight^T (+ bias)
- * with fp32 accumulation and no rounding of the result; workspace and split_k unused.  M <= 128, K a multiple of 64 and
- * at least 256, N a multiple of 64; other shapes HYMETA_ERR_UNSUPPORTED.
+ * with fp32 accumulation and no rounding of the result; workspace and split_k unused.  M <= 128 (to 256 where
+ * hymeta_bf16_gemm_takes(M, K, N, 2) says so: wide matrices), K a multiple of 64 and at least 256, N a multiple of 64;
+ * other shapes HYMETA_ERR_UNSUPPORTED.
  * Replaces lm_head.float() applied to hidden_states.float() in compute_logits
  * (vllm_hymeta/model_for_7B/modeling_gla_swa.py:548,579-583, vllm_hymeta/models/modeling_hymeta.py:1429,1462-1466):
  * a checkpoint's bf16 lm_head widened to fp32 holds the same values, so the product of the bf16 operands accumulated

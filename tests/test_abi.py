@@ -140,5 +140,5 @@ def test_shapes_the_bf16_entry_point_takes_above_128_rows():
     takes = _C.load().hymeta_bf16_gemm_takes
     assert takes(256, 18944, 3584, 0) == 1 and takes(129, 18944, 3584, 0) == 1        # deep, narrow: K slices
     assert takes(256, 3584, 3584, 0) == 1 and takes(256, 3584, 37888, 1) == 1         # K slices; whole tiles with the activation
-    assert takes(256, 3584, 9472, 1) == 0 and takes(256, 256, 1024, 0) == 0              # too few workgroups: a library GEMM
+    assert takes(256, 3584, 9472, 1) == 0 and takes(256, 256, 1024, 0) == 0 and takes(256, 3584, 152064, 2) == 1 and takes(256, 3584, 3584, 2) == 0              # too few workgroups: a library GEMM
     assert takes(128, 3584, 3584, 0) == 1 and takes(257, 18944, 3584, 0) == 0 and takes(64, 96, 64, 0) == 1

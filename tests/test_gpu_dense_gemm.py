@@ -199,11 +199,13 @@ def test_qkv_projection_finished_by_rope_from_its_partial_sums(kind):
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize("M,K,N", [(1, 512, 1024), (20, 3584, 4096), (64, 3584, 151936), (130, 1024, 2048 + 64)])
+@pytest.mark.parametrize("M,K,N", [(1, 512, 1024), (20, 3584, 4096), (64, 3584, 151936), (130, 1024, 2048 + 64), (200, 3584, 151936),
+                                   (300, 1024, 40960)])
 def test_bf16_logits_are_the_fp32_product_of_the_widened_operands(M, K, N):
     """lm_head kept in bf16: x W^T with fp32 accumulation and an unrounded fp32 result, against the fp64 product of the
     same bf16 values (what lm_head.float() on hidden_states.float() computes, up to fp32 summation error) -- also more
-    than 64 rows (64 at a time) and the 7B vocabulary; then the greedy token of each row."""
+    than 128 rows (128 at a time, or 256 where the 129..256-row kernel takes the matrix: the wide ones) and the 7B
+    vocabulary; then the greedy token of each row."""
     from vllm_hymeta import hip_ops
 
     g_ = gen(41)
@@ -211,7 +213,9 @@ def test_bf16_logits_are_the_fp32_product_of_the_widened_operands(M, K, N):
     w = randn_bf16(g_, N, K, scale=K ** -0.5).cuda()
     got = hip_ops.bf16_logits(x, w)
     assert got.dtype == torch.float32 and got.shape == (M, N)
-    rows = slice(0, M) if N <= 8192 else slice(0, 4)                  # the fp64 product of the large case on a few rows
+    # the fp64 product of the large cases on a few rows: the first ones, one of every later 64, the last
+    rows = torch.arange(M) if N <= 8192 else torch.tensor(sorted({0, 1, 2, 3, M - 1} | set(range(70, M, 64))))
+    rows = rows.cuda()
     ref = x[rows].double() @ w.double().t()
     err = (got[rows].double() - ref).abs().max().item()
     assert err <= 2e-5 * ref.abs().max().item(), err

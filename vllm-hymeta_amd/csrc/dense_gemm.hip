@@ -163,10 +163,11 @@ extern "C" size_t hymeta_bf16_gemm_workspace_bytes(int32_t M, int32_t N, int32_t
   return counters + static_cast<size_t>(split_k) * M * N * sizeof(float);
 }
 
-extern "C" int hymeta_bf16_gemm_takes(int32_t M, int32_t K, int32_t N, int32_t silu_mul) {
+extern "C" int hymeta_bf16_gemm_takes(int32_t M, int32_t K, int32_t N, int32_t form) {
   if (M <= 0 || K <= 0 || N <= 0 || M > 256 || K % 32 != 0 || N % kCols != 0 || K > (1 << 28)) return 0;
   StreamPlan plan;
-  if (silu_mul) return stream_gemm_plan_gated(M, K * 2, N, &plan) ? 1 : 0;
+  if (form == 1) return stream_gemm_plan_gated(M, K * 2, N, &plan) ? 1 : 0;
+  if (form == 2) return stream_gemm_plan(M, K * 2, N, false, &plan) && plan.splits == 1 ? 1 : 0;
   if (M <= 64) return 1;
   return stream_gemm_plan(M, K * 2, N, true, &plan) ? 1 : 0;
 }
@@ -249,7 +250,7 @@ extern "C" int hymeta_bf16_gemm_f32out(const hymeta_bf16_gemm_args* args, hymeta
        reinterpret_cast<uintptr_t>(a.bias)) % 16 != 0)
     return HYMETA_ERR_UNSUPPORTED;
   StreamPlan plan;
-  if (a.K > (1 << 28) || !stream_gemm_plan(a.M, a.K * 2, a.N, false, &plan, false) || plan.splits != 1) return HYMETA_ERR_UNSUPPORTED;
+  if (a.K > (1 << 28) || !stream_gemm_plan(a.M, a.K * 2, a.N, false, &plan) || plan.splits != 1) return HYMETA_ERR_UNSUPPORTED;
   StreamArgs sa = {};
   sa.x = static_cast<const char*>(a.x), sa.w = static_cast<const char*>(a.weight);
   sa.bias = static_cast<const uint16_t*>(a.bias), sa.out = static_cast<uint16_t*>(a.out);

@@ -33,7 +33,7 @@ struct StreamPlan {
 
 // Whether a streaming kernel takes the shape (M <= 128 rows: the decode-sized kernel; 129..256 rows: the tall one; K a multiple of 128 bytes and at least 512, N of 64 columns), and how
 // it is cut (one workgroup per compute unit where the shape allows).  Without a workspace every workgroup owns whole tiles (no slabs).
-bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* plan, bool allow_tall = true);
+bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* plan);
 // Gated form (see StreamArgs::gated): N counts the gate and the up rows together and must be a multiple of 128.
 bool stream_gemm_plan_gated(int M, int K_bytes, int N, StreamPlan* plan);
 // Slab bytes of that plan (0 without K slices); no ticket counters are used.

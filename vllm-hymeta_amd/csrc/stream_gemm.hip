@@ -367,9 +367,9 @@ static int tune(const char* name) {
   return e == nullptr ? 0 : atoi(e);
 }
 
-bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* p, bool allow_tall) {
+bool stream_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* p) {
   p->tall = 0;
-  if (allow_tall && tall_gemm_plan(M, K_bytes, N, have_workspace, p)) return true;
+  if (tall_gemm_plan(M, K_bytes, N, have_workspace, p)) return true;
   if (M <= 0 || M > 128 || K_bytes % 128 != 0 || K_bytes < kChunkBytes || N % 64 != 0) return false;
   static const int nf_forced = tune("HYMETA_STREAM_NF"), splits_forced = tune("HYMETA_STREAM_SPLITS");
   static const int ring_forced = tune("HYMETA_STREAM_RING"), want_forced = tune("HYMETA_STREAM_WGS");
@@ -430,7 +430,7 @@ int stream_gemm_launch(StreamArgs a, const StreamPlan& p, hipStream_t s, bool de
   a.tiles = p.tiles, a.chunks = p.chunks, a.splits = p.splits;
   if (p.tall) {
     if (a.gated && (p.splits != 1 || a.bias != nullptr)) return HYMETA_ERR_INVALID_ARG;
-    if (a.out_f32) return HYMETA_ERR_UNSUPPORTED;
+    if (a.out_f32 && (p.splits != 1 || a.gated)) return HYMETA_ERR_INVALID_ARG;
     const int rc = tall_gemm_launch<I8>(a, p, s);
     if (rc != HYMETA_OK || a.splits == 1 || defer_reduce) return rc;
     const int64_t threads = static_cast<int64_t>(a.M) * (a.N / 4);

@@ -276,6 +276,10 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
       } else {
         y = sum + b;
       }
+      if (a.out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + static_cast<int64_t>(row) * a.out_stride + col) = y;
+        continue;
+      }
       const u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
       *reinterpret_cast<u32x2*>(a.out + static_cast<int64_t>(row) * a.out_stride + col) = o;
     }
@@ -354,7 +358,7 @@ bool tall_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* 
 
 template <bool I8>
 int tall_gemm_launch(const StreamArgs& a, const StreamPlan& p, hipStream_t s) {
-  if (a.M <= 0 || a.M > 256 || a.k_bytes % 128 != 0 || a.k_bytes / 128 < p.splits || a.out_f32) return HYMETA_ERR_INVALID_ARG;
+  if (a.M <= 0 || a.M > 256 || a.k_bytes % 128 != 0 || a.k_bytes / 128 < p.splits) return HYMETA_ERR_INVALID_ARG;
   if (p.nf < 8 || p.nf > kMaxNf) return HYMETA_ERR_INVALID_ARG;
   if (a.M <= 192) return launch_tall<3, I8>(a, s);
   return launch_tall<4, I8>(a, s);

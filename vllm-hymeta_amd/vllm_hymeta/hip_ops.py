@@ -961,7 +961,7 @@ def logits_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
 def bf16_logits(x: torch.Tensor, weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x bf16 [M, K] @ weight bf16 [N, K]^T -> fp32 [M, N], fp32 accumulation, result not rounded: the logits of a bf16
     lm_head (the fp32 GEMM of the operands widened to fp32, up to the order of the sums).  Rows go through the
-    weight-streaming kernel 64 at a time."""
+    weight-streaming kernels 128 or 256 at a time."""
     _dev(x, weight, out)
     M, K = x.shape
     N = weight.shape[0]
@@ -970,8 +970,14 @@ def bf16_logits(x: torch.Tensor, weight: torch.Tensor, out: Optional[torch.Tenso
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     _require(out.shape == (M, N) and out.dtype == torch.float32 and out.stride(1) == 1 and out.stride(0) % 4 == 0, "out must be fp32 [M, N]")
     lib = _C.load()
-    for r0 in range(0, M, BF16_GEMM_MAX_ROWS):
-        xs, os_ = x[r0:r0 + BF16_GEMM_MAX_ROWS], out[r0:r0 + BF16_GEMM_MAX_ROWS]
+    r0 = 0
+    while r0 < M:
+        # 256 rows at a time where the 129..256-row kernel takes the matrix (one pass over the weights instead of two)
+        rows = min(M - r0, BF16_GEMM_TALL_ROWS)
+        if rows > BF16_GEMM_MAX_ROWS and not lib.hymeta_bf16_gemm_takes(rows, K, N, 2):
+            rows = BF16_GEMM_MAX_ROWS
+        xs, os_ = x[r0:r0 + rows], out[r0:r0 + rows]
+        r0 += rows
         a = _C.Bf16GemmArgs()
         a.x, a.weight, a.out = _p(xs), _p(weight), _p(os_)
         a.M, a.K, a.N = xs.shape[0], K, N
