@@ -588,6 +588,11 @@ int hymeta_lowrank_gate(const hymeta_lowrank_gate_args* args, hymeta_stream_t st
  * hymeta_gptq_gemm_workspace_bytes(M, N, 0), is a bound that holds for every K.  Without a
  * workspace the library runs unsplit.  split_k > 1 forces that many slices and needs
  * hymeta_gptq_gemm_workspace_bytes(M, N, split_k) bytes.
+ * From 129 to 256 rows (4-bit, group size 64 or 128, split_k <= 0) the 129..256-row streaming kernel runs instead,
+ * on the shapes it cuts into at least 128 workgroups: it reads the packed weights ONCE for all rows and expands each
+ * word to bf16(scale * (q - zero)) -- the values hymeta_gptq_dequant writes -- on its way into LDS, so its result
+ * equals hymeta_bf16_gemm on the expanded matrix bit for bit (the kernels below 129 rows keep q exact and apply scale
+ * and zero to fp32 partial sums: results of the two regimes agree to bf16 rounding of the weights, not bit for bit).
  *
  * Workspace contract of the three split-K GEMMs (hymeta_gptq_gemm, hymeta_bf16_gemm,
  * hymeta_w8a8_gemm): the first HYMETA_GEMM_TICKET_BYTES bytes are the ticket counters.  Zero them

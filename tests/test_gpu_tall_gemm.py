@@ -100,3 +100,47 @@ def test_gate_up_with_the_activation_in_the_epilogue_above_128_rows(kind, M, K, 
     two = hip_ops.silu_and_mul(lin(x))
     torch.cuda.synchronize()
     assert fused.shape == (M, I) and torch.equal(fused, two)
+
+
+@pytest.mark.parametrize("group,scales_dtype,zero_offset", [(128, torch.float16, 1), (64, torch.bfloat16, 0)])
+@pytest.mark.parametrize("M,K,N,bias", [
+    (256, 3584, 4608, True),         # K slices
+    (200, 18944, 3584, False),       # deep K: 296 pairs in 9 slices
+    (130, 3584, 37888, False),       # whole tiles of 9 or 10 fragments
+    (193, 1024, 4608 + 64, True),    # tiles of 7 or 8 fragments, 16 pairs
+])
+def test_gptq4_rows_129_to_256(M, K, N, bias, group, scales_dtype, zero_offset):
+    """4-bit GPTQ linears at 129..256 rows: the packed words are expanded into the kernel's weight image as
+    bf16(scale * (q - zero)) -- the values of the whole-matrix expansion -- so the result equals the bf16 kernel run on
+    the expanded matrix bit for bit (same tiles, same order of the sums), and the fp64 restatement within tolerance."""
+    from oracle.quant import gptq_gemm_ref
+    from test_gpu_quant import _gptq_problem
+    from vllm_hymeta import hip_ops
+    from vllm_hymeta.linear import HymetaLinear
+
+    qw, qz, scales = _gptq_problem(M + K + N, K, N, 4, group, scales_dtype)
+    g_ = gen(M + N)
+    x = randn_bf16(g_, M, K)
+    b = randn_bf16(g_, N) if bias else None
+    lin = HymetaLinear.from_gptq(qw.cuda(), qz.cuda(), scales.cuda(), 4, group, bias=None if b is None else b.cuda(), zero_offset=zero_offset)
+    xd = x.cuda()
+    y, again = lin(xd), lin(xd)
+    w_t = hip_ops.gptq_dequant(lin.qweight, lin.qzeros, lin.scales, 4, group, zero_offset=zero_offset).t().contiguous()      # [N, K]
+    assert hip_ops.bf16_gemm_supported(xd, w_t)
+    same_tiles = hip_ops.bf16_gemm(xd, w_t, lin.bias)
+    torch.cuda.synchronize()
+    assert torch.equal(y, again)
+    assert torch.equal(y, same_tiles), "the expanded pair in LDS holds the values of the expanded matrix"
+    if M * K * N < 6e9:
+        ref = gptq_gemm_ref(x, qw, qz, scales, 4, group, b, zero_offset=zero_offset)
+        assert_bf16_close(y.cpu(), ref, f"gptq4 M={M} K={K} N={N}", rel=8e-3)
+    if N < 16384:
+        part = lin(xd, defer=True)
+        assert isinstance(part, hip_ops.PartialSums), "cut into K slices"
+        nw = (1 + 0.1 * torch.randn(N, generator=g_)).to(torch.bfloat16).cuda()
+        res = randn_bf16(g_, M, N).cuda()
+        r1, r2 = res.clone(), res.clone()
+        out1 = hip_ops.add_rmsnorm(y, nw, 1e-6, residual=r1)
+        out2 = hip_ops.add_rmsnorm(part, nw, 1e-6, residual=r2)
+        torch.cuda.synchronize()
+        assert torch.equal(out1, out2) and torch.equal(r1, r2)

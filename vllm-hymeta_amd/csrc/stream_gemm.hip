@@ -425,6 +425,12 @@ size_t stream_gemm_workspace_bound(int M, int N) {
   return static_cast<size_t>(kMaxSplits) * M * N * 4 / (N >= 16384 ? 4 : 1);   // wide matrices never take more than kMaxSplits / 4 slices
 }
 
+int stream_gemm_reduce_launch(const StreamArgs& a, hipStream_t s) {
+  const int64_t threads = static_cast<int64_t>(a.M) * (a.N / 4);
+  hipLaunchKernelGGL(stream_gemm_reduce_kernel<false>, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, s, a);
+  return launch_status();
+}
+
 template <bool I8>
 int stream_gemm_launch(StreamArgs a, const StreamPlan& p, hipStream_t s, bool defer_reduce) {
   a.tiles = p.tiles, a.chunks = p.chunks, a.splits = p.splits;

@@ -1,4 +1,5 @@
-// Weight-streaming GEMM for 129 to 256 rows: out = x W^T (+ bias), W [N, K] K-contiguous (bf16, or int8 against int8 rows).
+// Weight-streaming GEMM for 129 to 256 rows: out = x W^T (+ bias), W [N, K] K-contiguous (bf16, or int8 against int8 rows),
+// or 4-bit GPTQ weights (qweight int32 [K / 8, N], group size 64 or 128).
 //
 // At these row counts a weight is still read once, but each one now feeds 256 multiply-adds: the matrix cores and the
 // HBM stream are both near their limits (one compute unit's share of HBM, 31 GB/s, is 8 TFLOP/s of its 9.8 at 256
@@ -19,6 +20,10 @@
 //     images pair g - 1 used.  x comes from L2 (one pair of latency), the weights from HBM (two).  Past the end of the
 //     slice the same instructions re-load the last pair into an idle image, so that the count the wait relies on is the
 //     same in every trip.
+//   * 4-bit GPTQ weights (GPTQ = true) do not come by LDS-DMA: a pair of a 160-column tile is 5 KB of packed words, which
+//     the workgroup's threads load (one pair ahead, three words a thread), expand to bf16(scale * (q - zero)) -- the
+//     values of the whole-matrix expansion -- and write into one of two weight images behind the barrier, one word per
+//     step; the MFMA loop is the bf16 one.
 //   * the matrix's N / 16 fragments are dealt to the tiles in equal shares (9 or 10 to each of 256 workgroups for the 7B
 //     gate_up matrix); narrow matrices use 128-column tiles and K slices whose fp32 partial tiles go to slabs
 //     [slice][M][N], summed by the reduce kernel or by the consumer (the same contract as the decode-sized kernel).
@@ -71,7 +76,7 @@ constexpr int kWInstr = 3;       // weight instructions per wave and pair: 8 x 3
 // Every wave requests an eighth of each pair's x and weight lines.  The counter a wave waits on counts its requests in
 // the order they were made: per pair it asks for x (one pair ahead of its use, from L2) first and then for the weights
 // (two pairs ahead, from HBM), so that the wait which opens a pair can leave exactly the newest weights in flight.
-template <int MTW, int NFW, bool I8>
+template <int MTW, int NFW, bool I8, bool GPTQ = false>
 __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const int tile_f0, const int nf, const int wave_f0,
                                           const int split) {
   typedef typename Acc<I8>::type acc_t;
@@ -79,7 +84,9 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
   constexpr int kXBuf = kRows * 128;            // one pair of every row
   constexpr int kWSlot = kMaxNf * 2048;         // one pair of the tile's weight rows
   constexpr int kXInstr = MTW;                  // x instructions per wave and pair (8 rows each)
-  constexpr int kReq = kXInstr + kWInstr;       // requests per wave and pair
+  constexpr int kReq = kXInstr + (GPTQ ? 0 : kWInstr);      // requests per wave and pair
+  constexpr int kRing = GPTQ ? 2 : kWRing;      // weight images (GPTQ: expanded by the workgroup itself, one pair ahead)
+  constexpr int kItems = 3;                     // GPTQ: packed words a thread expands per pair (8 x 16 kMaxNf <= 3 x 512)
   constexpr int kPitch = 16 * kMaxNf + 4;       // floats per row of the epilogue image
   static_assert(kReq <= 2 * NFW, "one request per step");
 
@@ -112,7 +119,7 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
     dst[q] = t * 1024;
   }
 #pragma unroll
-  for (int u = 0; u < kWInstr; ++u) {
+  for (int u = 0; u < (GPTQ ? 0 : kWInstr); ++u) {
     const int t = min(wave + 8 * u, 2 * nf - 1);        // a wave past the tile's last instruction repeats it
     const int i = t >> 1, j = t & 1, r = 8 * j + sub;
     // plain: a fragment's 16 weight rows are consecutive output columns.  Gated: 8 gate rows, then the 8 up rows of
@@ -129,12 +136,56 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
     if (q < kXInstr) {
       glds16(src[q] + pair_off(g + 1), xbuf + ((g + 1) & 1) * kXBuf + dst[q]);
     } else {
-      glds16(src[q] + pair_off(g + 2), wbuf + ((g + 2) % kWRing) * kWSlot + dst[q]);
+      glds16(src[q] + pair_off(g + 2), wbuf + ((g + 2) % kRing) * kWSlot + dst[q]);
     }
   };
   // every wave: until all but its newest weight requests have landed, then until every wave's have -- at which point
-  // every wave has also issued its last read of the pair before
-  auto landed = [&]() { wait_loads_then_barrier<kWInstr>(); };
+  // every wave has also issued its last read of the pair before.  GPTQ: everything the wave has asked for (x of the
+  // next pair, the packed words of the one after) and its writes of the expanded pair.
+  auto landed = [&]() {
+    if constexpr (GPTQ) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else wait_loads_then_barrier<kWInstr>();
+  };
+
+  // GPTQ: the tile's packed words of a pair are 8 rows (8 k each) x 16 nf columns; a thread takes up to three of them
+  // (item = thread + 512 m: consecutive threads, consecutive columns), expands each into the 16-byte piece of its
+  // column's 128-byte line in the weight image -- bf16(scale * (q - zero)), the arithmetic of the whole-matrix expansion
+  // -- and asks for the same item of the next pair at once: a word is in flight for one pair.
+  uint32_t qw[kItems], qs[kItems], qz[kItems];
+  const char* qsrc[kItems];
+  int qcol[kItems], qdst[kItems], qrow[kItems];
+  if constexpr (GPTQ) {
+#pragma unroll
+    for (int m = 0; m < kItems; ++m) {
+      const int item = min(tid + kThreads * m, 8 * 16 * nf - 1);      // threads past the last word repeat it
+      const int j = item / (16 * nf), c = item % (16 * nf);
+      const int i = c >> 4, r = c & 15;
+      qcol[m] = a.gated ? (r < 8 ? 0 : up0) + 8 * (tile_f0 + i) + (r & 7) : 16 * (tile_f0 + i) + r;
+      qrow[m] = j;
+      qsrc[m] = a.w + (static_cast<int64_t>(p_lo) * 8 + j) * a.N * 4 + static_cast<int64_t>(qcol[m]) * 4;
+      qdst[m] = c * 128 + ((j ^ ((r >> 1) & 7)) * 16);
+    }
+  }
+  auto ask_item = [&](int m, int g) {        // the words, scale and zeros of item m for pair g
+    const int pg = min(g, P - 1);
+    qw[m] = *reinterpret_cast<const uint32_t*>(qsrc[m] + static_cast<int64_t>(pg) * 8 * a.N * 4);
+    const int grp = (p_lo + pg) * 64 / a.group_size;
+    qs[m] = static_cast<const uint16_t*>(a.scales)[static_cast<int64_t>(grp) * a.N + qcol[m]];
+    qz[m] = static_cast<const uint32_t*>(a.qzeros)[static_cast<int64_t>(grp) * (a.N / 8) + (qcol[m] >> 3)];
+  };
+  auto expand_item = [&](int m, int g) {     // item m as loaded, into the image of pair g
+    const float sc = a.scales_f16 ? static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(qs[m])))
+                                  : __uint_as_float(qs[m] << 16);
+    const float zf = static_cast<float>(((qz[m] >> (4 * (qcol[m] & 7))) & 0xFu) + a.zero_offset);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = sc * (static_cast<float>((qw[m] >> (8 * e)) & 0xFu) - zf);
+      const float hi = sc * (static_cast<float>((qw[m] >> (8 * e + 4)) & 0xFu) - zf);
+      o[e] = pack_bf16x2(lo, hi);
+    }
+    *reinterpret_cast<u32x4*>(wbuf + (g & 1) * kWSlot + qdst[m]) = o;
+  };
 
   // fragment reads: row n of a 16-row fragment, piece 4 h + cq of its 128-byte line
   int roff[2];
@@ -158,22 +209,58 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
       fa[h][i] = *reinterpret_cast<const u32x4*>(xbuf + (g & 1) * kXBuf + (rg + 4 * i) * 2048 + roff[h]);
 #pragma unroll
     for (int f = 0; f < NFW; ++f)
-      fb[h][f] = *reinterpret_cast<const u32x4*>(wbuf + (g % kWRing) * kWSlot + (wave_f0 + f) * 2048 + roff[h]);
+      fb[h][f] = *reinterpret_cast<const u32x4*>(wbuf + (g % kRing) * kWSlot + (wave_f0 + f) * 2048 + roff[h]);
   };
   auto mfmas = [&](int h, int f) {
 #pragma unroll
     for (int i = 0; i < MTW; ++i) acc[i][f] = mma<I8>(fa[h][i], fb[h][f], acc[i][f]);
   };
-  // before the loop: x of pair 0, the weights of pairs 0 and 1 (the sets of g = -2 and -1 as far as they exist)
+  // What a wave does at step f (1 .. NFW - 1) behind the barrier that opens pair g + 1: its requests for x of pair
+  // g + 2 (and the weights of pair g + 3), the set the next barrier waits for.  GPTQ: per step one item of pair g + 2 expanded and
+  // re-asked for g + 3, then all x requests (the wait at the next barrier is for everything).
+  auto behind_barrier = [&](int f, int g) {
+    if constexpr (GPTQ) {
+      if (f - 1 < kItems) {
+        expand_item(f - 1, g + 2);
+        ask_item(f - 1, g + 3);
+      }
+      // x last: the compiler counts only its own loads when it waits for an item's words, and a request of this wave
+      // still in flight in front of them would make that wait a wait for x
+      if (f == NFW - 1) {
 #pragma unroll
-  for (int q = 0; q < kXInstr; ++q) request(q, -1);
+        for (int q = 0; q < kXInstr; ++q) request(q, g + 1);
+      }
+    } else {
+      request(f - 1, g + 1);
+    }
+  };
+  static_assert(!GPTQ || kItems <= 3, "NFW - 1 >= 3 steps behind the barrier");
+  if constexpr (GPTQ) {
+    // before the loop: pair 0 expanded, pair 1 in registers, x of pair 0 asked for
 #pragma unroll
-  for (int q = kXInstr; q < kReq; ++q) request(q, -2);
+    for (int q = 0; q < kXInstr; ++q) request(q, -1);
 #pragma unroll
-  for (int q = kXInstr; q < kReq; ++q) request(q, -1);
-  landed();                       // pair 0
+    for (int m = 0; m < kItems; ++m) ask_item(m, 0);
 #pragma unroll
-  for (int q = 0; q < NFW - 1; ++q) request(q, 0);
+    for (int m = 0; m < kItems; ++m) {
+      expand_item(m, 0);
+      ask_item(m, 1);
+    }
+    landed();                     // pair 0
+#pragma unroll
+    for (int f = 1; f < NFW; ++f) behind_barrier(f, -1);
+  } else {
+    // before the loop: x of pair 0, the weights of pairs 0 and 1 (the sets of g = -2 and -1 as far as they exist)
+#pragma unroll
+    for (int q = 0; q < kXInstr; ++q) request(q, -1);
+#pragma unroll
+    for (int q = kXInstr; q < kReq; ++q) request(q, -2);
+#pragma unroll
+    for (int q = kXInstr; q < kReq; ++q) request(q, -1);
+    landed();                       // pair 0
+#pragma unroll
+    for (int q = 0; q < NFW - 1; ++q) request(q, 0);
+  }
   reads(0, 0);
   for (int g = 0; g < P; ++g) {
     // the scheduler may not move anything across a step's boundaries (left alone it puts every read right before its
@@ -182,7 +269,7 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
     reads(g, 1);
 #pragma unroll
     for (int f = 0; f < NFW; ++f) {
-      request(NFW - 1 + f, g);
+      if constexpr (!GPTQ) request(NFW - 1 + f, g);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(0, f);
       __builtin_amdgcn_sched_barrier(0);
@@ -194,7 +281,7 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
     reads(g + 1, 0);
 #pragma unroll
     for (int f = 1; f < NFW; ++f) {
-      request(f - 1, g + 1);
+      behind_barrier(f, g);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(1, f);
       __builtin_amdgcn_sched_barrier(0);
@@ -288,7 +375,7 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
 
 // A tile holds 8 to 10 fragments (the matrix's fragments dealt in equal shares); waves 0..3 own its first
 // (nf + 1) / 2, waves 4..7 the rest.
-template <int MTW, bool I8>
+template <int MTW, bool I8, bool GPTQ = false>
 __global__ __launch_bounds__(kThreads) void tall_gemm_kernel(StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
@@ -299,16 +386,16 @@ __global__ __launch_bounds__(kThreads) void tall_gemm_kernel(StreamArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int first = (nf + 1) / 2;
   const int mine = wave < 4 ? first : nf - first;
-  if (mine == 5) tall_wave<MTW, 5, I8>(a, smem, f_lo, nf, wave < 4 ? 0 : first, split);
-  else tall_wave<MTW, 4, I8>(a, smem, f_lo, nf, wave < 4 ? 0 : first, split);
+  if (mine == 5) tall_wave<MTW, 5, I8, GPTQ>(a, smem, f_lo, nf, wave < 4 ? 0 : first, split);
+  else tall_wave<MTW, 4, I8, GPTQ>(a, smem, f_lo, nf, wave < 4 ? 0 : first, split);
 }
 
-template <int MTW, bool I8>
+template <int MTW, bool I8, bool GPTQ = false>
 int launch_tall(const StreamArgs& a, hipStream_t s) {
   constexpr size_t img = static_cast<size_t>(64) * (16 * kMaxNf + 4) * 4;
-  constexpr size_t stream = static_cast<size_t>(2) * 64 * MTW * 128 + static_cast<size_t>(kWRing) * kMaxNf * 2048;
+  constexpr size_t stream = static_cast<size_t>(2) * 64 * MTW * 128 + static_cast<size_t>(GPTQ ? 2 : kWRing) * kMaxNf * 2048;
   constexpr size_t lds = img > stream ? img : stream;
-  auto kern = tall_gemm_kernel<MTW, I8>;
+  auto kern = tall_gemm_kernel<MTW, I8, GPTQ>;
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
@@ -362,6 +449,17 @@ int tall_gemm_launch(const StreamArgs& a, const StreamPlan& p, hipStream_t s) {
   if (p.nf < 8 || p.nf > kMaxNf) return HYMETA_ERR_INVALID_ARG;
   if (a.M <= 192) return launch_tall<3, I8>(a, s);
   return launch_tall<4, I8>(a, s);
+}
+
+int tall_gemm_gptq_launch(const StreamArgs& a0, const StreamPlan& p, hipStream_t s, bool defer_reduce) {
+  StreamArgs a = a0;
+  a.tiles = p.tiles, a.chunks = p.chunks, a.splits = p.splits;
+  if (!p.tall || a.M <= 0 || a.M > 256 || a.k_bytes % 128 != 0 || a.k_bytes / 128 < p.splits || a.out_f32) return HYMETA_ERR_INVALID_ARG;
+  if (a.group_size != 64 && a.group_size != 128) return HYMETA_ERR_UNSUPPORTED;
+  if (p.nf < 8 || p.nf > kMaxNf || (a.gated && p.splits != 1)) return HYMETA_ERR_INVALID_ARG;
+  const int rc = a.M <= 192 ? launch_tall<3, false, true>(a, s) : launch_tall<4, false, true>(a, s);
+  if (rc != HYMETA_OK || a.splits == 1 || defer_reduce) return rc;
+  return stream_gemm_reduce_launch(a, s);
 }
 
 template int tall_gemm_launch<false>(const StreamArgs&, const StreamPlan&, hipStream_t);

@@ -1,5 +1,5 @@
 """Linear layers of the attention blocks: bf16 or one of the fused dequant-GEMMs (GPTQ 4/8-bit, W8A8).
-Decode-sized batches (up to 128 rows, int8 up to 256; GPTQ up to 64) always run on this package's weight-streaming kernels; prefill-sized
+Decode-sized batches (up to 256 rows; GPTQ: up to 64 and 129 to 256) run on this package's weight-streaming kernels; prefill-sized
 batches of bf16 / expanded GPTQ / int8 weights go to the library GEMM.  Stands where the reference puts vLLM's
 ``QKVParallelLinear`` / ``RowParallelLinear`` / ``ReplicatedLinear`` with a ``quant_config``
 (``vllm_hymeta/model_for_7B/gla_attention.py:147-176``): a tensor-parallel shard is simply a
