@@ -588,7 +588,7 @@ int hymeta_lowrank_gate(const hymeta_lowrank_gate_args* args, hymeta_stream_t st
  * hymeta_gptq_gemm_workspace_bytes(M, N, 0), is a bound that holds for every K.  Without a
  * workspace the library runs unsplit.  split_k > 1 forces that many slices and needs
  * hymeta_gptq_gemm_workspace_bytes(M, N, split_k) bytes.
- * From 129 to 256 rows (4-bit, group size 64 or 128, split_k <= 0) the 129..256-row streaming kernel runs instead,
+ * From 129 to 256 rows (8-bit: from 65; group size 64 or 128, split_k <= 0) the 129..256-row streaming kernel runs instead,
  * on the shapes it cuts into at least 128 workgroups: it reads the packed weights ONCE for all rows and expands each
  * word to bf16(scale * (q - zero)) -- the values hymeta_gptq_dequant writes -- on its way into LDS, so its result
  * equals hymeta_bf16_gemm on the expanded matrix bit for bit (the kernels below 129 rows keep q exact and apply scale

@@ -102,15 +102,18 @@ def test_gate_up_with_the_activation_in_the_epilogue_above_128_rows(kind, M, K, 
     assert fused.shape == (M, I) and torch.equal(fused, two)
 
 
-@pytest.mark.parametrize("group,scales_dtype,zero_offset", [(128, torch.float16, 1), (64, torch.bfloat16, 0)])
+@pytest.mark.parametrize("bits,group,scales_dtype,zero_offset", [(4, 128, torch.float16, 1), (4, 64, torch.bfloat16, 0),
+                                                                 (8, 64, torch.float16, 1), (8, 128, torch.bfloat16, 0)])
 @pytest.mark.parametrize("M,K,N,bias", [
     (256, 3584, 4608, True),         # K slices
     (200, 18944, 3584, False),       # deep K: 296 pairs in 9 slices
     (130, 3584, 37888, False),       # whole tiles of 9 or 10 fragments
     (193, 1024, 4608 + 64, True),    # tiles of 7 or 8 fragments, 16 pairs
+    (100, 3584, 4608, True),         # 8-bit weights take this kernel from 65 rows on (two row fragments per wave)
+    (65, 18944, 3584, False),
 ])
-def test_gptq4_rows_129_to_256(M, K, N, bias, group, scales_dtype, zero_offset):
-    """4-bit GPTQ linears at 129..256 rows: the packed words are expanded into the kernel's weight image as
+def test_gptq_rows_129_to_256(M, K, N, bias, bits, group, scales_dtype, zero_offset):
+    """4- and 8-bit GPTQ linears at 129..256 rows: the packed words are expanded into the kernel's weight image as
     bf16(scale * (q - zero)) -- the values of the whole-matrix expansion -- so the result equals the bf16 kernel run on
     the expanded matrix bit for bit (same tiles, same order of the sums), and the fp64 restatement within tolerance."""
     from oracle.quant import gptq_gemm_ref
@@ -118,23 +121,25 @@ def test_gptq4_rows_129_to_256(M, K, N, bias, group, scales_dtype, zero_offset):
     from vllm_hymeta import hip_ops
     from vllm_hymeta.linear import HymetaLinear
 
-    qw, qz, scales = _gptq_problem(M + K + N, K, N, 4, group, scales_dtype)
+    qw, qz, scales = _gptq_problem(M + K + N, K, N, bits, group, scales_dtype)
     g_ = gen(M + N)
     x = randn_bf16(g_, M, K)
     b = randn_bf16(g_, N) if bias else None
-    lin = HymetaLinear.from_gptq(qw.cuda(), qz.cuda(), scales.cuda(), 4, group, bias=None if b is None else b.cuda(), zero_offset=zero_offset)
+    lin = HymetaLinear.from_gptq(qw.cuda(), qz.cuda(), scales.cuda(), bits, group, bias=None if b is None else b.cuda(), zero_offset=zero_offset)
     xd = x.cuda()
     y, again = lin(xd), lin(xd)
-    w_t = hip_ops.gptq_dequant(lin.qweight, lin.qzeros, lin.scales, 4, group, zero_offset=zero_offset).t().contiguous()      # [N, K]
-    assert hip_ops.bf16_gemm_supported(xd, w_t)
-    same_tiles = hip_ops.bf16_gemm(xd, w_t, lin.bias)
     torch.cuda.synchronize()
     assert torch.equal(y, again)
-    assert torch.equal(y, same_tiles), "the expanded pair in LDS holds the values of the expanded matrix"
+    if M > 128:
+        w_t = hip_ops.gptq_dequant(lin.qweight, lin.qzeros, lin.scales, bits, group, zero_offset=zero_offset).t().contiguous()      # [N, K]
+        assert hip_ops.bf16_gemm_supported(xd, w_t)
+        same_tiles = hip_ops.bf16_gemm(xd, w_t, lin.bias)
+        torch.cuda.synchronize()
+        assert torch.equal(y, same_tiles), "the expanded pair in LDS holds the values of the expanded matrix"
     if M * K * N < 6e9:
-        ref = gptq_gemm_ref(x, qw, qz, scales, 4, group, b, zero_offset=zero_offset)
-        assert_bf16_close(y.cpu(), ref, f"gptq4 M={M} K={K} N={N}", rel=8e-3)
-    if N < 16384:
+        ref = gptq_gemm_ref(x, qw, qz, scales, bits, group, b, zero_offset=zero_offset)
+        assert_bf16_close(y.cpu(), ref, f"gptq{bits} M={M} K={K} N={N}", rel=8e-3)
+    if N < 16384 and (M > 128 or bits == 8):
         part = lin(xd, defer=True)
         assert isinstance(part, hip_ops.PartialSums), "cut into K slices"
         nw = (1 + 0.1 * torch.randn(N, generator=g_)).to(torch.bfloat16).cuda()

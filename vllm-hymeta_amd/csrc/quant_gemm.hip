@@ -1101,7 +1101,7 @@ extern "C" size_t hymeta_gptq_gemm_workspace_bytes(int32_t M, int32_t N, int32_t
   // split_k <= 0 (the library chooses): never more (tile, slice) pairs than kMaxPairs, whatever K is
   if (split_k <= 0) {
     const size_t old = static_cast<size_t>(kMaxPairs) * 64 * kWideCols * sizeof(float);
-    const size_t streaming = M <= 64 ? stream_gptq_workspace_bound(M, N) : (M > 128 && M <= 256 ? stream_gemm_workspace_bound(M, N) : 0);
+    const size_t streaming = M <= 64 ? stream_gptq_workspace_bound(M, N) : (M <= 256 ? stream_gemm_workspace_bound(M, N) : 0);
     return gptq_counter_bytes(M, N) + (old > streaming ? old : streaming);
   }
   return gptq_counter_bytes(M, N) + static_cast<size_t>(split_k) * M * N * sizeof(float);
@@ -1157,19 +1157,23 @@ static int gptq_gemm_impl(const hymeta_gptq_gemm_args* args, hymeta_stream_t str
       return stream_gptq_launch(sa, sp, begin_launches(stream), deferred != nullptr);
     }
   }
-  // 129 to 256 rows, 4-bit: the 129..256-row streaming kernel with the packed words expanded into its weight image (one
-  // pass over the weights for all rows; the kernels below re-read and re-expand them per 64-row block).
-  // HYMETA_GPTQ_TALL=0 keeps those rows on the kernels below.  (From 65 rows it was measured too: the 7B step at 96 / 128
-  // sequences 7.24 / 7.73 ms against 7.18 / 7.59 on the kernels below.)
+  // 129 to 256 rows (8-bit: 65 to 256): the 129..256-row streaming kernel with the packed words expanded into its weight
+  // image (one pass over the weights for all rows; the kernels below re-read and re-expand them per 64-row block).
+  // Measured on the 7B shapes, us per launch, this kernel / the kernels below: 8-bit group 64 at 128 rows gate_up
+  // 76 / 103, down 50 / 60, qkv 24 / 25, o 24 / 25; at 64 rows 65 / 63, 42 / 40, 20 / 23, 19 / 21 (level); 4-bit
+  // group 128 at 96 / 128 sequences of the 7B step 7.24 / 7.73 ms against 7.18 / 7.59 (those rows stay below).
+  // HYMETA_GPTQ_TALL=0 keeps every row count on the kernels below; HYMETA_GPTQ8_TALL_FROM moves the 8-bit threshold.
   static const int tall_on = [] { const char* e = getenv("HYMETA_GPTQ_TALL"); return e ? atoi(e) : 1; }();
-  if (tall_on && a.split_k <= 0 && a.M > 128 && a.bits == 4 && (a.group_size == 64 || a.group_size == 128) && a.K % 64 == 0) {
+  static const int tall8_from = [] { const char* e = getenv("HYMETA_GPTQ8_TALL_FROM"); return e ? atoi(e) : 65; }();
+  const int tall_from = a.bits == 8 ? tall8_from : 129;
+  if (tall_on && a.split_k <= 0 && a.M >= tall_from && (a.group_size == 64 || a.group_size == 128) && a.K % 64 == 0) {
     StreamPlan tp;
     const bool have_ws = a.workspace != nullptr;
-    if (tall_gemm_plan(a.M, a.K * 2, a.N, have_ws, &tp) &&
+    if (tall_gemm_plan(a.M, a.K * 2, a.N, have_ws, &tp, tall_from) &&
         (!have_ws || a.workspace_bytes >= kTicketBytes + stream_gemm_workspace_bytes(a.M, a.N, tp))) {
       StreamArgs sa = {};
       sa.x = static_cast<const char*>(a.x), sa.w = reinterpret_cast<const char*>(a.qweight);
-      sa.qzeros = a.qzeros, sa.scales = a.scales;
+      sa.qzeros = a.qzeros, sa.scales = a.scales, sa.bits = a.bits;
       sa.scales_f16 = a.scales_dtype == HYMETA_F16, sa.zero_offset = a.zero_offset, sa.group_size = a.group_size;
       sa.bias = static_cast<const uint16_t*>(a.bias), sa.out = static_cast<uint16_t*>(a.out);
       sa.slabs = have_ws ? reinterpret_cast<char*>(a.workspace) + kTicketBytes : nullptr;

@@ -20,11 +20,11 @@ struct StreamArgs {
   int gated;              // 1: W = [gate rows | up rows] (N / 2 each), out [M, N / 2] = bf16(silu(bf16(x gate^T)) * bf16(x up^T));
                           // no bias, no K slices
   int tiles, chunks, splits;    // filled from the plan
-  // 4-bit GPTQ weights for the 129..256-row kernel (tall_gemm_gptq_launch): w = qweight int32 [K / 8, N] (w_stride_bytes
+  // GPTQ weights (bits 4 or 8) for the 129..256-row kernel (tall_gemm_gptq_launch): w = qweight int32 [K * bits / 32, N] (w_stride_bytes
   // unused), k_bytes = 2 K (the bytes of a bf16 row of x)
-  const void* qzeros;     // int32 [K / group_size, N / 8]
+  const void* qzeros;     // int32 [K / group_size, N * bits / 32]
   const void* scales;     // fp16 | bf16 [K / group_size, N]
-  int scales_f16, zero_offset, group_size;
+  int scales_f16, zero_offset, group_size, bits;
 };
 
 struct StreamPlan {
@@ -50,13 +50,13 @@ template <bool I8>
 int stream_gemm_launch(StreamArgs args, const StreamPlan& plan, hipStream_t stream, bool defer_reduce = false);
 
 // The 129..256-row kernel (tall_gemm.hip); stream_gemm_plan / stream_gemm_launch route to these two.
-bool tall_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* plan);
+bool tall_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* plan, int min_rows = 0);      // min_rows 0: 129
 template <bool I8>
 int tall_gemm_launch(const StreamArgs& args, const StreamPlan& plan, hipStream_t stream);
 
 // The fp32 slabs of a sliced launch summed in slice order (+ bias) -> bf16 out (args as the launch had them).
 int stream_gemm_reduce_launch(const StreamArgs& args, hipStream_t stream);
-// The same kernel on 4-bit GPTQ weights (group size 64 or 128): a pair's packed words are expanded into the weight image
+// The same kernel on 4- or 8-bit GPTQ weights (group size 64 or 128): a pair's packed words are expanded into the weight image
 // as bf16(scale * (q - zero)), the values hymeta_gptq_dequant writes; plan with tall_gemm_plan(M, 2 K, N, ...).
 int tall_gemm_gptq_launch(const StreamArgs& args, const StreamPlan& plan, hipStream_t stream, bool defer_reduce);
 

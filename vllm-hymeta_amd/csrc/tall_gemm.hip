@@ -1,5 +1,5 @@
 // Weight-streaming GEMM for 129 to 256 rows: out = x W^T (+ bias), W [N, K] K-contiguous (bf16, or int8 against int8 rows),
-// or 4-bit GPTQ weights (qweight int32 [K / 8, N], group size 64 or 128).
+// or 4- / 8-bit GPTQ weights (qweight int32 [K bits / 32, N], group size 64 or 128; 8-bit from 65 rows on).
 //
 // At these row counts a weight is still read once, but each one now feeds 256 multiply-adds: the matrix cores and the
 // HBM stream are both near their limits (one compute unit's share of HBM, 31 GB/s, is 8 TFLOP/s of its 9.8 at 256
@@ -20,8 +20,8 @@
 //     images pair g - 1 used.  x comes from L2 (one pair of latency), the weights from HBM (two).  Past the end of the
 //     slice the same instructions re-load the last pair into an idle image, so that the count the wait relies on is the
 //     same in every trip.
-//   * 4-bit GPTQ weights (GPTQ = true) do not come by LDS-DMA: a pair of a 160-column tile is 5 KB of packed words, which
-//     the workgroup's threads load (one pair ahead, three words a thread), expand to bf16(scale * (q - zero)) -- the
+//   * GPTQ weights (GQ = their bits) do not come by LDS-DMA: a pair of a 160-column tile is 5 or 10 KB of packed words, which
+//     the workgroup's threads load (one pair ahead, three 8-k pieces a thread), expand to bf16(scale * (q - zero)) -- the
 //     values of the whole-matrix expansion -- and write into one of two weight images behind the barrier, one word per
 //     step; the MFMA loop is the bf16 one.
 //   * the matrix's N / 16 fragments are dealt to the tiles in equal shares (9 or 10 to each of 256 workgroups for the 7B
@@ -76,10 +76,11 @@ constexpr int kWInstr = 3;       // weight instructions per wave and pair: 8 x 3
 // Every wave requests an eighth of each pair's x and weight lines.  The counter a wave waits on counts its requests in
 // the order they were made: per pair it asks for x (one pair ahead of its use, from L2) first and then for the weights
 // (two pairs ahead, from HBM), so that the wait which opens a pair can leave exactly the newest weights in flight.
-template <int MTW, int NFW, bool I8, bool GPTQ = false>
+template <int MTW, int NFW, bool I8, int GQ = 0>
 __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const int tile_f0, const int nf, const int wave_f0,
                                           const int split) {
   typedef typename Acc<I8>::type acc_t;
+  constexpr bool GPTQ = GQ != 0;                // GQ: bits of GPTQ weights (4 or 8), 0: bf16 / int8 weights by LDS-DMA
   constexpr int kRows = 64 * MTW;
   constexpr int kXBuf = kRows * 128;            // one pair of every row
   constexpr int kWSlot = kMaxNf * 2048;         // one pair of the tile's weight rows
@@ -151,38 +152,45 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
   // (item = thread + 512 m: consecutive threads, consecutive columns), expands each into the 16-byte piece of its
   // column's 128-byte line in the weight image -- bf16(scale * (q - zero)), the arithmetic of the whole-matrix expansion
   // -- and asks for the same item of the next pair at once: a word is in flight for one pair.
-  uint32_t qw[kItems], qs[kItems], qz[kItems];
+  constexpr int kWordRows = GQ == 8 ? 16 : 8;      // packed rows of a pair (a word holds 32 / GQ consecutive k of a column)
+  uint32_t qw[kItems][GQ == 8 ? 2 : 1], qs[kItems], qz[kItems];
   const char* qsrc[kItems];
-  int qcol[kItems], qdst[kItems], qrow[kItems];
+  int qcol[kItems], qdst[kItems];
   if constexpr (GPTQ) {
 #pragma unroll
     for (int m = 0; m < kItems; ++m) {
-      const int item = min(tid + kThreads * m, 8 * 16 * nf - 1);      // threads past the last word repeat it
-      const int j = item / (16 * nf), c = item % (16 * nf);
+      const int item = min(tid + kThreads * m, 8 * 16 * nf - 1);      // threads past the last piece repeat it
+      const int j = item / (16 * nf), c = item % (16 * nf);            // piece j (8 k) of the tile's column c
       const int i = c >> 4, r = c & 15;
       qcol[m] = a.gated ? (r < 8 ? 0 : up0) + 8 * (tile_f0 + i) + (r & 7) : 16 * (tile_f0 + i) + r;
-      qrow[m] = j;
-      qsrc[m] = a.w + (static_cast<int64_t>(p_lo) * 8 + j) * a.N * 4 + static_cast<int64_t>(qcol[m]) * 4;
+      qsrc[m] = a.w + (static_cast<int64_t>(p_lo) * kWordRows + j * (kWordRows / 8)) * a.N * 4 + static_cast<int64_t>(qcol[m]) * 4;
       qdst[m] = c * 128 + ((j ^ ((r >> 1) & 7)) * 16);
     }
   }
   auto ask_item = [&](int m, int g) {        // the words, scale and zeros of item m for pair g
     const int pg = min(g, P - 1);
-    qw[m] = *reinterpret_cast<const uint32_t*>(qsrc[m] + static_cast<int64_t>(pg) * 8 * a.N * 4);
+    const char* w0 = qsrc[m] + static_cast<int64_t>(pg) * kWordRows * a.N * 4;
+    qw[m][0] = *reinterpret_cast<const uint32_t*>(w0);
+    if constexpr (GQ == 8) qw[m][1] = *reinterpret_cast<const uint32_t*>(w0 + static_cast<int64_t>(a.N) * 4);
     const int grp = (p_lo + pg) * 64 / a.group_size;
     qs[m] = static_cast<const uint16_t*>(a.scales)[static_cast<int64_t>(grp) * a.N + qcol[m]];
-    qz[m] = static_cast<const uint32_t*>(a.qzeros)[static_cast<int64_t>(grp) * (a.N / 8) + (qcol[m] >> 3)];
+    qz[m] = static_cast<const uint32_t*>(a.qzeros)[static_cast<int64_t>(grp) * (a.N * GQ / 32) + (qcol[m] * GQ / 32)];
   };
   auto expand_item = [&](int m, int g) {     // item m as loaded, into the image of pair g
     const float sc = a.scales_f16 ? static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(qs[m])))
                                   : __uint_as_float(qs[m] << 16);
-    const float zf = static_cast<float>(((qz[m] >> (4 * (qcol[m] & 7))) & 0xFu) + a.zero_offset);
+    constexpr int kPack = GPTQ ? 32 / GQ : 8;
+    const float zf = static_cast<float>(((qz[m] >> (GQ * (qcol[m] & (kPack - 1)))) & ((1u << GQ) - 1u)) + a.zero_offset);
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float lo = sc * (static_cast<float>((qw[m] >> (8 * e)) & 0xFu) - zf);
-      const float hi = sc * (static_cast<float>((qw[m] >> (8 * e + 4)) & 0xFu) - zf);
-      o[e] = pack_bf16x2(lo, hi);
+      uint32_t q0, q1;
+      if constexpr (GQ == 8) {
+        q0 = (qw[m][e >> 1] >> (16 * (e & 1))) & 0xFFu, q1 = (qw[m][e >> 1] >> (16 * (e & 1) + 8)) & 0xFFu;
+      } else {
+        q0 = (qw[m][0] >> (8 * e)) & 0xFu, q1 = (qw[m][0] >> (8 * e + 4)) & 0xFu;
+      }
+      o[e] = pack_bf16x2(sc * (static_cast<float>(q0) - zf), sc * (static_cast<float>(q1) - zf));
     }
     *reinterpret_cast<u32x4*>(wbuf + (g & 1) * kWSlot + qdst[m]) = o;
   };
@@ -375,7 +383,7 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
 
 // A tile holds 8 to 10 fragments (the matrix's fragments dealt in equal shares); waves 0..3 own its first
 // (nf + 1) / 2, waves 4..7 the rest.
-template <int MTW, bool I8, bool GPTQ = false>
+template <int MTW, bool I8, int GQ = 0>
 __global__ __launch_bounds__(kThreads) void tall_gemm_kernel(StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
@@ -386,16 +394,16 @@ __global__ __launch_bounds__(kThreads) void tall_gemm_kernel(StreamArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int first = (nf + 1) / 2;
   const int mine = wave < 4 ? first : nf - first;
-  if (mine == 5) tall_wave<MTW, 5, I8, GPTQ>(a, smem, f_lo, nf, wave < 4 ? 0 : first, split);
-  else tall_wave<MTW, 4, I8, GPTQ>(a, smem, f_lo, nf, wave < 4 ? 0 : first, split);
+  if (mine == 5) tall_wave<MTW, 5, I8, GQ>(a, smem, f_lo, nf, wave < 4 ? 0 : first, split);
+  else tall_wave<MTW, 4, I8, GQ>(a, smem, f_lo, nf, wave < 4 ? 0 : first, split);
 }
 
-template <int MTW, bool I8, bool GPTQ = false>
+template <int MTW, bool I8, int GQ = 0>
 int launch_tall(const StreamArgs& a, hipStream_t s) {
   constexpr size_t img = static_cast<size_t>(64) * (16 * kMaxNf + 4) * 4;
-  constexpr size_t stream = static_cast<size_t>(2) * 64 * MTW * 128 + static_cast<size_t>(GPTQ ? 2 : kWRing) * kMaxNf * 2048;
+  constexpr size_t stream = static_cast<size_t>(2) * 64 * MTW * 128 + static_cast<size_t>(GQ ? 2 : kWRing) * kMaxNf * 2048;
   constexpr size_t lds = img > stream ? img : stream;
-  auto kern = tall_gemm_kernel<MTW, I8, GPTQ>;
+  auto kern = tall_gemm_kernel<MTW, I8, GQ>;
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
@@ -419,8 +427,8 @@ static int tall_min_rows() {
   return v;
 }
 
-bool tall_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* p) {
-  if (M < tall_min_rows() || M > 256 || K_bytes % 128 != 0 || K_bytes < 512 || N % 64 != 0) return false;
+bool tall_gemm_plan(int M, int K_bytes, int N, bool have_workspace, StreamPlan* p, int min_rows) {
+  if (M < (min_rows > 0 ? min_rows : tall_min_rows()) || M > 256 || K_bytes % 128 != 0 || K_bytes < 512 || N % 64 != 0) return false;
   const int frags = N / 16, pairs = K_bytes / 128;
   int tiles, splits = 1;
   if (frags >= 9 * kWant) {
@@ -457,7 +465,10 @@ int tall_gemm_gptq_launch(const StreamArgs& a0, const StreamPlan& p, hipStream_t
   if (!p.tall || a.M <= 0 || a.M > 256 || a.k_bytes % 128 != 0 || a.k_bytes / 128 < p.splits || a.out_f32) return HYMETA_ERR_INVALID_ARG;
   if (a.group_size != 64 && a.group_size != 128) return HYMETA_ERR_UNSUPPORTED;
   if (p.nf < 8 || p.nf > kMaxNf || (a.gated && p.splits != 1)) return HYMETA_ERR_INVALID_ARG;
-  const int rc = a.M <= 192 ? launch_tall<3, false, true>(a, s) : launch_tall<4, false, true>(a, s);
+  int rc;
+  if (a.bits == 4) rc = a.M <= 192 ? launch_tall<3, false, 4>(a, s) : launch_tall<4, false, 4>(a, s);
+  else if (a.bits == 8) rc = a.M <= 128 ? launch_tall<2, false, 8>(a, s) : a.M <= 192 ? launch_tall<3, false, 8>(a, s) : launch_tall<4, false, 8>(a, s);
+  else return HYMETA_ERR_UNSUPPORTED;
   if (rc != HYMETA_OK || a.splits == 1 || defer_reduce) return rc;
   return stream_gemm_reduce_launch(a, s);
 }
