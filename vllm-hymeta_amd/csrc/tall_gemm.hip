@@ -167,14 +167,29 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
       qdst[m] = c * 128 + ((j ^ ((r >> 1) & 7)) * 16);
     }
   }
+  // (offsets as 32-bit element counts from per-item base pointers: a 64-bit multiply per load and a division by the
+  // group size per pair would be a third of the loop's instructions)
+  const int gshift = a.group_size == 128 ? 1 : 0;      // pairs per group = 1 << gshift
+  const int word_step = kWordRows * a.N;               // words from a pair to the next
+  const uint32_t* qbase[kItems];
+  const uint16_t* sbase[kItems];
+  const uint32_t* zbase[kItems];
+  if constexpr (GPTQ) {
+#pragma unroll
+    for (int m = 0; m < kItems; ++m) {
+      qbase[m] = reinterpret_cast<const uint32_t*>(qsrc[m]);
+      sbase[m] = static_cast<const uint16_t*>(a.scales) + qcol[m];
+      zbase[m] = static_cast<const uint32_t*>(a.qzeros) + (qcol[m] * GQ / 32);
+    }
+  }
   auto ask_item = [&](int m, int g) {        // the words, scale and zeros of item m for pair g
     const int pg = min(g, P - 1);
-    const char* w0 = qsrc[m] + static_cast<int64_t>(pg) * kWordRows * a.N * 4;
-    qw[m][0] = *reinterpret_cast<const uint32_t*>(w0);
-    if constexpr (GQ == 8) qw[m][1] = *reinterpret_cast<const uint32_t*>(w0 + static_cast<int64_t>(a.N) * 4);
-    const int grp = (p_lo + pg) * 64 / a.group_size;
-    qs[m] = static_cast<const uint16_t*>(a.scales)[static_cast<int64_t>(grp) * a.N + qcol[m]];
-    qz[m] = static_cast<const uint32_t*>(a.qzeros)[static_cast<int64_t>(grp) * (a.N * GQ / 32) + (qcol[m] * GQ / 32)];
+    const uint32_t* w0 = qbase[m] + static_cast<uint32_t>(pg * word_step);
+    qw[m][0] = w0[0];
+    if constexpr (GQ == 8) qw[m][1] = w0[a.N];
+    const uint32_t grp = static_cast<uint32_t>((p_lo + pg) >> gshift);
+    qs[m] = sbase[m][grp * static_cast<uint32_t>(a.N)];
+    qz[m] = zbase[m][grp * static_cast<uint32_t>(a.N * GQ / 32)];
   };
   auto expand_item = [&](int m, int g) {     // item m as loaded, into the image of pair g
     const float sc = a.scales_f16 ? static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(qs[m])))
@@ -182,13 +197,14 @@ __device__ __forceinline__ void tall_wave(const StreamArgs& a, char* smem, const
     constexpr int kPack = GPTQ ? 32 / GQ : 8;
     const float zf = static_cast<float>(((qz[m] >> (GQ * (qcol[m] & (kPack - 1)))) & ((1u << GQ) - 1u)) + a.zero_offset);
     u32x4 o;
+    const uint32_t lo4 = qw[m][0] & 0x0F0F0F0Fu, hi4 = (qw[m][0] >> 4) & 0x0F0F0F0Fu;      // 4-bit: values 0,2,4,6 and 1,3,5,7 as bytes
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       uint32_t q0, q1;
       if constexpr (GQ == 8) {
         q0 = (qw[m][e >> 1] >> (16 * (e & 1))) & 0xFFu, q1 = (qw[m][e >> 1] >> (16 * (e & 1) + 8)) & 0xFFu;
       } else {
-        q0 = (qw[m][0] >> (8 * e)) & 0xFu, q1 = (qw[m][0] >> (8 * e + 4)) & 0xFu;
+        q0 = (lo4 >> (8 * e)) & 0xFFu, q1 = (hi4 >> (8 * e)) & 0xFFu;      // byte extracts: one conversion instruction each
       }
       o[e] = pack_bf16x2(sc * (static_cast<float>(q0) - zf), sc * (static_cast<float>(q1) - zf));
     }
