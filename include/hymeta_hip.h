@@ -718,7 +718,8 @@ int hymeta_advance_step(int32_t num_seqs, int32_t num_queries, int32_t block_siz
  * in one launch and without the [M, N] intermediate.
  * Replaces MergedColumnParallelLinear + SiluAndMul in the MLP forward
  * (vllm_hymeta/model_for_7B/modeling_gla_swa.py:108-121, vllm_hymeta/models/modeling_hymeta.py:262-271).
- * bias must be NULL, the workspace fields are ignored.  Takes M <= 128, K % 64 == 0, N % 128 == 0;
+ * bias must be NULL, the workspace fields are ignored.  Takes M <= 128, K % 64 == 0, N % 128 == 0, and from 129 to
+ * 256 rows the shapes for which hymeta_bf16_gemm_takes(M, K, N, 1) says so (matrices wide enough for 128 whole tiles);
  * other shapes are HYMETA_ERR_UNSUPPORTED: run the two calls. */
 int hymeta_bf16_gemm_silu_mul(const hymeta_bf16_gemm_args* args, hymeta_stream_t stream);
 
@@ -755,7 +756,8 @@ size_t hymeta_w8a8_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int hymeta_w8a8_gemm(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream);
 
 /* W8A8 form of hymeta_bf16_gemm_silu_mul (same layout, same rule: equals hymeta_w8a8_gemm followed by
- * hymeta_silu_and_mul bit for bit).  bias must be NULL; M <= 128, K % 128 == 0, N % 128 == 0. */
+ * hymeta_silu_and_mul bit for bit).  bias must be NULL; K % 128 == 0, N % 128 == 0; any M (up to 256 rows a
+ * streaming kernel where it covers the shape, the tiled kernel otherwise and above). */
 int hymeta_w8a8_gemm_silu_mul(const hymeta_w8a8_gemm_args* args, hymeta_stream_t stream);
 
 /* ------------------------------------------------------------------------
