@@ -705,7 +705,7 @@ def main():
             return round(timed_steps(r1, args.warmup, args.steps)[1], 4)
 
         line["model_decode"] = {args.quant: {"ms_per_step": line["ms_per_step"], "tokens_per_s": line["value"], "batch1_ms_per_token": b1_main}}
-        # the same step at other batch sizes (up to 128 rows the linears stream their weights once; beyond, library GEMMs)
+        # the same step at other batch sizes (up to 256 rows the linears stream their weights once; beyond, library GEMMs)
         line["decode_by_batch"] = {}
         mb = build_model_7b(dev, args.quant, max_num_seqs=256, gla_state=args.gla_state)
         for bb in (8, 128, 256):
@@ -720,7 +720,7 @@ def main():
         for q in ("bf16", "gptq4", "w8a8"):
             if q == args.quant:
                 continue
-            mq = build_model_7b(dev, q, max_num_seqs=B, gla_state=args.gla_state)
+            mq = build_model_7b(dev, q, max_num_seqs=max(B, 256), gla_state=args.gla_state)
             rq = DecodeRunner(mq, B, args.ctx, total + 8, dev)
             rq.capture()
             el, ms = timed_steps(rq, args.warmup, args.steps)
@@ -728,6 +728,13 @@ def main():
             line["model_decode"][q] = {"ms_per_step": round(ms, 4), "tokens_per_s": round(B / (ms * 1e-3), 1),
                                        "hbm_frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernels": kernel_table(rq, q)}
             del rq
+            torch.cuda.empty_cache()
+            # 256 sequences: the 129..256-row streaming kernels of this weight format
+            r256 = DecodeRunner(mq, 256, args.ctx, total + 8, dev, seed=256)
+            r256.capture()
+            _, ms256 = timed_steps(r256, args.warmup, args.steps)
+            line["model_decode"][q]["batch256"] = {"ms_per_step": round(ms256, 4), "tokens_per_s": round(256 / (ms256 * 1e-3), 1)}
+            del r256
             torch.cuda.empty_cache()
             line["model_decode"][q]["batch1_ms_per_token"] = decode_b1(mq)
             if not args.no_prefill:
