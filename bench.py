@@ -41,7 +41,8 @@ WINDOW = 4096          # 7B attends to W+1 keys: flash window_left = W (hf_7B_mo
 BLOCK = 256
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 GROUP = 128            # GPTQ group size of the synthetic 4-bit checkpoint
-WBYTES = {"bf16": 2.0, "w8a8": 1.0, "gptq4": 0.5}
+WBYTES = {"bf16": 2.0, "w8a8": 1.0, "gptq4": 0.5, "gptq8": 1.0}
+GPTQ_RECIPES = {"gptq4": (4, GROUP), "gptq8": (8, 64)}      # bits, group size (gptq8: hf_7B_model/quant_7B.py:32-36)
 
 
 def parse():
@@ -51,7 +52,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="decode sequences (global batch)")
     ap.add_argument("--ctx", type=int, default=None, help="context length (default: 8192 at N=1, 32768 in the tensor-parallel mode)")
-    ap.add_argument("--quant", choices=("bf16", "gptq4", "w8a8"), default="bf16", help="linears of the timed model")
+    ap.add_argument("--quant", choices=("bf16", "gptq4", "gptq8", "w8a8"), default="bf16", help="linears of the timed model")
     ap.add_argument("--gla-state", choices=("kv_head", "query_head"), default="kv_head",
                     help="GLA state layout: one state per key/value head (the package's default; the 7 query heads "
                          "of a group hold identical states) or one per query head (the reference's cache shape)")
@@ -97,8 +98,9 @@ def config_7b(vocab=VOCAB):
 
 def synthetic_checkpoint_7b(cfg, dev, quant, seed=0):
     """(name, tensor) pairs of a random-init checkpoint under the published names, generated on the device one
-    tensor at a time.  ``quant``: "bf16"; "gptq4" (gptqmodel tensors: qweight / qzeros / scales / g_idx, 4 bit,
-    group 128, the rank-16 gate projection left in bf16 as hf_7B_model/gla_swa_gptq.py:18-24 leaves it); "w8a8"
+    tensor at a time.  ``quant``: "bf16"; "gptq4" / "gptq8" (gptqmodel tensors: qweight / qzeros / scales / g_idx; 4 bit
+    group 128, or the 8 bit group 64 of hf_7B_model/quant_7B.py:32-36; the rank-16 gate projection left in bf16 as
+    hf_7B_model/gla_swa_gptq.py:18-24 leaves it); "w8a8"
     (compressed-tensors int8 weight + per-channel weight_scale, hf_model/quant_w8a8.py:121-124)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -117,10 +119,12 @@ def synthetic_checkpoint_7b(cfg, dev, quant, seed=0):
             yield prefix + ".weight", torch.randint(-127, 128, (out_f, in_f), dtype=torch.int8, device=dev, generator=g)
             yield prefix + ".weight_scale", (torch.rand(out_f, 1, device=dev, generator=g) * (2.0 / 127) * in_f ** -0.5).float()
         else:
-            yield prefix + ".qweight", torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // 8, out_f), dtype=torch.int32, device=dev, generator=g)
-            yield prefix + ".qzeros", torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // GROUP, out_f // 8), dtype=torch.int32, device=dev, generator=g)
-            yield prefix + ".scales", (torch.rand(in_f // GROUP, out_f, device=dev, generator=g) * (0.25 * in_f ** -0.5)).to(torch.float16)
-            yield prefix + ".g_idx", (torch.arange(in_f, dtype=torch.int32, device=dev) // GROUP)
+            bits, group = GPTQ_RECIPES[quant]
+            pack = 32 // bits
+            yield prefix + ".qweight", torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // pack, out_f), dtype=torch.int32, device=dev, generator=g)
+            yield prefix + ".qzeros", torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // group, out_f // pack), dtype=torch.int32, device=dev, generator=g)
+            yield prefix + ".scales", (torch.rand(in_f // group, out_f, device=dev, generator=g) * (4.0 / 2 ** bits * in_f ** -0.5)).to(torch.float16)
+            yield prefix + ".g_idx", (torch.arange(in_f, dtype=torch.int32, device=dev) // group)
 
     yield "model.embeddings.weight", rnd(cfg.vocab_size, hidden, scale=0.5)
     yield "model.norm.weight", torch.ones(hidden, dtype=torch.bfloat16, device=dev)
@@ -146,7 +150,7 @@ def build_model_7b(dev, quant, max_num_seqs, gla_state="kv_head", tp_group=None)
     from vllm_hymeta.model_for_7B.modeling_gla_swa import GLAswaForCausalLM
 
     cfg = config_7b()
-    q = {"bits": 4, "group_size": GROUP, "zero_offset": 1} if quant == "gptq4" else None
+    q = {"bits": GPTQ_RECIPES[quant][0], "group_size": GPTQ_RECIPES[quant][1], "zero_offset": 1} if quant in GPTQ_RECIPES else None
     model = GLAswaForCausalLM(cfg, max_num_seqs=max_num_seqs, quant=q, tp_group=tp_group, device=dev,
                               state_per_kv_head=gla_state == "kv_head")
     model.load_weights(synthetic_checkpoint_7b(cfg, dev, quant))
@@ -717,7 +721,7 @@ def main():
             torch.cuda.empty_cache()
         del mb
         torch.cuda.empty_cache()
-        for q in ("bf16", "gptq4", "w8a8"):
+        for q in ("bf16", "gptq4", "gptq8", "w8a8"):
             if q == args.quant:
                 continue
             mq = build_model_7b(dev, q, max_num_seqs=max(B, 256), gla_state=args.gla_state)

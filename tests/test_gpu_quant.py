@@ -134,34 +134,36 @@ def test_gptq_transposed_expansion_covers_whole_tiles_only():
     assert_bf16_close(out.cpu(), gptq_gemm_ref(x, qw, qz, scales, 4, 128, None), "gptq [K, N] expansion", rel=8e-3)
 
 
-@pytest.mark.parametrize("scales_dtype,zero_offset", [(torch.float16, 1), (torch.bfloat16, 0)])
+@pytest.mark.parametrize("bits,group,scales_dtype,zero_offset", [(4, 128, torch.float16, 1), (4, 128, torch.bfloat16, 0),
+                                                                 (8, 64, torch.float16, 1), (8, 64, torch.bfloat16, 0)])
 @pytest.mark.parametrize("M,K,N,bias", [(64, 3584, 4608, True), (33, 18944, 3584, False), (1, 3584, 3584, False), (16, 256, 128, True),
-                                        (20, 1024, 640, False)])
-def test_gptq4_streaming_kernel_and_deferred_slice_sum(M, K, N, bias, scales_dtype, zero_offset):
-    """Group-128 4-bit linears with few columns (qkv / o / down shapes; one tile; five 32-column blocks per tile) run on
-    the weight-streaming kernel: against the fp64 restatement, deterministic, and with the K slices' sum left to the fused
-    add + RMS norm the same bits as the plain call followed by the norm."""
+                                        (20, 1024, 640, False), (24, 3584, 37888, False)])
+def test_gptq_streaming_kernel_and_deferred_slice_sum(M, K, N, bias, bits, group, scales_dtype, zero_offset):
+    """Group-128 4-bit and group-64 8-bit linears (the two recipes of the reference) with few columns (qkv / o / down shapes;
+    one tile; five 32-column blocks per tile) or few rows (gate_up) run on the weight-streaming kernel: against the fp64
+    restatement, deterministic, and with the K slices' sum left to the fused add + RMS norm the same bits as the plain call
+    followed by the norm."""
     from oracle.quant import gptq_gemm_ref
     from vllm_hymeta import hip_ops
     from vllm_hymeta.linear import HymetaLinear
 
-    qw, qz, scales = _gptq_problem(M + K + N, K, N, 4, 128, scales_dtype)
+    qw, qz, scales = _gptq_problem(M + K + N, K, N, bits, group, scales_dtype)
     g_ = gen(M + N)
     x = randn_bf16(g_, M, K)
     b = randn_bf16(g_, N) if bias else None
-    ref = gptq_gemm_ref(x, qw, qz, scales, 4, 128, b, zero_offset=zero_offset)
-    lin = HymetaLinear.from_gptq(qw.cuda(), qz.cuda(), scales.cuda(), 4, 128, bias=None if b is None else b.cuda(), zero_offset=zero_offset)
+    ref = gptq_gemm_ref(x, qw, qz, scales, bits, group, b, zero_offset=zero_offset)
+    lin = HymetaLinear.from_gptq(qw.cuda(), qz.cuda(), scales.cuda(), bits, group, bias=None if b is None else b.cuda(), zero_offset=zero_offset)
     xd = x.cuda()
     y, again = lin(xd), lin(xd)
     torch.cuda.synchronize()
-    assert_bf16_close(y.cpu(), ref, f"gptq4 streaming M={M} K={K} N={N}", rel=8e-3)
+    assert_bf16_close(y.cpu(), ref, f"gptq{bits} streaming M={M} K={K} N={N}", rel=8e-3)
     assert torch.equal(y, again)
     part = lin(xd, defer=True)
     w = (1 + 0.1 * torch.randn(N, generator=g_)).to(torch.bfloat16).cuda()
     res = randn_bf16(g_, M, N).cuda()
     r1, r2 = res.clone(), res.clone()
     out1 = hip_ops.add_rmsnorm(y, w, 1e-6, residual=r1)
-    if K >= 1024:
+    if K >= 1024 and N < 16384:
         assert isinstance(part, hip_ops.PartialSums), "cut into K slices"
     out2 = hip_ops.add_rmsnorm(part, w, 1e-6, residual=r2)
     torch.cuda.synchronize()

@@ -60,12 +60,13 @@ int stream_gemm_reduce_launch(const StreamArgs& args, hipStream_t stream);
 // as bf16(scale * (q - zero)), the values hymeta_gptq_dequant writes; plan with tall_gemm_plan(M, 2 K, N, ...).
 int tall_gemm_gptq_launch(const StreamArgs& args, const StreamPlan& plan, hipStream_t stream, bool defer_reduce);
 
-// ---- the 4-bit GPTQ form (stream_gptq.hip): group size 128, K a multiple of 256, N of 128 ----
+// ---- the GPTQ form (stream_gptq.hip): 4-bit with group size 128 (K a multiple of 256) or 8-bit with group size 64
+// (K a multiple of 128); N a multiple of 128 ----
 struct StreamGptqArgs {
   const char* x;            // bf16 [M, K], x_stride_bytes per row
-  const void* qweight;      // int32 [K / 8, N]
-  const void* qzeros;       // int32 [K / 128, N / 8]
-  const void* scales;       // fp16 | bf16 [K / 128, N]
+  const void* qweight;      // int32 [K bits / 32, N]
+  const void* qzeros;       // int32 [K / group, N bits / 32]
+  const void* scales;       // fp16 | bf16 [K / group, N]
   const uint16_t* bias;     // bf16 [N] or null
   uint16_t* out;            // bf16 [M, N]
   char* slabs;              // [splits][M][N] fp32 partial sums (splits > 1)
@@ -77,8 +78,9 @@ struct StreamGptqArgs {
 
 struct StreamGptqPlan {
   int np;               // 32-column blocks of the widest wave (1 or 2)
-  int tiles, chunks;    // chunks: 256-k pieces of K
+  int tiles, chunks;    // chunks: pieces of K of 32 packed rows (256 k for 4-bit, 128 k for 8-bit weights)
   int splits;
+  int bits;             // 4 (group size 128) or 8 (group size 64)
 };
 
 bool stream_gptq_plan(int M, int K, int N, int bits, int group_size, bool have_workspace, StreamGptqPlan* plan);
