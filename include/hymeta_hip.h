@@ -588,6 +588,10 @@ int hymeta_lowrank_gate(const hymeta_lowrank_gate_args* args, hymeta_stream_t st
  * hymeta_gptq_gemm_workspace_bytes(M, N, 0), is a bound that holds for every K.  Without a
  * workspace the library runs unsplit.  split_k > 1 forces that many slices and needs
  * hymeta_gptq_gemm_workspace_bytes(M, N, split_k) bytes.
+ * Up to 64 rows with split_k <= 0, 4-bit weights of group size 128 or 64 (K % 256 == 0) and 8-bit weights of group size
+ * 64 (K % 128 == 0) with N % 128 == 0 run on a weight-streaming kernel (one workgroup per compute unit, x shared through
+ * LDS, q kept exact in bf16, scale and zero applied to each group's fp32 partial sums); the widest matrices and other
+ * formats on the tiled kernels with the same arithmetic.
  * From 129 to 256 rows (8-bit: from 65; group size 64 or 128, split_k <= 0) the 129..256-row streaming kernel runs instead,
  * on the shapes it cuts into at least 128 workgroups: it reads the packed weights ONCE for all rows and expands each
  * word to bf16(scale * (q - zero)) -- the values hymeta_gptq_dequant writes -- on its way into LDS, so its result

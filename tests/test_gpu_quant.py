@@ -135,11 +135,12 @@ def test_gptq_transposed_expansion_covers_whole_tiles_only():
 
 
 @pytest.mark.parametrize("bits,group,scales_dtype,zero_offset", [(4, 128, torch.float16, 1), (4, 128, torch.bfloat16, 0),
-                                                                 (8, 64, torch.float16, 1), (8, 64, torch.bfloat16, 0)])
+                                                                 (8, 64, torch.float16, 1), (8, 64, torch.bfloat16, 0),
+                                                                 (4, 64, torch.float16, 1)])
 @pytest.mark.parametrize("M,K,N,bias", [(64, 3584, 4608, True), (33, 18944, 3584, False), (1, 3584, 3584, False), (16, 256, 128, True),
                                         (20, 1024, 640, False), (24, 3584, 37888, False)])
 def test_gptq_streaming_kernel_and_deferred_slice_sum(M, K, N, bias, bits, group, scales_dtype, zero_offset):
-    """Group-128 4-bit and group-64 8-bit linears (the two recipes of the reference) with few columns (qkv / o / down shapes;
+    """Group-128 4-bit and group-64 8-bit linears (the two recipes of the reference; 4-bit at group 64 as well) with few columns (qkv / o / down shapes;
     one tile; five 32-column blocks per tile) or few rows (gate_up) run on the weight-streaming kernel: against the fp64
     restatement, deterministic, and with the K slices' sum left to the fused add + RMS norm the same bits as the plain call
     followed by the norm."""

@@ -60,7 +60,7 @@ int stream_gemm_reduce_launch(const StreamArgs& args, hipStream_t stream);
 // as bf16(scale * (q - zero)), the values hymeta_gptq_dequant writes; plan with tall_gemm_plan(M, 2 K, N, ...).
 int tall_gemm_gptq_launch(const StreamArgs& args, const StreamPlan& plan, hipStream_t stream, bool defer_reduce);
 
-// ---- the GPTQ form (stream_gptq.hip): 4-bit with group size 128 (K a multiple of 256) or 8-bit with group size 64
+// ---- the GPTQ form (stream_gptq.hip): 4-bit with group size 128 or 64 (K a multiple of 256) or 8-bit with group size 64
 // (K a multiple of 128); N a multiple of 128 ----
 struct StreamGptqArgs {
   const char* x;            // bf16 [M, K], x_stride_bytes per row
@@ -80,7 +80,8 @@ struct StreamGptqPlan {
   int np;               // 32-column blocks of the widest wave (1 or 2)
   int tiles, chunks;    // chunks: pieces of K of 32 packed rows (256 k for 4-bit, 128 k for 8-bit weights)
   int splits;
-  int bits;             // 4 (group size 128) or 8 (group size 64)
+  int bits;             // 4 (group size 128 or 64) or 8 (group size 64)
+  int group_units;      // units of 8 packed rows in a group: 2, or 1 for 4-bit weights of group size 64
 };
 
 bool stream_gptq_plan(int M, int K, int N, int bits, int group_size, bool have_workspace, StreamGptqPlan* plan);

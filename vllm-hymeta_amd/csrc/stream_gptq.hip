@@ -1,6 +1,6 @@
 // Weight-streaming GEMM for 4-bit GPTQ linears at decode-sized batches (up to 64 rows): out = x dequant(W) (+ bias),
-// qweight int32 [K / 8, N] (a word = 8 consecutive k of ONE output column), qzeros int32 [K / 128, N / 8], scales
-// fp16 | bf16 [K / 128, N], group size 128 -- and for 8-bit ones of group size 64 (qweight [K / 4, N], a word = 4 k;
+// qweight int32 [K / 8, N] (a word = 8 consecutive k of ONE output column), qzeros int32 [K / G, N / 8], scales
+// fp16 | bf16 [K / G, N], group size G = 128 or 64 -- and for 8-bit ones of group size 64 (qweight [K / 4, N], a word = 4 k;
 // the 7B recipe of the reference, hf_7B_model/quant_7B.py:32-36), described at the end of this comment.
 //
 // Built like the bf16 streaming kernel (stream_gemm.hip): a workgroup owns a tile of columns and a K slice, x is staged
@@ -14,7 +14,8 @@
 //     k-slots of column n (rows two apart in parity sit in opposite halves of the banks);
 //   * (w >> 4 j) & 0x000F000F | 0x43004300 makes the bf16 pair (128 + q_j, 128 + q_{j+4}) in one instruction, 4 per
 //     word; the k order this induces inside a word, (0,4,1,5,2,6,3,7), is given to x when it is staged;
-//   * scale and zero are applied once per group to the group's partial sums, outside the MFMA chain:
+//   * scale and zero are applied once per group (of 128 k: once per chunk and wave; of 64 k: twice) to the group's
+//     partial sums, outside the MFMA chain:
 //       sum_k x w = s * ( sum_k x (128 + q)  -  (128 + z) * sum_k x ),
 //     with sum_k x from one extra MFMA per k-step against an all-ones fragment (it lands in the accumulator layout).
 // Tiles and waves are dealt the matrix's 32-column blocks in equal shares (a wave owns 1 or 2); narrow matrices are
@@ -50,7 +51,7 @@ __device__ __forceinline__ float scale_at(const void* p, int64_t idx, bool f16) 
 // One wave's part of a tile: NP blocks of 32 columns from block ``wave_b0`` on; the tile is blocks [tile_b0, tile_b0 +
 // tile_nb).  MT: the wave's 16-row fragments; NPT: the widest wave of the launch (sizes the shared images).
 // Waves w and w + 4 own the same columns and split K: one group of every chunk each, over all 16 MT rows.
-template <int MT, int NP, int NPT, int BITS>
+template <int MT, int NP, int NPT, int BITS, int GU>
 __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, const int wave_b0, const int tile_b0,
                                           const int tile_nb, const int split) {
   // How far ahead the wave asks for things.  Deeper rings (4 chunks) with x and the scales two chunks ahead were measured
@@ -58,8 +59,7 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
   // wide ones, not by the time a load is in flight.
   constexpr int R = 4;                           // ring of the wave's weight units per block of columns: two chunks ahead
   constexpr int kAheadX = 1;                     // chunks of x held in registers ahead of the shared image
-  constexpr int kAheadS = 1;                     // groups the scales and zeros are loaded ahead
-  constexpr int kSets = 2 * kAheadS;             // their register sets
+  constexpr int GH = 2 / GU;                     // groups of a chunk this wave takes (GU = units of a group: 1 or 2)
   constexpr int kUnroll = 2;                     // chunks per trip of the main loop: every index above is static inside
   constexpr int kThreads = 512;
   constexpr int kChunkBytes = BITS == 4 ? 512 : 256;      // bytes of one x row per staged chunk (32 packed rows: 256 or 128 k)
@@ -138,24 +138,27 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
   // scales and zeros of the lane's column in each fragment, one group ahead
   const bool f16 = a.scales_f16 != 0;
   const int groups_n8 = a.N * BITS / 32;          // words of a row of qzeros
-  // register sets used in rotation (the wave's group index modulo kSets is static in the unrolled chunk loop): a set is
-  // loaded kAheadS groups before its own and first read at the end of its own -- no copy, no early wait
+  // two register sets, one per chunk parity (static in the unrolled chunk loop): a set is loaded a chunk before its
+  // own and first read at the end of a group of its own -- no copy, no early wait
   // (kept as loaded -- a 16-bit scale, the packed word of zeros -- and converted where they are used: a conversion next
   // to the load would make the wave wait for it, and for every weight load before it, on the spot)
-  uint32_t sc[kSets][NF], zc[kSets][NF];
-  auto load_group = [&](int gi, uint32_t (&s_)[NF], uint32_t (&z_)[NF]) {      // gi: the wave's own group count from c_lo
-    const int gg = min(2 * (c_lo + gi) + half, a.chunks * 2 - 1);
+  uint32_t sc[2][GH][NF], zc[2][GH][NF];
+  auto load_groups = [&](int ci, uint32_t (&s_)[GH][NF], uint32_t (&z_)[GH][NF]) {      // ci: chunk, counted from c_lo
+    const int cg = min(c_lo + ci, a.chunks - 1);
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      const int col = (wave_b0 + (f >> 1)) * 32 + 16 * (f & 1) + n;
-      s_[f] = static_cast<const uint16_t*>(a.scales)[static_cast<int64_t>(gg) * a.N + col];
-      z_[f] = static_cast<const uint32_t*>(a.qzeros)[static_cast<int64_t>(gg) * groups_n8 + (col * BITS / 32)];
+    for (int u = 0; u < GH; ++u) {
+      const int gg = (2 * cg + half) * GH + u;          // the chunk's groups in k order: half 0's, then half 1's
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int col = (wave_b0 + (f >> 1)) * 32 + 16 * (f & 1) + n;
+        s_[u][f] = static_cast<const uint16_t*>(a.scales)[static_cast<int64_t>(gg) * a.N + col];
+        z_[u][f] = static_cast<const uint32_t*>(a.qzeros)[static_cast<int64_t>(gg) * groups_n8 + (col * BITS / 32)];
+      }
     }
   };
   const int zshift = BITS * (n & (32 / BITS - 1));      // the lane's column inside a packed word of zeros (16 f + n: same for every f)
   const float zbase = static_cast<float>((BITS == 4 ? 128 : 0) + a.zero_offset);
-#pragma unroll
-  for (int g = 0; g < kAheadS; ++g) load_group(g, sc[g], zc[g]);
+  load_groups(0, sc[0], zc[0]);
 
   f32x4 acc[MT][NF];
 #pragma unroll
@@ -199,8 +202,8 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
       const char* cur = smem + ((c - c_lo) & 1) * kBufBytes;
       stage_load(cc % kAheadX, c + kAheadX);
       {
-        const int gb = cc % kSets;                     // the group's set of scale / zero registers
-        load_group(c - c_lo + kAheadS, sc[(gb + kAheadS) % kSets], zc[(gb + kAheadS) % kSets]);
+        const int gb = cc % 2;                         // the chunk's set of scale / zero registers
+        load_groups(c - c_lo + 1, sc[gb ^ 1], zc[gb ^ 1]);
         __builtin_amdgcn_sched_barrier(0);
         const int unit0 = (c - c_lo) * 2;
         // the group's two units (64 k each) of every block go to the wave's images, and their ring slots are refilled
@@ -215,13 +218,18 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
 #pragma unroll
         for (int uu = 0; uu < 2; ++uu) issue((2 * cc + uu) % R, unit0 + uu + R);
         __builtin_amdgcn_sched_barrier(0);
-        // one block of 32 columns at a time (its partial sums are the only ones live); the rows' sums of x come with the first
+        // one group, and in it one block of 32 columns, at a time (its partial sums are the only ones live); the rows' sums
+        // of x over the group come with the first block
+#pragma unroll
+        for (int u = 0; u < GH; ++u) {
         f32x4 sx[MT];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
           f32x4 gacc[MT][2];
+          constexpr int kGroupSteps = GU * kStepsPerUnit;
 #pragma unroll
-          for (int ks = 0; ks < 2 * kStepsPerUnit; ++ks) {      // the group's k-steps; 4-bit: unit ks / 2, half ks % 2 of it; 8-bit: unit ks
+          for (int kg = 0; kg < kGroupSteps; ++kg) {      // the group's k-steps; 4-bit: unit ks / 2, half ks % 2 of it; 8-bit: unit ks
+            const int ks = u * kGroupSteps + kg;
             const int uu = ks / kStepsPerUnit, s = ks % kStepsPerUnit;
             const char* region = wimg + uu * (NPT * 1024) + i * 1024;
             u32x4 af[MT];
@@ -231,7 +239,7 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
             for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(cur + aoff[mt] + poff);
             if (i == 0) {
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) sx[mt] = mma_bf16(af[mt], ones, ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sx[mt]);
+              for (int mt = 0; mt < MT; ++mt) sx[mt] = mma_bf16(af[mt], ones, kg == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sx[mt]);
             }
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
@@ -249,20 +257,21 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
                 }
               }
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) gacc[mt][f] = mma_bf16(af[mt], b, ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : gacc[mt][f]);
+              for (int mt = 0; mt < MT; ++mt) gacc[mt][f] = mma_bf16(af[mt], b, kg == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : gacc[mt][f]);
             }
           }
           // the group's scale and zero, applied to its partial sums
 #pragma unroll
           for (int f2 = 0; f2 < 2; ++f2) {
             const int f = 2 * i + f2;
-            const float s_ = f16 ? static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(sc[gb][f]))) : __uint_as_float(sc[gb][f] << 16);
-            const float z_ = zbase + static_cast<float>((zc[gb][f] >> zshift) & ((1u << BITS) - 1u));
+            const float s_ = f16 ? static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(sc[gb][u][f]))) : __uint_as_float(sc[gb][u][f] << 16);
+            const float z_ = zbase + static_cast<float>((zc[gb][u][f] >> zshift) & ((1u << BITS) - 1u));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
               for (int r = 0; r < 4; ++r) acc[mt][f][r] = fmaf(s_, fmaf(-z_, sx[mt][r], gacc[mt][f2][r]), acc[mt][f][r]);
           }
+        }
         }
       }
       stage_store((cc + 1) % kAheadX, smem + (((c - c_lo) & 1) ^ 1) * kBufBytes);
@@ -302,7 +311,7 @@ __device__ __forceinline__ void gptq_wave(const StreamGptqArgs& a, char* smem, c
   }
 }
 
-template <int MT, int NPHI, int BITS>
+template <int MT, int NPHI, int BITS, int GU>
 __global__ __launch_bounds__(512, 1) void stream_gptq_kernel(StreamGptqArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
@@ -313,9 +322,9 @@ __global__ __launch_bounds__(512, 1) void stream_gptq_kernel(StreamGptqArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;      // waves w and w + 4 share their columns
   const int w_lo = b_lo + wave * c / 4, w_hi = b_lo + (wave + 1) * c / 4;
   if (w_hi - w_lo == NPHI) {
-    gptq_wave<MT, NPHI, NPHI, BITS>(a, smem, w_lo, b_lo, c, split);
+    gptq_wave<MT, NPHI, NPHI, BITS, GU>(a, smem, w_lo, b_lo, c, split);
   } else if constexpr (NPHI > 1) {
-    gptq_wave<MT, NPHI - 1, NPHI, BITS>(a, smem, w_lo, b_lo, c, split);
+    gptq_wave<MT, NPHI - 1, NPHI, BITS, GU>(a, smem, w_lo, b_lo, c, split);
   }
 }
 
@@ -343,13 +352,13 @@ __global__ __launch_bounds__(256) void stream_gptq_reduce_kernel(StreamGptqArgs 
   *reinterpret_cast<u32x2*>(a.out + static_cast<int64_t>(row) * a.out_stride + col) = o;
 }
 
-template <int MT, int NP, int BITS>
+template <int MT, int NP, int BITS, int GU>
 int launch_gptq(const StreamGptqArgs& a, hipStream_t s, bool defer_reduce) {
   constexpr int rows = 16 * MT;
   constexpr size_t img = 2u * static_cast<size_t>(rows) * (128 * NP + 4) * 4;     // K split: one image per half
   constexpr size_t stream = 2u * rows * (BITS == 4 ? 512 : 256) + 8u * 2 * NP * 1024;
   constexpr size_t lds = img > stream ? img : stream;
-  auto kern = stream_gptq_kernel<MT, NP, BITS>;
+  auto kern = stream_gptq_kernel<MT, NP, BITS, GU>;
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
@@ -368,8 +377,8 @@ int launch_gptq(const StreamGptqArgs& a, hipStream_t s, bool defer_reduce) {
 }  // namespace
 
 bool stream_gptq_plan(int M, int K, int N, int bits, int group_size, bool have_workspace, StreamGptqPlan* p) {
-  // 4-bit group 128 (chunks of 256 k), or 8-bit group 64 (chunks of 128 k): 32 packed rows a chunk either way
-  const bool four = bits == 4 && group_size == 128, eight = bits == 8 && group_size == 64;
+  // 4-bit group 128 or 64 (chunks of 256 k), or 8-bit group 64 (chunks of 128 k): 32 packed rows a chunk either way
+  const bool four = bits == 4 && (group_size == 128 || group_size == 64), eight = bits == 8 && group_size == 64;
   if ((!four && !eight) || M <= 0 || M > 64 || K % (four ? 256 : 128) != 0 || N % 128 != 0) return false;
   static const int want_forced = [] { const char* e = getenv("HYMETA_GPTQ_STREAM_WGS"); return e ? atoi(e) : 0; }();
   static const int splits_forced = [] { const char* e = getenv("HYMETA_GPTQ_STREAM_SPLITS"); return e ? atoi(e) : 0; }();
@@ -384,7 +393,8 @@ bool stream_gptq_plan(int M, int K, int N, int bits, int group_size, bool have_w
   // 296 tiles, with 1 to 4 K slices: 61 to 72 us on the 7B gate_up matrix against 60 on the older kernel.)
   static const int wide_mode = [] { const char* e = getenv("HYMETA_GPTQ_STREAM_WIDE"); return e == nullptr ? 1 : atoi(e); }();
   const bool wide = blocks / 4 >= want;
-  if (wide && (wide_mode == 0 || M > 32 || (M <= 16 && wide_mode != 2))) return false;
+  // (4-bit weights of group size 64 at 17 to 32 rows: 35.1 against 32.5 us on the older kernel, which keeps them)
+  if (wide && (wide_mode == 0 || M > 32 || (M <= 16 && wide_mode != 2) || (four && group_size == 64 && wide_mode != 2))) return false;
   int tiles = blocks / 4 < want ? blocks / 4 : want;
   if (tiles < (blocks + 7) / 8) tiles = (blocks + 7) / 8;
   const int np = ((blocks + tiles - 1) / tiles + 3) / 4;
@@ -394,7 +404,7 @@ bool stream_gptq_plan(int M, int K, int N, int bits, int group_size, bool have_w
   if (splits > chunks) splits = chunks;
   if (splits > kMaxSplits) splits = kMaxSplits;
   if (splits < 1) splits = 1;
-  p->np = np, p->tiles = tiles, p->chunks = chunks, p->splits = splits, p->bits = bits;
+  p->np = np, p->tiles = tiles, p->chunks = chunks, p->splits = splits, p->bits = bits, p->group_units = group_size * bits / 256;
   return np == 1 || (np == 2 && M <= 32);
 }
 
@@ -409,7 +419,8 @@ int stream_gptq_launch(StreamGptqArgs a, const StreamGptqPlan& p, hipStream_t s,
   const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
 #define HYMETA_GPTQ_CASE(MT_, NP_)                                                             \
   if (mt == MT_ && p.np == NP_)                                                                \
-    return p.bits == 8 ? launch_gptq<MT_, NP_, 8>(a, s, defer_reduce) : launch_gptq<MT_, NP_, 4>(a, s, defer_reduce);
+    return p.bits == 8 ? launch_gptq<MT_, NP_, 8, 2>(a, s, defer_reduce)                      \
+                       : (p.group_units == 1 ? launch_gptq<MT_, NP_, 4, 1>(a, s, defer_reduce) : launch_gptq<MT_, NP_, 4, 2>(a, s, defer_reduce));
   HYMETA_GPTQ_CASE(1, 1) HYMETA_GPTQ_CASE(1, 2) HYMETA_GPTQ_CASE(2, 1) HYMETA_GPTQ_CASE(2, 2) HYMETA_GPTQ_CASE(4, 1)
 #undef HYMETA_GPTQ_CASE
   return HYMETA_ERR_UNSUPPORTED;
