@@ -12,16 +12,25 @@ H, HKV, D = 28, 4, 128
 
 
 def bench(fn, iters=40):
+    """Mean time of one call inside a replayed graph of ``iters`` calls (the host's launch cost stays outside)."""
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
+    if os.environ.get("EAGER") == "1":       # a counter pass: plain launches, no timing
+        return float("nan")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(iters):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(3):
+        graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    return e0.elapsed_time(e1) / (3 * iters) * 1e3
 
 
 def main():

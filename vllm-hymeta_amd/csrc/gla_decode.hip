@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 // so out is bit-identical to REP per-query-head units.
 // NT: the state rows are read with the non-temporal hint (256 sequences x 4 groups: 23.7 -> 21.3-22.2 us;
 // at 64 sequences it is level to slightly behind, so small launches keep plain loads).
-template <int REP, int NSPLIT, bool STATE_F32, int THREADS, bool NT>
+// GATE_X: the first linear of the low-rank gate runs in this kernel (a.g_w0); a variant of its own because its 32 weight
+// loads in flight hold 128 registers and would halve the workgroups a compute unit holds for every other caller.
+template <int REP, int NSPLIT, bool STATE_F32, int THREADS, bool NT, bool GATE_X>
 __global__ __launch_bounds__(THREADS) void gla_decode_group_kernel(hymeta_gla_decode_args a, GateParams gp) {
   constexpr int D = kHeadDim;
   constexpr int COLS = D / NSPLIT;
@@ -318,8 +320,8 @@ __global__ __launch_bounds__(THREADS) void gla_decode_group_kernel(hymeta_gla_de
   }
 
   // both linears of the low-rank gate here: g is the layer's input row, the first linear's 16 values land in s_t
-  const bool gate_from_x = a.g_w0 != nullptr;
-  if (gate_from_x)
+  constexpr bool gate_from_x = GATE_X;
+  if constexpr (GATE_X)
     lowrank_first_linear(reinterpret_cast<const uint16_t*>(a.g) + b * a.g_stride_b, reinterpret_cast<const uint16_t*>(a.g_w0), a.g_hidden,
                          reinterpret_cast<float(*)[16]>(&s_red[0][0][0]), s_t);
 
@@ -497,20 +499,26 @@ using namespace hymeta;
 
 namespace {
 
-template <int REP>
-void launch_group(const hymeta_gla_decode_args& a, const GateParams& gp, bool split2, bool f32, hipStream_t s) {
+template <int REP, bool GATE_X>
+void launch_group_variant(const hymeta_gla_decode_args& a, const GateParams& gp, bool split2, bool f32, hipStream_t s) {
   const int64_t groups = static_cast<int64_t>(a.batch) * a.num_kv_heads;
   dim3 grid(static_cast<unsigned>(groups), split2 ? 2 : 1);
   if (split2) {
-    if (f32) hipLaunchKernelGGL((gla_decode_group_kernel<REP, 2, true, 256, false>), grid, dim3(256), 0, s, a, gp);
-    else hipLaunchKernelGGL((gla_decode_group_kernel<REP, 2, false, 256, false>), grid, dim3(256), 0, s, a, gp);
+    if (f32) hipLaunchKernelGGL((gla_decode_group_kernel<REP, 2, true, 256, false, GATE_X>), grid, dim3(256), 0, s, a, gp);
+    else hipLaunchKernelGGL((gla_decode_group_kernel<REP, 2, false, 256, false, GATE_X>), grid, dim3(256), 0, s, a, gp);
   } else if (groups > 512) {   // more than two workgroups per compute unit: the launch is bandwidth-bound
-    if (f32) hipLaunchKernelGGL((gla_decode_group_kernel<REP, 1, true, 256, true>), grid, dim3(256), 0, s, a, gp);
-    else hipLaunchKernelGGL((gla_decode_group_kernel<REP, 1, false, 256, true>), grid, dim3(256), 0, s, a, gp);
+    if (f32) hipLaunchKernelGGL((gla_decode_group_kernel<REP, 1, true, 256, true, GATE_X>), grid, dim3(256), 0, s, a, gp);
+    else hipLaunchKernelGGL((gla_decode_group_kernel<REP, 1, false, 256, true, GATE_X>), grid, dim3(256), 0, s, a, gp);
   } else {   // (512-thread workgroups measured level with 256 at 64 sequences: 9.1 against 9.35 us)
-    if (f32) hipLaunchKernelGGL((gla_decode_group_kernel<REP, 1, true, 256, false>), grid, dim3(256), 0, s, a, gp);
-    else hipLaunchKernelGGL((gla_decode_group_kernel<REP, 1, false, 256, false>), grid, dim3(256), 0, s, a, gp);
+    if (f32) hipLaunchKernelGGL((gla_decode_group_kernel<REP, 1, true, 256, false, GATE_X>), grid, dim3(256), 0, s, a, gp);
+    else hipLaunchKernelGGL((gla_decode_group_kernel<REP, 1, false, 256, false, GATE_X>), grid, dim3(256), 0, s, a, gp);
   }
+}
+
+template <int REP>
+void launch_group(const hymeta_gla_decode_args& a, const GateParams& gp, bool split2, bool f32, hipStream_t s) {
+  if (a.g_w0 != nullptr) launch_group_variant<REP, true>(a, gp, split2, f32, s);
+  else launch_group_variant<REP, false>(a, gp, split2, f32, s);
 }
 
 }  // namespace
