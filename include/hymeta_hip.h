@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define HYMETA_ABI_VERSION 2
+#define HYMETA_ABI_VERSION 3
 
 typedef void* hymeta_stream_t;
 
@@ -160,10 +160,15 @@ typedef struct hymeta_gla_decode_args {
   int32_t qkv_splits, qkv_n;
   int32_t q_col, k_col, v_col, g_col;
   /* Both linears of the low-rank gate inside the kernel (a checkpoint whose qkv projection is quantised cannot carry
-   * the gate's first linear as extra rows): with g_w0 bf16 [16, g_hidden] contiguous given (g_w1 required, no
-   * qkv_slabs), g is the LAYER INPUT, bf16 [batch, g_hidden] rows g_stride_b apart.  State per key/value head only. */
+   * the gate's first linear as extra rows): with g_w0 bf16 [16, g_hidden] contiguous given (g_w1 required), g is the
+   * LAYER INPUT, bf16 [batch, g_hidden] rows g_stride_b apart -- also beside qkv_slabs, whose g_col is then unused.
+   * State per key/value head only. */
   const void* g_w0;
   int32_t g_hidden;
+  /* qkv_slabs of a W8A8 projection: int32 slabs, finished as hymeta_w8a8_gemm finishes them (x_scale fp32 [batch],
+   * w_scale fp32 [qkv_n], 16-byte aligned; both or neither).  State per key/value head only. */
+  const float* qkv_x_scale;
+  const float* qkv_w_scale;
 } hymeta_gla_decode_args;
 
 int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stream_t stream);

@@ -223,6 +223,47 @@ def test_gla_decode_reads_the_projection_from_its_partial_sums():
     assert torch.equal(out_a, out_b) and torch.equal(s_a, s_b)
 
 
+@pytest.mark.parametrize("kind", ["w8a8", "gptq4", "gptq8"])
+def test_gla_decode_reads_a_quantised_projection_from_its_partial_sums(kind):
+    """7B GLA layer of a quantised checkpoint, pure decode: q, k, v from the K-slice sums of the quantised qkv projection
+    (int32 slabs with the W8A8 scales, fp32 slabs for GPTQ) and both linears of the gate applied to the layer input inside
+    the kernel give the outputs and states of the run on the finished projection, bit for bit."""
+    from test_gpu_quant import _gptq_problem
+    from vllm_hymeta import hip_ops, _C
+    from vllm_hymeta.linear import HymetaLinear
+
+    B, H, Hkv, hidden = 23, 28, 4, 3584
+    QKV = (H + 2 * Hkv) * D
+    g_ = gen(9)
+    x = randn_bf16(g_, B, hidden).cuda()
+    bias = randn_bf16(g_, QKV, scale=0.1).cuda()
+    if kind == "w8a8":
+        qw = torch.randint(-127, 128, (QKV, hidden), generator=g_, dtype=torch.int8).cuda()
+        ws = (torch.rand(QKV, generator=g_) * (2.0 / 127) * hidden ** -0.5).float().cuda()
+        lin = HymetaLinear.from_w8a8(qw, ws, bias=bias)
+    else:
+        bits, group = (4, 128) if kind == "gptq4" else (8, 64)
+        qw, qz, scales = _gptq_problem(5, hidden, QKV, bits, group, torch.float16)
+        lin = HymetaLinear.from_gptq(qw.cuda(), qz.cuda(), scales.cuda(), bits, group, bias=bias)
+    w0 = randn_bf16(g_, 16, hidden, scale=hidden ** -0.5).cuda()
+    w1, b1 = randn_bf16(g_, Hkv * D, 16, scale=0.5).cuda(), randn_bf16(g_, Hkv * D, scale=0.1).cuda()
+    w = (1 + 0.1 * torch.randn(D, generator=g_)).to(torch.bfloat16).cuda()
+    state = randn_bf16(g_, B + 2, Hkv, D, D, scale=0.1).cuda()
+    slot = torch.randperm(B + 2, generator=g_)[:B].to(torch.int32).cuda()
+    kw = dict(gate_mode=_C.GATE_7B, out_norm_weight=w, out_norm_eps=1e-6, g_w0=w0, g_w1=w1, g_bias=b1)
+    qkv = lin(x)
+    q, k, v = qkv[:, : H * D].view(B, H, D), qkv[:, H * D:(H + Hkv) * D].view(B, Hkv, D), qkv[:, (H + Hkv) * D:QKV].view(B, Hkv, D)
+    s_a = state.clone()
+    out_a = hip_ops.gla_decode(q, k, v, x, s_a, slot, **kw)
+    part = lin(x, defer=True)
+    assert isinstance(part, hip_ops.PartialSums) and bool(part.desc.is_int32) == (kind == "w8a8")
+    s_b = state.clone()
+    out_b = hip_ops.gla_decode((B, H, D), (B, Hkv, D), None, x, s_b, slot, qkv_partials=part,
+                               qkv_cols=(0, H * D, (H + Hkv) * D, 0), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b) and torch.equal(s_a, s_b)
+
+
 def test_gla_decode_follows_the_reference_kernels_rounding_points():
     """The kernel's bf16 outputs against the restatement that the reference's own Triton kernel pins bit for bit
     (tests/test_ref_fixtures.py): q * scale rounded to bf16 with the scale itself rounded to bf16

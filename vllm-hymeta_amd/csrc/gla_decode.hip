@@ -24,6 +24,7 @@ namespace hymeta {
 __device__ __forceinline__ hymeta_gemm_partials qkv_partials(const hymeta_gla_decode_args& a) {
   hymeta_gemm_partials p = hymeta::make_args<hymeta_gemm_partials>();
   p.slabs = a.qkv_slabs, p.splits = a.qkv_splits, p.bias = a.qkv_bias, p.M = a.batch, p.N = a.qkv_n;
+  p.x_scale = a.qkv_x_scale, p.w_scale = a.qkv_w_scale, p.is_int32 = a.qkv_x_scale != nullptr;
   return p;
 }
 
@@ -304,9 +305,10 @@ __global__ __launch_bounds__(THREADS) void gla_decode_group_kernel(hymeta_gla_de
   const bool from_slabs = a.qkv_slabs != nullptr;
   if (from_slabs) {
     // the whole workgroup sums the slices of its (REP + 2) x 128 input values (+ the 16 rank columns) in 4-column pieces
+    // (with the gate's first linear in this kernel the projection carries no rank columns)
     const hymeta_gemm_partials qp_ = qkv_partials(a);
     constexpr int kPer = D / 4;
-    for (int item = tid; item < (REP + 2) * kPer + 4; item += THREADS) {
+    for (int item = tid; item < (REP + 2) * kPer + (GATE_X ? 0 : 4); item += THREADS) {
       const int row = item / kPer, c4 = item % kPer;
       int col;
       float* dst;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(THREADS) void gla_decode_group_kernel(hymeta_gla_de
       else if (row == REP) col = a.k_col + kvh * D + 4 * c4, dst = &s_in[REP][4 * c4];
       else if (row == REP + 1) col = a.v_col + kvh * D + 4 * c4, dst = &s_in[REP + 1][4 * c4];
       else col = a.g_col + 4 * c4, dst = &s_t[4 * c4];
-      *reinterpret_cast<f32x4*>(dst) = partial_row4(qp_, b, col);
+      *reinterpret_cast<f32x4*>(dst) = qp_.is_int32 ? partial_row4<true>(qp_, b, col) : partial_row4<false>(qp_, b, col);
     }
     __syncthreads();
   }
@@ -534,7 +536,8 @@ extern "C" int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stre
     if (a.q_col < 0 || a.q_col + a.num_heads * a.head_dim > a.qkv_n || a.k_col < 0 || a.k_col + a.num_kv_heads * a.head_dim > a.qkv_n ||
         a.v_col < 0 || a.v_col + a.num_kv_heads * a.head_dim > a.qkv_n)
       return HYMETA_ERR_INVALID_ARG;
-    if (a.g_w1 != nullptr && (a.g_col < 0 || a.g_col + 16 > a.qkv_n)) return HYMETA_ERR_INVALID_ARG;
+    if (a.g_w1 != nullptr && a.g_w0 == nullptr && (a.g_col < 0 || a.g_col + 16 > a.qkv_n)) return HYMETA_ERR_INVALID_ARG;
+    if ((a.qkv_x_scale == nullptr) != (a.qkv_w_scale == nullptr)) return HYMETA_ERR_INVALID_ARG;
     if ((a.gate_mode == HYMETA_GATE_NONE || a.gate_mode == HYMETA_GATE_7B) && !a.g_w1) return HYMETA_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(a.qkv_slabs) | reinterpret_cast<uintptr_t>(a.qkv_bias)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
     if (!a.out || !a.state || !a.slot_idx) return HYMETA_ERR_INVALID_ARG;
@@ -553,8 +556,8 @@ extern "C" int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stre
     if ((reinterpret_cast<uintptr_t>(a.g) | reinterpret_cast<uintptr_t>(a.g_w1)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
   }
   if (a.g_w0 != nullptr) {      // both linears in the kernel: g = the layer input, bf16 [batch, g_hidden]
-    if (!a.g_w1 || from_slabs || a.g_hidden <= 0 || a.g_hidden % 8 != 0) return HYMETA_ERR_INVALID_ARG;
-    if (reinterpret_cast<uintptr_t>(a.g_w0) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
+    if (!a.g_w1 || !a.g || a.g_dtype != HYMETA_BF16 || a.g_stride_b % 8 != 0 || a.g_hidden <= 0 || a.g_hidden % 8 != 0) return HYMETA_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(a.g_w0) | reinterpret_cast<uintptr_t>(a.g) | reinterpret_cast<uintptr_t>(a.g_w1)) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
     const int sh = a.state_heads == 0 ? a.num_heads : a.state_heads;
     if (sh == a.num_heads) return HYMETA_ERR_UNSUPPORTED;   // the kernels of the state per key/value head only
   }
@@ -580,6 +583,8 @@ extern "C" int hymeta_gla_decode(const hymeta_gla_decode_args* args, hymeta_stre
   // a state shared by a group needs a gate that is the same for every query head of the group
   if (grouped && a.gate_mode == HYMETA_GATE_70B_LOWER_BOUND) return HYMETA_ERR_INVALID_ARG;
   if (grouped && rep > 8) return HYMETA_ERR_UNSUPPORTED;
+  if (!grouped && from_slabs && a.qkv_x_scale != nullptr) return HYMETA_ERR_UNSUPPORTED;      // int32 slabs: the grouped kernels only
+  if (from_slabs && a.qkv_x_scale != nullptr && reinterpret_cast<uintptr_t>(a.qkv_w_scale) % 16 != 0) return HYMETA_ERR_UNSUPPORTED;
 
   hipStream_t s = begin_launches(stream);
   const bool f32 = a.state_dtype == HYMETA_F32;

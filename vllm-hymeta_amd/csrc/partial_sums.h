@@ -107,24 +107,36 @@ __device__ __forceinline__ void partial_row8_x2(const hymeta_gemm_partials& p, i
   }
 }
 
-// 4 consecutive columns of row t (fp32 slabs only; col a multiple of 4), as bf16-rounded floats.
+// 4 consecutive columns of row t (col a multiple of 4), as bf16-rounded floats.
+template <bool I8>
 __device__ __forceinline__ f32x4 partial_row4(const hymeta_gemm_partials& p, int64_t t, int col) {
   const int64_t slab = static_cast<int64_t>(p.M) * p.N;
-  const float* src = static_cast<const float*>(p.slabs) + t * p.N + col;
-  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  typedef typename std::conditional<I8, i32x4, f32x4>::type vec_t;
+  const char* src = static_cast<const char*>(p.slabs) + (t * p.N + col) * 4;
+  vec_t sum = {0, 0, 0, 0};
   for (int sp = 0; sp < p.splits; sp += 4) {
-    f32x4 v[4];
+    vec_t v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + static_cast<int64_t>(min(sp + i, p.splits - 1)) * slab);
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const vec_t*>(src + static_cast<int64_t>(min(sp + i, p.splits - 1)) * slab * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       if (sp + i < p.splits) sum += v[i];
   }
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
   if (p.bias != nullptr) {
     const u32x2 bw = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(p.bias) + col);
-    sum += f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
+    b = f32x4{lo_bf(bw[0]), hi_bf(bw[0]), lo_bf(bw[1]), hi_bf(bw[1])};
   }
-  return f32x4{bf16_round(sum[0]), bf16_round(sum[1]), bf16_round(sum[2]), bf16_round(sum[3])};
+  f32x4 y;
+  if constexpr (I8) {
+    const float xs = p.x_scale[t];
+    const f32x4 ws = *reinterpret_cast<const f32x4*>(p.w_scale + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = w8a8_scaled(sum[e], xs, ws[e], b[e]);
+  } else {
+    y = sum + b;
+  }
+  return f32x4{bf16_round(y[0]), bf16_round(y[1]), bf16_round(y[2]), bf16_round(y[3])};
 }
 
 // One column of row t (fp32 slabs only), as a bf16-rounded float.

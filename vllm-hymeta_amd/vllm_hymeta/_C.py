@@ -24,7 +24,7 @@ GATE_7B = 1
 GATE_70B_CLAMP = 2
 GATE_70B_LOWER_BOUND = 3
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ERR_SCRATCH_LIMIT = -5
 GEMM_TICKET_BYTES = 16384
 STATIC_SCRATCH_BYTES = 16 << 20
@@ -61,6 +61,7 @@ class GlaDecodeArgs(_Args):
         ("qkv_slabs", _ptr), ("qkv_bias", _ptr), ("qkv_splits", _i32), ("qkv_n", _i32),
         ("q_col", _i32), ("k_col", _i32), ("v_col", _i32), ("g_col", _i32),
         ("g_w0", _ptr), ("g_hidden", _i32),
+        ("qkv_x_scale", _ptr), ("qkv_w_scale", _ptr),
     ]
 
 

@@ -79,15 +79,17 @@ def gla_decode(
     [16, hidden] as well, ``g`` is the layer input bf16 [B, hidden] and the kernel applies both linears (state per
     key/value head only).
 
-    ``qkv_partials`` (fp32 ``PartialSums`` of the fused qkv projection) with ``qkv_cols = (q_col, k_col, v_col, g_col)``:
+    ``qkv_partials`` (``PartialSums`` of the fused qkv projection) with ``qkv_cols = (q_col, k_col, v_col, g_col)``:
     q, k, v and the rank-16 gate input are read from the partial sums (the projection's reduce launch is skipped); then
     ``q`` / ``k`` / ``v`` / ``g`` are given as shapes only: ``(B, H, D)``, ``(B, Hkv, D)``, ``(B, Hkv, D)``, None.
+    With ``g_w0`` as well (a quantised projection carries no rank columns; its partial sums may be the int32 ones of a
+    W8A8 linear) ``g`` is the layer input bf16 [B, hidden] and ``g_col`` is unused; state per key/value head only.
 
     Returns out [B,H,D] bf16 (rows of skipped sequences, slot -1, are left as they were).
     """
     if qkv_partials is not None:
         return _gla_decode_from_partials(q, k, qkv_partials, qkv_cols, state, slot_idx, scale, out, gate_mode, gate_normalizer,
-                                         gate_clamp, out_norm_weight, out_norm_eps, g_w1, g_bias)
+                                         gate_clamp, out_norm_weight, out_norm_eps, g_w1, g_bias, g, g_w0)
     _dev(q, k, v, g, state, slot_idx, lower_bound, out_norm_weight)
     B, H, D = q.shape
     Hkv = k.shape[1]
@@ -155,12 +157,21 @@ def gla_decode(
 
 
 def _gla_decode_from_partials(q_shape, k_shape, partials, cols, state, slot_idx, scale, out, gate_mode, gate_normalizer,
-                              gate_clamp, out_norm_weight, out_norm_eps, g_w1, g_bias) -> torch.Tensor:
+                              gate_clamp, out_norm_weight, out_norm_eps, g_w1, g_bias, g=None, g_w0=None) -> torch.Tensor:
     partials.check_live()
     B, H, D = q_shape
     Hkv = k_shape[1]
-    _dev(state, slot_idx, out_norm_weight, g_w1, g_bias, out)
-    _require(partials.shape[0] == B and not partials.desc.is_int32, "partial sums must be fp32 slabs of B rows")
+    _dev(state, slot_idx, out_norm_weight, g_w1, g_bias, out, g, g_w0)
+    _require(partials.shape[0] == B, "partial sums must be slabs of B rows")
+    _require(not partials.desc.is_int32 or state.shape[1] == Hkv != H, "int32 partial sums: state per key/value head only")
+    if g_w0 is not None:
+        _require(g_w0.dtype == torch.bfloat16 and g_w0.is_contiguous() and g_w0.dim() == 2 and g_w0.shape[0] == 16
+                 and g_w0.shape[1] % 8 == 0 and state.shape[1] == Hkv != H,
+                 "g_w0 must be contiguous bf16 [16, hidden], with a state per key/value head")
+        _require(g is not None and g.shape == (B, g_w0.shape[1]) and g.dtype == torch.bfloat16 and g.stride(1) == 1 and g.stride(0) % 8 == 0,
+                 "with g_w0, g must be the layer input bf16 [B, hidden] with rows a multiple of 8 elements apart")
+    else:
+        _require(g is None, "partial-sum inputs carry the rank-16 gate input themselves (or give g_w0 and the layer input)")
     _require(gate_mode == _C.GATE_7B and g_w1 is not None, "partial-sum inputs are wired for the 7B low-rank gate")
     _require(g_w1.dtype == torch.bfloat16 and g_w1.is_contiguous() and g_w1.shape == (Hkv * D, 16), "g_w1 must be contiguous bf16 [Hkv*D, 16]")
     _require(g_bias is None or (g_bias.dtype == torch.bfloat16 and g_bias.is_contiguous() and g_bias.numel() == Hkv * D),
@@ -187,7 +198,11 @@ def _gla_decode_from_partials(q_shape, k_shape, partials, cols, state, slot_idx,
     a.g_w1, a.g_bias = _p(g_w1), _p(g_bias)
     d = partials.desc
     a.qkv_slabs, a.qkv_bias, a.qkv_splits, a.qkv_n = d.slabs, d.bias, d.splits, d.N
+    if d.is_int32:
+        a.qkv_x_scale, a.qkv_w_scale = d.x_scale, d.w_scale
     a.q_col, a.k_col, a.v_col, a.g_col = (int(c) for c in cols)
+    if g_w0 is not None:
+        a.g, a.g_stride_b, a.g_w0, a.g_hidden = _p(g), g.stride(0), _p(g_w0), g_w0.shape[1]
     _C.check(_C.load().hymeta_gla_decode(C.byref(a), _stream(out)), "hymeta_gla_decode")
     return out
 

@@ -66,20 +66,25 @@ class GatedLinearAttention(torch.nn.Module):
                     out_norm_weight=self.g_norm_weight, out_norm_eps=self.norm_eps)
         # a pure decode step with the gate in the projection: the recurrence kernel reads q, k, v and the gate's rank-16
         # input straight from the projection's K-slice sums (no reduce launch for the projection)
-        qkv = self.qkv_proj(hidden_states, defer=self.gate_in_qkv and n_pre == 0)
-        if isinstance(qkv, hip_ops.PartialSums):
-            QKV = self.qkv_features
-            out = hip_ops.gla_decode((T, H, D), (T, Hkv, D), None, None, gla_cache, state_indices_tensor, g_w1=p1.weight, g_bias=p1.bias,
-                                     qkv_partials=qkv, qkv_cols=(0, H * D, (H + Hkv) * D, QKV), **gate)
-            reduce = parallel._active(self.tp_group)
-            y = self.o_proj(out.view(T, H * D), defer=defer_out and not reduce)
-            return all_reduce_sum(y, self.tp_group) if reduce else y
-        gk = rank16 = None
         # a quantised checkpoint (its gate projection is not quantised): on a pure decode step with a state per key/value
         # head the recurrence kernel applies both of the gate's linears to the layer input itself
         gate_in_kernel = (not self.gate_in_qkv and n_pre == 0 and T > 0 and gla_cache.shape[1] == Hkv != H
                           and p0.kind == "bf16" and p1.kind == "bf16" and p0.bias is None and p0.weight.shape[0] == 16
                           and p0.weight.is_contiguous() and p1.weight.is_contiguous() and hidden_states.stride(0) % 8 == 0)
+        qkv = self.qkv_proj(hidden_states, defer=(self.gate_in_qkv or gate_in_kernel) and n_pre == 0)
+        if isinstance(qkv, hip_ops.PartialSums):
+            QKV = self.qkv_features
+            if self.gate_in_qkv:
+                out = hip_ops.gla_decode((T, H, D), (T, Hkv, D), None, None, gla_cache, state_indices_tensor, g_w1=p1.weight,
+                                         g_bias=p1.bias, qkv_partials=qkv, qkv_cols=(0, H * D, (H + Hkv) * D, QKV), **gate)
+            else:       # quantised projection: q, k, v from its partial sums, the gate from the layer input
+                out = hip_ops.gla_decode((T, H, D), (T, Hkv, D), None, hidden_states, gla_cache, state_indices_tensor,
+                                         g_w0=p0.weight, g_w1=p1.weight, g_bias=p1.bias, qkv_partials=qkv,
+                                         qkv_cols=(0, H * D, (H + Hkv) * D, 0), **gate)
+            reduce = parallel._active(self.tp_group)
+            y = self.o_proj(out.view(T, H * D), defer=defer_out and not reduce)
+            return all_reduce_sum(y, self.tp_group) if reduce else y
+        gk = rank16 = None
         if gate_in_kernel:
             q = qkv[:, : H * D].view(T, H, D)
             k = qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
