@@ -194,6 +194,42 @@ def test_gla_decode_rejects_bad_arguments():
         hip_ops.gla_decode(q.float(), q, q, q, st, slot)
 
 
+def test_gla_decode_rejects_inconsistent_partial_sum_arguments():
+    """Through the C ABI: W8A8 scales of the partial sums come in pairs; int32 slabs need the state per key/value head."""
+    import ctypes as C
+    from vllm_hymeta import _C
+
+    B, H, Hkv = 2, 28, 4
+    dev = "cuda"
+    out = torch.zeros(B, H, D, dtype=torch.bfloat16, device=dev)
+    slabs = torch.zeros(2, B, (H + 2 * Hkv) * D, dtype=torch.int32, device=dev)
+    scale = torch.ones((H + 2 * Hkv) * D, dtype=torch.float32, device=dev)
+    w1 = torch.zeros(Hkv * D, 16, dtype=torch.bfloat16, device=dev)
+    w0 = torch.zeros(16, 256, dtype=torch.bfloat16, device=dev)
+    x = torch.zeros(B, 256, dtype=torch.bfloat16, device=dev)
+    slot = torch.arange(B, dtype=torch.int32, device=dev)
+
+    def call(state, **fields):
+        a = _C.GlaDecodeArgs()
+        a.out, a.state, a.slot_idx = out.data_ptr(), state.data_ptr(), slot.data_ptr()
+        a.batch, a.num_heads, a.num_kv_heads, a.head_dim = B, H, Hkv, D
+        a.out_stride_b, a.out_stride_h = out.stride(0), out.stride(1)
+        a.state_stride_slot, a.state_stride_h, a.state_heads = state.stride(0), state.stride(1), state.shape[1]
+        a.gate_mode, a.g_w1, a.g_w0, a.g_hidden, a.g, a.g_stride_b = _C.GATE_7B, w1.data_ptr(), w0.data_ptr(), 256, x.data_ptr(), 256
+        a.qkv_slabs, a.qkv_splits, a.qkv_n = slabs.data_ptr(), 2, slabs.shape[2]
+        a.q_col, a.k_col, a.v_col = 0, H * D, (H + Hkv) * D
+        for k, v in fields.items():
+            setattr(a, k, v)
+        return _C.load().hymeta_gla_decode(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    grouped = torch.zeros(B, Hkv, D, D, dtype=torch.bfloat16, device=dev)
+    per_head = torch.zeros(B, H, D, D, dtype=torch.bfloat16, device=dev)
+    assert call(grouped, qkv_x_scale=scale.data_ptr(), qkv_w_scale=scale.data_ptr()) == 0
+    assert call(grouped, qkv_x_scale=scale.data_ptr()) == -1                  # one scale without the other
+    assert call(per_head, qkv_x_scale=scale.data_ptr(), qkv_w_scale=scale.data_ptr()) == -2      # state per query head
+    torch.cuda.synchronize()
+
+
 def test_gla_decode_reads_the_projection_from_its_partial_sums():
     """7B GLA layer, pure decode: q, k, v and the gate's rank-16 input taken from the K-slice sums of the fused qkv (+ gate)
     projection give the outputs and states of the run on the finished projection, bit for bit."""
