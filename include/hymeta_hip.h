@@ -25,7 +25,8 @@
  * Versioning
  *  - hymeta_abi_version() returns the HYMETA_ABI_VERSION the library was built
  *    with; a binding compares it with the header it was written against before
- *    the first call (version 2: every argument struct starts with struct_size).
+ *    the first call (version 2: every argument struct starts with struct_size;
+ *    version 3: hymeta_gla_decode_args ends with qkv_x_scale / qkv_w_scale).
  *  - Every argument struct starts with `uint32_t struct_size`, which the caller
  *    sets to sizeof(the struct) of ITS declaration.  An entry point returns
  *    HYMETA_ERR_INVALID_ARG, before it reads any other field, when the value
